@@ -1,0 +1,122 @@
+/* ydorb C ABI — the drop-in boundary of the MI355X-native ORB / matcher / local-BA hot path.
+ *
+ * The reference (WeiZhang1988/YDORBSLAM) has no FFI layer: its hot path sits behind three C++
+ * classes linked into libslam.so (src/CMakeLists.txt:14-31).  This header is the flat C ABI a
+ * maintainer binds those classes to; include/ydorb/*.hpp are the adapter classes with the
+ * reference's own signatures.  Every entry point cites the reference interface it replaces.
+ *
+ * Conventions: plain pointers + sizes, caller-owned buffers, opaque handles, int status return
+ * (0 = YDORB_OK, <0 = error; ydorb_last_error() gives text).  No exceptions cross the ABI.
+ * "d_" pointers are device (HBM) addresses, everything else is host memory.
+ * A handle owns one HIP stream; distinct handles may be used concurrently from distinct threads
+ * (the reference runs two extractors on two transient threads, src/frame.cpp:84-87).
+ */
+#ifndef YDORB_C_API_H
+#define YDORB_C_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YDORB_OK 0
+#define YDORB_ERR_INVALID_ARG -1
+#define YDORB_ERR_NO_DEVICE -2     /* HIP runtime / gfx950 device not usable: there is NO CPU fallback */
+#define YDORB_ERR_HIP -3           /* a HIP call failed */
+#define YDORB_ERR_CAPACITY -4      /* caller buffer or internal scratch too small */
+#define YDORB_ERR_UNSUPPORTED -5
+#define YDORB_ERR_NUMERIC -6       /* BA: non-finite state */
+
+const char* ydorb_last_error(void);
+/* number of usable gfx950 devices (0 if none); never throws */
+int ydorb_device_count(void);
+const char* ydorb_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * cv::KeyPoint-compatible POD: 7 x 4 bytes, no padding (what extractAndCompute fills,
+ * src/orbExtractor.cpp:355-399).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct YdKeyPoint {
+  float x, y;       /* pt, level-0 pixel units (level coords * scaleFactor[octave]) */
+  float size;       /* (float)(int)(31 * scaleFactor[octave])   orbExtractor.cpp:595,600 */
+  float angle;      /* degrees [0,360), cv::fastAtan2            orbExtractor.cpp:419 */
+  float response;   /* FAST-9/16 corner score */
+  int32_t octave;
+  int32_t class_id; /* -1 */
+} YdKeyPoint;
+
+/* ------------------------------------------------------------------------------------------
+ * ORB extractor.  Replaces YDORBSLAM::OrbExtractor (src/orbExtractor.hpp:31-74).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct YdExtractorConfig {
+  int32_t n_features;    /* OrbExtractor ctor args, src/orbExtractor.cpp:315-317 */
+  float scale_factor;
+  int32_t n_levels;      /* 1..8 */
+  int32_t ini_fast_thr;
+  int32_t min_fast_thr;  /* accepted and, like the reference (:318), replaced by ini_fast_thr */
+  int32_t device;        /* HIP device ordinal */
+  int32_t max_batch;     /* frames per launch the scratch is sized for (>=1) */
+  int32_t reserved;
+} YdExtractorConfig;
+
+typedef struct ydorb_extractor ydorb_extractor_t;
+
+/* OrbExtractor::OrbExtractor, src/orbExtractor.cpp:315-354 */
+int ydorb_extractor_create(const YdExtractorConfig* cfg, ydorb_extractor_t** out);
+void ydorb_extractor_destroy(ydorb_extractor_t* h);
+
+/* getScaleFactors / getInvScaleFactors / getScaleFactorSquares / getInvScaleFactorSquares and the
+ * per-level keypoint quotas (src/orbExtractor.hpp:42-49, orbExtractor.cpp:325-339).  Each output may
+ * be NULL; arrays hold n_levels entries. */
+int ydorb_extractor_tables(const ydorb_extractor_t* h, float* scale, float* inv_scale, float* scale_sq,
+                           float* inv_scale_sq, int32_t* per_level);
+/* upper bound of keypoints one frame can return (sum of the per-level quotas) */
+int ydorb_extractor_max_keypoints(const ydorb_extractor_t* h);
+
+/* OrbExtractor::extractAndCompute(image, keypoints, descriptors), src/orbExtractor.cpp:355-399.
+ * img: 8-bit gray, `stride` bytes per row (host).  kps/desc: caller buffers for `cap` keypoints
+ * (desc is cap x 32 bytes, row-major like the CV_8U Mat at :373).  *n_out = keypoints written.
+ * Empty image (w<=0||h<=0||!img) returns YDORB_OK with *n_out = 0, like :357-359. */
+int ydorb_extract(ydorb_extractor_t* h, const uint8_t* img, int32_t w, int32_t hgt, int32_t stride,
+                  YdKeyPoint* kps, uint8_t* desc, int32_t cap, int32_t* n_out);
+
+/* Batched form of the same call: n_frames images of identical size, frame f at img + f*frame_stride.
+ * Outputs: frame f's keypoints at kps + f*cap, descriptors at desc + f*cap*32, count at n_out[f]. */
+int ydorb_extract_batch(ydorb_extractor_t* h, const uint8_t* img, int32_t w, int32_t hgt, int32_t stride,
+                        size_t frame_stride, int32_t n_frames, YdKeyPoint* kps, uint8_t* desc, int32_t cap,
+                        int32_t* n_out);
+
+/* Device-resident batched form (inputs and outputs in HBM, asynchronous on the handle's stream or
+ * on `stream` (a hipStream_t) when non-NULL; no host synchronisation).  cap must be >=
+ * ydorb_extractor_max_keypoints().  d_n_out: int32[n_frames]. */
+int ydorb_extract_batch_device(ydorb_extractor_t* h, const uint8_t* d_img, int32_t w, int32_t hgt, int32_t stride,
+                               size_t frame_stride, int32_t n_frames, YdKeyPoint* d_kps, uint8_t* d_desc,
+                               int32_t cap, int32_t* d_n_out, void* stream);
+int ydorb_extractor_synchronize(ydorb_extractor_t* h);
+
+/* m_v_imagePyramid[level] of the last call (public member read by src/frame.cpp:366,412-427):
+ * device pointer to the level's ROI origin inside its 19-px reflect-101 padded buffer. */
+int ydorb_extractor_pyramid(const ydorb_extractor_t* h, int32_t frame, int32_t level, const uint8_t** d_roi,
+                            int32_t* w, int32_t* hgt, int32_t* stride);
+/* Copy one padded level ((hgt+38) rows x (w+38) bytes, tightly packed) of the last call to host. */
+int ydorb_extractor_read_level(ydorb_extractor_t* h, int32_t frame, int32_t level, uint8_t* dst, size_t dst_bytes);
+
+/* Test/diagnostic access to intermediate stages of the last call (parity tests compare each stage
+ * with the oracle).  what: 0 = blurred level (hgt x w bytes), 1 = pre-quad-tree candidates
+ * (YdKeyPoint[], border-relative coords as at orbExtractor.cpp:587-589), 2 = per-level keypoints after
+ * orientation (YdKeyPoint[], level coords).  Returns bytes written in *written. */
+int ydorb_extractor_debug_read(ydorb_extractor_t* h, int32_t what, int32_t frame, int32_t level, void* dst,
+                               size_t dst_bytes, size_t* written);
+
+/* Average device time (ms) of each pipeline stage over the calls since the last reset, measured with
+ * HIP events on the handle's stream when profiling is enabled.  names: out array of static strings. */
+int ydorb_extractor_set_profiling(ydorb_extractor_t* h, int32_t on);
+int ydorb_extractor_stage_times(ydorb_extractor_t* h, int32_t max_stages, const char** names, float* ms,
+                                int32_t* n_stages);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YDORB_C_API_H */

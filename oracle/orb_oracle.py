@@ -1,0 +1,178 @@
+"""ctypes front-end to oracle/liborb_oracle.so (CPU restatement of the reference hot path).
+
+ORACLE — TEST INFRASTRUCTURE ONLY.  Never imported by ydorbslam_amd.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liborb_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.yo_extractor_create.restype = C.c_void_p
+        L.yo_extractor_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.yo_extractor_destroy.argtypes = [C.c_void_p]
+        L.yo_extractor_set_libm_trig.argtypes = [C.c_void_p, C.c_int]
+        L.yo_extractor_set_stale_pyramid.argtypes = [C.c_void_p, C.c_int]
+        L.yo_extract.restype = C.c_int
+        L.yo_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.yo_extractor_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.yo_level_dims.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.yo_level_padded.restype = C.c_void_p
+        L.yo_level_padded.argtypes = [C.c_void_p, C.c_int]
+        L.yo_level_blurred.restype = C.c_void_p
+        L.yo_level_blurred.argtypes = [C.c_void_p, C.c_int]
+        L.yo_level_candidates.restype = C.c_int
+        L.yo_level_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.yo_level_keypoints.restype = C.c_int
+        L.yo_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.yo_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.yo_fast9_16.restype = C.c_int
+        L.yo_fast9_16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.yo_corner_score16.restype = C.c_int
+        L.yo_corner_score16.argtypes = [C.c_void_p, C.c_int]
+        L.yo_gaussian_blur_7x7_s2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.yo_gauss_kernel_fixed.argtypes = [C.c_int, C.c_double, C.c_int, C.c_void_p]
+        L.yo_fast_atan2.restype = C.c_float
+        L.yo_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.yo_cv_round.restype = C.c_int
+        L.yo_cv_round.argtypes = [C.c_float]
+        L.yo_reflect101.restype = C.c_int
+        L.yo_reflect101.argtypes = [C.c_int, C.c_int]
+        L.yo_cosf_det.restype = C.c_float
+        L.yo_cosf_det.argtypes = [C.c_float]
+        L.yo_sinf_det.restype = C.c_float
+        L.yo_sinf_det.argtypes = [C.c_float]
+        L.yo_trig_mismatch_count.restype = C.c_long
+        L.yo_trig_mismatch_count.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OrbExtractorOracle:
+    """Mirror of YDORBSLAM::OrbExtractor (orbExtractor.hpp:31-74) on numpy arrays."""
+
+    def __init__(self, n_features=1000, scale_factor=1.2, n_levels=8, ini_th=20, min_th=7):
+        self.L = lib()
+        self.n_levels = n_levels
+        self.n_features = n_features
+        self.h = self.L.yo_extractor_create(n_features, scale_factor, n_levels, ini_th, min_th)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.yo_extractor_destroy(self.h)
+            self.h = None
+
+    def set_libm_trig(self, on):
+        self.L.yo_extractor_set_libm_trig(self.h, int(on))
+
+    def set_stale_pyramid(self, on):
+        self.L.yo_extractor_set_stale_pyramid(self.h, int(on))
+
+    def tables(self):
+        n = self.n_levels
+        sf, isf, sf2, isf2 = (np.zeros(n, np.float32) for _ in range(4))
+        per = np.zeros(n, np.int32)
+        maxx = np.zeros(28, np.int32)
+        self.L.yo_extractor_tables(self.h, _p(sf), _p(isf), _p(sf2), _p(isf2), _p(per), _p(maxx))
+        return dict(scale=sf, inv_scale=isf, scale2=sf2, inv_scale2=isf2, per_level=per, max_x=maxx)
+
+    def extract(self, img, cap=None):
+        """extractAndCompute (orbExtractor.cpp:355): returns (keypoints[KP_DTYPE], descriptors[N,32] u8)."""
+        img = np.ascontiguousarray(img, np.uint8)
+        cap = cap or 4 * self.n_features + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = self.L.yo_extract(self.h, _p(img), img.shape[1], img.shape[0], img.strides[0], _p(kps), _p(desc), cap)
+        if n < 0:
+            raise RuntimeError("oracle: capacity exceeded")
+        return kps[:n].copy(), desc[:n].copy()
+
+    def level_dims(self, l):
+        w, h, s = C.c_int(), C.c_int(), C.c_int()
+        self.L.yo_level_dims(self.h, l, C.byref(w), C.byref(h), C.byref(s))
+        return w.value, h.value, s.value
+
+    def level_padded(self, l):
+        w, h, s = self.level_dims(l)
+        ptr = self.L.yo_level_padded(self.h, l)
+        buf = (C.c_uint8 * ((h + 38) * s)).from_address(ptr)
+        return np.frombuffer(buf, np.uint8).reshape(h + 38, s).copy()
+
+    def level_blurred(self, l):
+        w, h, _ = self.level_dims(l)
+        ptr = self.L.yo_level_blurred(self.h, l)
+        if not ptr:
+            return None
+        buf = (C.c_uint8 * (h * w)).from_address(ptr)
+        return np.frombuffer(buf, np.uint8).reshape(h, w).copy()
+
+    def level_candidates(self, l):
+        n = self.L.yo_level_candidates(self.h, l, None, 0)
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        self.L.yo_level_candidates(self.h, l, _p(out), n)
+        return out[:n]
+
+    def level_keypoints(self, l):
+        n = self.L.yo_level_keypoints(self.h, l, None, 0)
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        self.L.yo_level_keypoints(self.h, l, _p(out), n)
+        return out[:n]
+
+
+def resize_linear_u8(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().yo_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
+    return dst
+
+
+def fast9_16(img, thr, nms=True):
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = img.size
+    out = np.zeros(cap, KP_DTYPE)
+    n = lib().yo_fast9_16(_p(img), img.strides[0], img.shape[1], img.shape[0], thr, int(nms), _p(out), cap)
+    return out[:n].copy()
+
+
+def corner_score16(d25, thr):
+    d = np.ascontiguousarray(d25, np.int32)
+    return lib().yo_corner_score16(_p(d), thr)
+
+
+def gaussian_blur_7x7_s2(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros_like(img)
+    lib().yo_gaussian_blur_7x7_s2(_p(img), img.shape[1], img.shape[0], img.strides[0], _p(out), out.strides[0])
+    return out
+
+
+def gauss_kernel_fixed(n, sigma, bits):
+    out = np.zeros(n, np.int32)
+    lib().yo_gauss_kernel_fixed(n, sigma, bits, _p(out))
+    return out
+
+
+def fast_atan2(y, x):
+    return lib().yo_fast_atan2(float(y), float(x))

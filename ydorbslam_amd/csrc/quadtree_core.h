@@ -1,0 +1,331 @@
+// Quad-tree keypoint thinning for one (frame, pyramid level), written for ONE workgroup.
+//
+// Behaviour restated from reference src/orbExtractor.cpp:455-544 (distributeQuadTree) and :4-54
+// (QuadTreeNode::divideNode) — but re-designed as flat arrays + prefix sums so a 256..1024-thread
+// workgroup can run it with LDS-resident nodes:
+//   * the reference's std::list with push_front becomes an index formula: after one pass the list is
+//       [children of the LAST divisible node (n4,n3,n2,n1) ... children of the FIRST] ++ [old leaves],
+//     so a child's new index is a suffix sum over nodes of their non-empty child counts;
+//   * the per-node std::vector<KeyPoint> becomes a contiguous segment of a candidate array that is
+//     stably 4-way partitioned each pass with one block-wide scan of four packed 16-bit counters;
+//   * "best keypoint per node" = front() of libstdc++ std::sort by response (:536-539): ties are
+//     resolved exactly as introsort would (first max for <=16 elements, else the left-most partition
+//     chain of __introsort_loop is replayed), see qt_sort_front().
+// The same template runs single-threaded on the host (tests/cpu harness) and as a HIP workgroup.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define YD_HD __host__ __device__
+#else
+#define YD_HD
+#endif
+
+namespace ydorb {
+
+// candidate packing: x:12 | y:12 | response:8   (border-relative coords, orbExtractor.cpp:587-589)
+YD_HD inline uint32_t qt_pack(int x, int y, int r) { return (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)r << 24); }
+YD_HD inline int qt_x(uint32_t c) { return (int)(c & 0xFFFu); }
+YD_HD inline int qt_y(uint32_t c) { return (int)((c >> 12) & 0xFFFu); }
+YD_HD inline int qt_r(uint32_t c) { return (int)(c >> 24); }
+
+// The four numbers divideNode actually reads: tl.x, tr.x, tl.y, bl.y (:8-9).
+struct QtGeom { int16_t x0, x1, y0, y1; };
+
+YD_HD inline int qt_center(int a, int b) {  // ceil(float(a+b)/2.0) for small non-negative ints
+  return (a + b + 1) >> 1;
+}
+// child q = 0..3 <-> _node1.._node4 of divideNode, including the line-27 slip that gives node4 the
+// PARENT's top edge as its "bottom" (n3.br = (cx, tl.y); n4.bl = n3.br).
+YD_HD inline QtGeom qt_child(const QtGeom& g, int cx, int cy, int q) {
+  QtGeom c;
+  switch (q) {
+    case 0: c.x0 = g.x0; c.x1 = (int16_t)cx; c.y0 = g.y0; c.y1 = (int16_t)cy; break;
+    case 1: c.x0 = (int16_t)cx; c.x1 = g.x1; c.y0 = g.y0; c.y1 = (int16_t)cy; break;
+    case 2: c.x0 = g.x0; c.x1 = (int16_t)cx; c.y0 = (int16_t)cy; c.y1 = g.y1; break;
+    default: c.x0 = (int16_t)cx; c.x1 = g.x1; c.y0 = (int16_t)cy; c.y1 = g.y0; break;
+  }
+  return c;
+}
+YD_HD inline int qt_quadrant(uint32_t c, int cx, int cy) {  // :37-47
+  const bool l = qt_x(c) < cx, t = qt_y(c) < cy;
+  return l ? (t ? 0 : 2) : (t ? 1 : 3);
+}
+
+// ---- libstdc++ std::sort(first,last,[](a,b){return a.response>b.response;}) -> index of front() ----
+// keys[i] = (response << 16) | i ; comparison looks at the response only.
+YD_HD inline bool qt_gt(uint32_t a, uint32_t b) { return (a >> 16) > (b >> 16); }
+YD_HD inline void qt_swap(uint32_t* a, int i, int j) { uint32_t t = a[i]; a[i] = a[j]; a[j] = t; }
+
+YD_HD inline void qt_push_heap(uint32_t* a, int hole, int top, uint32_t v) {
+  int parent = (hole - 1) / 2;
+  while (hole > top && qt_gt(a[parent], v)) {
+    a[hole] = a[parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  a[hole] = v;
+}
+YD_HD inline void qt_adjust_heap(uint32_t* a, int hole, int len, uint32_t v) {
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (qt_gt(a[child], a[child - 1])) child--;
+    a[hole] = a[child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    a[hole] = a[child - 1];
+    hole = child - 1;
+  }
+  qt_push_heap(a, hole, top, v);
+}
+YD_HD inline void qt_heap_sort(uint32_t* a, int len) {  // __partial_sort(first,last,last)
+  if (len >= 2) {
+    int parent = (len - 2) / 2;
+    for (;;) {
+      uint32_t v = a[parent];
+      qt_adjust_heap(a, parent, len, v);
+      if (parent == 0) break;
+      parent--;
+    }
+  }
+  int last = len;
+  while (last > 1) {
+    --last;
+    uint32_t v = a[last];
+    a[last] = a[0];
+    qt_adjust_heap(a, 0, last, v);
+  }
+}
+// a[0..m): scratch holding the keys in member order; returns the member index that std::sort leaves at front().
+YD_HD inline int qt_sort_front(uint32_t* a, int m) {
+  int hi = m;
+  if (m > 16) {
+    int depth = 0;
+    for (int t = m; t > 1; t >>= 1) depth++;
+    depth *= 2;
+    while (hi > 16) {
+      if (depth == 0) {
+        qt_heap_sort(a, hi);
+        return (int)(a[0] & 0xFFFFu);
+      }
+      --depth;
+      const int mid = hi / 2;
+      {  // __move_median_to_first(first, first+1, mid, last-1)
+        const int x = 1, y = mid, z = hi - 1;
+        if (qt_gt(a[x], a[y])) {
+          if (qt_gt(a[y], a[z])) qt_swap(a, 0, y);
+          else if (qt_gt(a[x], a[z])) qt_swap(a, 0, z);
+          else qt_swap(a, 0, x);
+        } else if (qt_gt(a[x], a[z])) qt_swap(a, 0, x);
+        else if (qt_gt(a[y], a[z])) qt_swap(a, 0, z);
+        else qt_swap(a, 0, y);
+      }
+      int f = 1, l = hi;  // __unguarded_partition(first+1, last, pivot=first)
+      for (;;) {
+        while (qt_gt(a[f], a[0])) ++f;
+        --l;
+        while (qt_gt(a[0], a[l])) --l;
+        if (!(f < l)) break;
+        qt_swap(a, f, l);
+        ++f;
+      }
+      hi = f;  // recursion on [cut,last) never touches [first,cut)
+    }
+  }
+  // stable insertion sort of a block that dominates everything to its right: front = first maximum
+  int best = 0;
+  for (int i = 1; i < hi; i++)
+    if (qt_gt(a[i], a[best])) best = i;
+  return (int)(a[best] & 0xFFFFu);
+}
+
+// ---- workgroup algorithm -------------------------------------------------------------------------
+struct QtShared {           // LDS (device) / heap (host); arrays of nodeCap entries
+  QtGeom* geom[2];
+  uint32_t* cnt[2];
+  uint32_t* base[2];
+  unsigned long long* cc;   // packed 4x16 child counts; re-used as the segment-start prefix in sweep 2
+  uint16_t* childIdx;       // [nodeCap*4] new list index of child q (slot 0: own new index for a leaf)
+};
+struct QtGlobal {           // per (frame, level) scratch in HBM, n entries each
+  uint32_t* cand[2];
+  uint16_t* node[2];
+  uint32_t* sortKeys;
+};
+
+// Ctx: tid(), nthreads(), sync(), scan_incl_u64(v,&total), scan_incl_u32(v,&total), lds_add_u64(p,v)
+template <class Ctx>
+YD_HD int qt_distribute(Ctx& cx, const QtShared& S, const QtGlobal& G, int n, int rootX1, int rootY1, int quota,
+                        int nodeCap, uint32_t* out) {
+  const int tid = cx.tid(), nt = cx.nthreads();
+  if (n <= 0 || quota <= 0) return 0;  // resize(desired) of an empty or zero-quota list
+  int cur = 0;
+  if (tid == 0) {
+    S.geom[0][0] = QtGeom{0, (int16_t)rootX1, 0, (int16_t)rootY1};
+    S.cnt[0][0] = (uint32_t)n;
+    S.base[0][0] = 0;
+  }
+  for (int p = tid; p < n; p += nt) G.node[0][p] = 0;
+  cx.sync();
+  int K = 1, last = 0;
+  while (K > last && K < quota) {
+    last = K;
+    const int nxt = cur ^ 1;
+    const QtGeom* geom = S.geom[cur];
+    const uint32_t* cnt = S.cnt[cur];
+    const uint32_t* base = S.base[cur];
+    for (int k = tid; k < K; k += nt) S.cc[k] = 0;
+    cx.sync();
+    // sweep 1: child counts
+    for (int p = tid; p < n; p += nt) {
+      const int k = G.node[cur][p];
+      if (cnt[k] > 1) {
+        const QtGeom g = geom[k];
+        const int q = qt_quadrant(G.cand[cur][p], qt_center(g.x0, g.x1), qt_center(g.y0, g.y1));
+        cx.lds_add_u64(&S.cc[k], 1ull << (16 * q));
+      }
+    }
+    cx.sync();
+    // node phase A: number of new front nodes M (suffix sums) and rank of leaves
+    // processed in chunks in REVERSE list order so an inclusive prefix scan yields the suffix sum.
+    int M = 0;      // total children created
+    {
+      int carry = 0;
+      for (int c0 = 0; c0 < K; c0 += nt) {
+        const int kr = c0 + tid;          // reversed index
+        const int k = K - 1 - kr;
+        int m = 0;
+        unsigned long long ccv = 0;
+        if (kr < K && cnt[k] > 1) {
+          ccv = S.cc[k];
+          for (int q = 0; q < 4; q++) m += ((ccv >> (16 * q)) & 0xFFFF) != 0;
+        }
+        unsigned total;
+        const unsigned incl = cx.scan_incl_u32((unsigned)m, &total);
+        if (kr < K && cnt[k] > 1) {
+          int idx = carry + (int)incl - m;  // children of nodes after k come first
+          for (int q = 3; q >= 0; q--) {    // n4 is pushed last -> sits first
+            if ((ccv >> (16 * q)) & 0xFFFF) S.childIdx[k * 4 + q] = (uint16_t)idx++;
+          }
+        }
+        carry += (int)total;
+      }
+      M = carry;
+    }
+    int Knew = M;
+    {
+      int carry = 0;
+      for (int c0 = 0; c0 < K; c0 += nt) {
+        const int k = c0 + tid;
+        const unsigned leaf = (k < K && cnt[k] <= 1) ? 1u : 0u;
+        unsigned total;
+        const unsigned incl = cx.scan_incl_u32(leaf, &total);
+        if (leaf) S.childIdx[k * 4] = (uint16_t)(M + carry + (int)incl - 1);
+        carry += (int)total;
+      }
+      Knew += carry;
+    }
+    if (Knew > nodeCap) return -1;  // cannot happen for nodeCap >= 4*quota
+    cx.sync();
+    // node phase B: write the new node table
+    for (int k = tid; k < K; k += nt) {
+      const QtGeom g = geom[k];
+      if (cnt[k] > 1) {
+        const unsigned long long ccv = S.cc[k];
+        const int cxm = qt_center(g.x0, g.x1), cym = qt_center(g.y0, g.y1);
+        for (int q = 0; q < 4; q++) {
+          const uint32_t c = (uint32_t)((ccv >> (16 * q)) & 0xFFFF);
+          if (c) {
+            const int idx = S.childIdx[k * 4 + q];
+            S.geom[nxt][idx] = qt_child(g, cxm, cym, q);
+            S.cnt[nxt][idx] = c;
+          }
+        }
+      } else {
+        const int idx = S.childIdx[k * 4];
+        S.geom[nxt][idx] = g;
+        S.cnt[nxt][idx] = cnt[k];
+      }
+    }
+    cx.sync();
+    // node phase C: segment bases of the new list (exclusive scan of counts in new list order)
+    {
+      unsigned carry = 0;
+      for (int c0 = 0; c0 < Knew; c0 += nt) {
+        const int k = c0 + tid;
+        const unsigned v = k < Knew ? S.cnt[nxt][k] : 0u;
+        unsigned total;
+        const unsigned incl = cx.scan_incl_u32(v, &total);
+        if (k < Knew) S.base[nxt][k] = carry + incl - v;
+        carry += total;
+      }
+    }
+    cx.sync();
+    // sweep 2: stable 4-way partition (ordered scan of packed quadrant counters)
+    {
+      unsigned long long carry = 0;
+      for (int c0 = 0; c0 < n; c0 += nt) {
+        const int p = c0 + tid;
+        int k = 0, q = -1;
+        uint32_t c = 0;
+        unsigned long long v = 0;
+        if (p < n) {
+          k = G.node[cur][p];
+          c = G.cand[cur][p];
+          if (cnt[k] > 1) {
+            const QtGeom g = geom[k];
+            q = qt_quadrant(c, qt_center(g.x0, g.x1), qt_center(g.y0, g.y1));
+            v = 1ull << (16 * q);
+          }
+        }
+        unsigned long long total;
+        const unsigned long long incl = cx.scan_incl_u64(v, &total);
+        const unsigned long long excl = carry + incl - v;
+        if (p < n && (uint32_t)p == base[k]) S.cc[k] = excl;  // prefix at segment start
+        cx.sync();
+        if (p < n) {
+          int idx, rank;
+          if (q >= 0) {
+            idx = S.childIdx[k * 4 + q];
+            rank = (int)(((excl - S.cc[k]) >> (16 * q)) & 0xFFFF);
+          } else {
+            idx = S.childIdx[k * 4];
+            rank = 0;
+          }
+          const uint32_t np = S.base[nxt][idx] + (uint32_t)rank;
+          G.cand[nxt][np] = c;
+          G.node[nxt][np] = (uint16_t)idx;
+        }
+        carry += total;
+        cx.sync();
+      }
+    }
+    K = Knew;
+    cur = nxt;
+    cx.sync();
+  }
+  // best keypoint per node, list order, truncated to the quota (:534-543)
+  const int nOut = K < quota ? K : quota;
+  for (int k = tid; k < nOut; k += nt) {
+    const uint32_t b = S.base[cur][k], m = S.cnt[cur][k];
+    const uint32_t* seg = G.cand[cur] + b;
+    int best = 0;
+    if (m > 16) {
+      uint32_t* keys = G.sortKeys + b;
+      for (uint32_t i = 0; i < m; i++) keys[i] = ((uint32_t)qt_r(seg[i]) << 16) | i;
+      best = qt_sort_front(keys, (int)m);
+    } else {
+      for (uint32_t i = 1; i < m; i++)
+        if (qt_r(seg[i]) > qt_r(seg[best])) best = (int)i;
+    }
+    out[k] = seg[best];
+  }
+  cx.sync();
+  return nOut;
+}
+
+}  // namespace ydorb
