@@ -2,7 +2,7 @@
  *
  * The reference (WeiZhang1988/YDORBSLAM) has no FFI layer: its hot path sits behind three C++
  * classes linked into libslam.so (src/CMakeLists.txt:14-31).  This header is the flat C ABI a
- * maintainer binds those classes to; include/ydorb/*.hpp are the adapter classes with the
+ * maintainer binds those classes to; the .hpp files next to this header are the adapter classes with the
  * reference's own signatures.  Every entry point cites the reference interface it replaces.
  *
  * Conventions: plain pointers + sizes, caller-owned buffers, opaque handles, int status return

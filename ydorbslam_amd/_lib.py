@@ -1,0 +1,78 @@
+"""Loader for libydorb.so (the C-ABI product library).  Fails loudly; never substitutes a CPU path."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class YdorbError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "libydorb.so")
+
+
+def build_library(jobs=4):
+    """Compile every HIP source for gfx950 into ydorbslam_amd/libydorb.so (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", "-j%d" % jobs, "-C", os.path.join(_HERE, "csrc")])
+    return library_path()
+
+
+class YdKeyPoint(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float), ("angle", C.c_float),
+                ("response", C.c_float), ("octave", C.c_int32), ("class_id", C.c_int32)]
+
+
+class YdExtractorConfig(C.Structure):
+    _fields_ = [("n_features", C.c_int32), ("scale_factor", C.c_float), ("n_levels", C.c_int32),
+                ("ini_fast_thr", C.c_int32), ("min_fast_thr", C.c_int32), ("device", C.c_int32),
+                ("max_batch", C.c_int32), ("reserved", C.c_int32)]
+
+
+# every symbol include/ydorb/c_api.h declares: (restype, argtypes)
+_VP, _I, _Z = C.c_void_p, C.c_int32, C.c_size_t
+SYMBOLS = {
+    "ydorb_last_error": (C.c_char_p, []),
+    "ydorb_device_count": (C.c_int, []),
+    "ydorb_version": (C.c_char_p, []),
+    "ydorb_extractor_create": (C.c_int, [C.POINTER(YdExtractorConfig), C.POINTER(_VP)]),
+    "ydorb_extractor_destroy": (None, [_VP]),
+    "ydorb_extractor_tables": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    "ydorb_extractor_max_keypoints": (C.c_int, [_VP]),
+    "ydorb_extract": (C.c_int, [_VP, _VP, _I, _I, _I, _VP, _VP, _I, C.POINTER(_I)]),
+    "ydorb_extract_batch": (C.c_int, [_VP, _VP, _I, _I, _I, _Z, _I, _VP, _VP, _I, _VP]),
+    "ydorb_extract_batch_device": (C.c_int, [_VP, _VP, _I, _I, _I, _Z, _I, _VP, _VP, _I, _VP, _VP]),
+    "ydorb_extractor_synchronize": (C.c_int, [_VP]),
+    "ydorb_extractor_pyramid": (C.c_int, [_VP, _I, _I, C.POINTER(_VP), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "ydorb_extractor_read_level": (C.c_int, [_VP, _I, _I, _VP, _Z]),
+    "ydorb_extractor_debug_read": (C.c_int, [_VP, _I, _I, _I, _VP, _Z, C.POINTER(_Z)]),
+    "ydorb_extractor_set_profiling": (C.c_int, [_VP, _I]),
+    "ydorb_extractor_stage_times": (C.c_int, [_VP, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_I)]),
+}
+
+
+def lib():
+    """The loaded C-ABI library.  Raises YdorbError when it has not been built — there is no fallback."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise YdorbError("%s is missing: build it with ydorbslam_amd.build_library(); the hot path has no CPU fallback" % path)
+        try:
+            L = C.CDLL(path)
+        except OSError as e:
+            raise YdorbError("cannot load %s: %s" % (path, e))
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise YdorbError("ydorb error %d: %s" % (rc, lib().ydorb_last_error().decode()))

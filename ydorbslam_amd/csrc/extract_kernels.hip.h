@@ -1,0 +1,547 @@
+// gfx950 HIP kernels of the ORB front-end (pyramid, per-cell FAST-9/16 + NMS + ordered compaction,
+// quad-tree thinning, 7x7 Gaussian, intensity-centroid orientation, steered rBRIEF).
+//
+// Behaviour follows reference src/orbExtractor.cpp (cited per kernel); the structure does not: frames are
+// batched (grid.y/z = frame), every stage is one launch over all frames x levels, all intermediate
+// products stay in HBM/L2, and nothing returns to the host between the image upload and the
+// keypoint/descriptor download.  All arithmetic that decides a result bit is integer or single IEEE
+// operations (this TU is compiled with -ffp-contract=off).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "quadtree_core.h"
+
+#pragma clang fp contract(off)
+
+namespace ydorb {
+
+constexpr int kPad = 19;          // m_int_maxPadSize, orbExtractor.hpp:71
+constexpr int kBorder = 16;       // m_int_maxPadSize - 3, orbExtractor.cpp:549
+constexpr int kMaxLevels = 8;
+constexpr int kTileMax = 72;      // FAST cell sub-image is at most (59+1+6) px wide
+constexpr int kQtThreads = 512;
+
+struct LevelDev {
+  int w, h, pitch;          // interior size, padded-row pitch (bytes)
+  int padOff;               // byte offset of the padded buffer inside a frame's pyramid block
+  int blurOff, blurPitch;   // unpadded blurred level inside a frame's blur block
+  int cellBegin, nCells;    // this level's cells in the cell table
+  int quota;                // m_v_keyPointsNumsPerLevel[level]
+  int candOff;              // entry offset of the level's quad-tree scratch inside a frame's scratch
+  int kpOff;                // entry offset of the level's keypoints inside a frame's level-keypoint array
+  int tabOff;               // offset of the resize tables (level >= 1)
+  float scale;              // m_v_scaleFactors[level]
+  float size;               // (float)(int)(31 * scale), orbExtractor.cpp:595
+};
+struct PlanDev {
+  int nLevels, nCellsTotal, cellCap, sumQuota;
+  int maxX[16];             // m_v_maxXcords[0..15]
+  LevelDev lv[kMaxLevels];
+};
+struct CellDev {            // FAST sub-image [x0,x1) x [y0,y1) in level coordinates (orbExtractor.cpp:562-581)
+  short level, x0, y0, x1, y1, pad0, pad1, pad2;
+};
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+  return i;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pyramid level 0: copyMakeBorder(image, 19 px, BORDER_REFLECT_101)  (orbExtractor.cpp:618).
+// One thread writes 4 consecutive bytes of the padded buffer.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ img, int stride, size_t frameStride,
+                                                    uint8_t* __restrict__ pyr, size_t pyrFrameStride, LevelDev L) {
+  const int wx = blockIdx.x * 256 + threadIdx.x;
+  const int y = blockIdx.y;
+  if (wx * 4 >= L.pitch) return;
+  const uint8_t* src = img + (size_t)blockIdx.z * frameStride;
+  const int sy = reflect101(y - kPad, L.h);
+  uint32_t v = 0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const int x = wx * 4 + b - kPad;
+    if (x < L.w + kPad) v |= (uint32_t)src[(size_t)sy * stride + reflect101(x, L.w)] << (8 * b);
+  }
+  *reinterpret_cast<uint32_t*>(pyr + (size_t)blockIdx.z * pyrFrameStride + L.padOff + (size_t)y * L.pitch + wx * 4) = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pyramid level l>=1: cv::resize(level l-1, INTER_LINEAR) + reflect-101 border (orbExtractor.cpp:614-615).
+// Border pixels are recomputed from the reflected interior coordinate instead of re-read, so the level
+// is written exactly once.  Coefficient tables (11-bit fixed point) are built on the host.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, size_t pyrFrameStride, LevelDev Lp, LevelDev L,
+                                                    const int* __restrict__ xofs, const short* __restrict__ alpha,
+                                                    const int* __restrict__ yofs, const short* __restrict__ beta) {
+  const int wx = blockIdx.x * 256 + threadIdx.x;
+  const int y = blockIdx.y;
+  if (wx * 4 >= L.pitch) return;
+  uint8_t* frame = pyr + (size_t)blockIdx.z * pyrFrameStride;
+  const uint8_t* S = frame + Lp.padOff + (size_t)kPad * Lp.pitch + kPad;  // ROI origin of the source level
+  const int dy = reflect101(y - kPad, L.h);
+  const int sy = yofs[dy];
+  const int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+  const int sy0 = min(max(sy, 0), Lp.h - 1), sy1 = min(max(sy + 1, 0), Lp.h - 1);
+  const uint8_t* r0p = S + (size_t)sy0 * Lp.pitch;
+  const uint8_t* r1p = S + (size_t)sy1 * Lp.pitch;
+  uint32_t v = 0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const int x = wx * 4 + b - kPad;
+    if (x < L.w + kPad) {
+      const int dx = reflect101(x, L.w);
+      const int sx = xofs[dx];
+      const int a0 = alpha[2 * dx], a1 = alpha[2 * dx + 1];
+      const int sx1 = min(sx + 1, Lp.w - 1);  // a1 == 0 whenever sx+1 is outside
+      const int h0 = r0p[sx] * a0 + r0p[sx1] * a1;
+      const int h1 = r1p[sx] * a0 + r1p[sx1] * a1;
+      const int o = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      v |= (uint32_t)(o & 0xFF) << (8 * b);
+    }
+  }
+  *reinterpret_cast<uint32_t*>(frame + L.padOff + (size_t)y * L.pitch + wx * 4) = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST-9/16 segment test + corner score for one pixel (cv::FAST, call site orbExtractor.cpp:581).
+// ring[k], k=0..15 in circle order.  Returns 0 if not a corner, else the score (>= thr):
+//   score = max over the 16 arcs of 9 contiguous ring pixels of  min(v - p)  resp.  min(p - v),  minus 1
+// which equals OpenCV's cornerScore<16> recurrence for every pixel that passes the segment test.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fast_corner_score(int v, const int (&ring)[16], int thr) {
+  unsigned dark = 0, bright = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    dark |= (unsigned)(ring[k] < v - thr) << k;
+    bright |= (unsigned)(ring[k] > v + thr) << k;
+  }
+  auto run9 = [](unsigned m) {
+    m |= m << 16;
+    unsigned a = m & (m >> 1);
+    unsigned b = a & (a >> 2);
+    unsigned c = b & (b >> 4);
+    return (c & (m >> 8)) != 0;
+  };
+  const bool isDark = run9(dark), isBright = run9(bright);
+  if (!isDark && !isBright) return 0;
+  int d[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) d[k] = v - ring[k];
+  int best = thr;
+  if (isDark) {  // max over arcs of min(d)
+    int m2[16], m4[16], m8[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) m2[k] = min(d[k], d[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) m4[k] = min(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) m8[k] = min(m4[k], m4[(k + 4) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) best = max(best, min(m8[k], d[(k + 8) & 15]));
+  }
+  if (isBright) {  // max over arcs of min(-d) = -(min over arcs of max(d))
+    int m2[16], m4[16], m8[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) m2[k] = max(d[k], d[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) m4[k] = max(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) m8[k] = max(m4[k], m4[(k + 4) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) best = max(best, -max(m8[k], d[(k + 8) & 15]));
+  }
+  return best - 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// One workgroup per (cell, frame): cv::FAST(cell sub-image, thr, nms=true) — orbExtractor.cpp:562-590.
+// FAST never looks outside the sub-image, so each cell has a private 3-px dead border and NMS sees
+// zeros outside the cell's detection band.  Survivors are written in row-major order (the order
+// cv::FAST returns them) into the cell's fixed slot; the quad-tree kernel concatenates cells in
+// (row, col) order, which reproduces keyPointsToDistr.  The retry at :583 uses the same threshold
+// (m_int_minFastThd is initialised from _initFastThd, :318), so it is a no-op and is not launched.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyrFrameStride, PlanDev P,
+                                                    const CellDev* __restrict__ cells, int thr,
+                                                    uint32_t* __restrict__ cellCount, uint32_t* __restrict__ cellCand) {
+  __shared__ uint8_t tile[kTileMax * kTileMax];
+  __shared__ uint8_t score[(kTileMax - 4) * (kTileMax - 4)];
+  __shared__ int waveCnt[4];
+  __shared__ int total;
+  const int cellId = blockIdx.x, f = blockIdx.y;
+  const CellDev c = cells[cellId];
+  const LevelDev L = P.lv[c.level];
+  const int tw = c.x1 - c.x0, th = c.y1 - c.y0;
+  const int bw = tw - 6, bh = th - 6;  // detection band
+  const size_t slot = (size_t)f * P.nCellsTotal + cellId;
+  if (bw <= 0 || bh <= 0) {
+    if (threadIdx.x == 0) cellCount[slot] = 0;
+    return;
+  }
+  const uint8_t* roi = pyr + (size_t)f * pyrFrameStride + L.padOff + (size_t)kPad * L.pitch + kPad;
+  for (int i = threadIdx.x; i < tw * th; i += 256) {
+    const int ty = i / tw, tx = i - ty * tw;
+    tile[ty * kTileMax + tx] = roi[(size_t)(c.y0 + ty) * L.pitch + c.x0 + tx];
+  }
+  const int sw = bw + 2, sh = bh + 2;  // score map with a zero ring
+  for (int i = threadIdx.x; i < sw * sh; i += 256) score[i] = 0;
+  if (threadIdx.x == 0) total = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < bw * bh; i += 256) {
+    const int by = i / bw, bx = i - by * bw;
+    const uint8_t* p = &tile[(by + 3) * kTileMax + bx + 3];
+    const int v = p[0];
+    int ring[16];
+    ring[0] = p[3 * kTileMax];       ring[1] = p[3 * kTileMax + 1];   ring[2] = p[2 * kTileMax + 2];   ring[3] = p[kTileMax + 3];
+    ring[4] = p[3];                  ring[5] = p[-kTileMax + 3];      ring[6] = p[-2 * kTileMax + 2];  ring[7] = p[-3 * kTileMax + 1];
+    ring[8] = p[-3 * kTileMax];      ring[9] = p[-3 * kTileMax - 1];  ring[10] = p[-2 * kTileMax - 2]; ring[11] = p[-kTileMax - 3];
+    ring[12] = p[-3];                ring[13] = p[kTileMax - 3];      ring[14] = p[2 * kTileMax - 2];  ring[15] = p[3 * kTileMax - 1];
+    const int s = fast_corner_score(v, ring, thr);
+    if (s) score[(by + 1) * sw + bx + 1] = (uint8_t)s;
+  }
+  __syncthreads();
+  // NMS (strictly greater than the 8 neighbours) + ordered compaction, 256 band pixels per round
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t* dst = cellCand + slot * P.cellCap;
+  for (int base = 0; base < bw * bh; base += 256) {
+    const int i = base + threadIdx.x;
+    bool keep = false;
+    int bx = 0, by = 0, s = 0;
+    if (i < bw * bh) {
+      by = i / bw;
+      bx = i - by * bw;
+      const uint8_t* q = &score[(by + 1) * sw + bx + 1];
+      s = q[0];
+      keep = s && s > q[-1] && s > q[1] && s > q[-sw - 1] && s > q[-sw] && s > q[-sw + 1] && s > q[sw - 1] && s > q[sw] && s > q[sw + 1];
+    }
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) waveCnt[wv] = __popcll(m);
+    __syncthreads();
+    int off = total;
+    for (int j = 0; j < wv; j++) off += waveCnt[j];
+    if (keep) {
+      const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+      if (pos < P.cellCap) dst[pos] = qt_pack(c.x0 + 3 + bx - kBorder, c.y0 + 3 + by - kBorder, s);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) total += waveCnt[0] + waveCnt[1] + waveCnt[2] + waveCnt[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cellCount[slot] = (uint32_t)min(total, P.cellCap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Quad-tree thinning, one workgroup per (level, frame).  See quadtree_core.h.
+// ------------------------------------------------------------------------------------------------
+struct QtGpuCtx {
+  unsigned* w32;
+  unsigned long long* w64;
+  __device__ int tid() const { return threadIdx.x; }
+  __device__ int nthreads() const { return blockDim.x; }
+  __device__ void sync() { __syncthreads(); }
+  __device__ unsigned scan_incl_u32(unsigned v, unsigned* total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    unsigned x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) w32[wv] = x;
+    __syncthreads();
+    unsigned off = 0, tot = 0;
+    for (int i = 0; i < nw; i++) {
+      const unsigned s = w32[i];
+      if (i < wv) off += s;
+      tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return x + off;
+  }
+  __device__ unsigned long long scan_incl_u64(unsigned long long v, unsigned long long* total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    unsigned long long x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned lo = __shfl_up((unsigned)x, d, 64), hi = __shfl_up((unsigned)(x >> 32), d, 64);
+      if (lane >= d) x += ((unsigned long long)hi << 32) | lo;
+    }
+    if (lane == 63) w64[wv] = x;
+    __syncthreads();
+    unsigned long long off = 0, tot = 0;
+    for (int i = 0; i < nw; i++) {
+      const unsigned long long s = w64[i];
+      if (i < wv) off += s;
+      tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return x + off;
+  }
+  __device__ void lds_add_u64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
+};
+
+// dynamic LDS layout: [geom0|geom1|cnt0|cnt1|base0|base1|cc|childIdx] for nodeCap nodes, then cellBase[maxCells+1]
+__global__ __launch_bounds__(kQtThreads) void k_quadtree(PlanDev P, const uint32_t* __restrict__ cellCount,
+                                                         const uint32_t* __restrict__ cellCand, uint32_t* __restrict__ qtCand,
+                                                         uint16_t* __restrict__ qtNode, uint32_t* __restrict__ qtKeys,
+                                                         size_t qtFrameStride, int nodeCap, uint32_t* __restrict__ lvlKp,
+                                                         int* __restrict__ lvlCount, int* __restrict__ status) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  __shared__ unsigned w32[kQtThreads / 64];
+  __shared__ unsigned long long w64[kQtThreads / 64];
+  const int level = blockIdx.x, f = blockIdx.y;
+  const LevelDev L = P.lv[level];
+  uint8_t* sp = smem;
+  QtShared S;
+  S.cc = reinterpret_cast<unsigned long long*>(sp); sp += sizeof(unsigned long long) * nodeCap;
+  S.geom[0] = reinterpret_cast<QtGeom*>(sp); sp += sizeof(QtGeom) * nodeCap;
+  S.geom[1] = reinterpret_cast<QtGeom*>(sp); sp += sizeof(QtGeom) * nodeCap;
+  S.childIdx = reinterpret_cast<uint16_t*>(sp); sp += sizeof(uint16_t) * 4 * nodeCap;
+  S.cnt[0] = reinterpret_cast<uint32_t*>(sp); sp += sizeof(uint32_t) * nodeCap;
+  S.cnt[1] = reinterpret_cast<uint32_t*>(sp); sp += sizeof(uint32_t) * nodeCap;
+  S.base[0] = reinterpret_cast<uint32_t*>(sp); sp += sizeof(uint32_t) * nodeCap;
+  S.base[1] = reinterpret_cast<uint32_t*>(sp); sp += sizeof(uint32_t) * nodeCap;
+  uint32_t* cellBase = reinterpret_cast<uint32_t*>(sp);
+  QtGpuCtx cx{w32, w64};
+
+  // concatenate the level's cells in (row, col) order == keyPointsToDistr (orbExtractor.cpp:584-590)
+  const uint32_t* cnts = cellCount + (size_t)f * P.nCellsTotal + L.cellBegin;
+  unsigned n = 0;
+  for (int c0 = 0; c0 < L.nCells; c0 += kQtThreads) {
+    const int c = c0 + threadIdx.x;
+    const unsigned v = c < L.nCells ? cnts[c] : 0u;
+    unsigned tot;
+    const unsigned incl = cx.scan_incl_u32(v, &tot);
+    if (c < L.nCells) cellBase[c] = n + incl - v;
+    n += tot;
+  }
+  __syncthreads();
+  const size_t so = (size_t)f * qtFrameStride + L.candOff;
+  const size_t cap = (size_t)L.nCells * P.cellCap;
+  QtGlobal G;
+  G.cand[0] = qtCand + 2 * so;
+  G.cand[1] = G.cand[0] + cap;
+  G.node[0] = qtNode + 2 * so;
+  G.node[1] = G.node[0] + cap;
+  G.sortKeys = qtKeys + so;
+  int nOut = 0;
+  if (n > 65535u) {
+    if (threadIdx.x == 0) atomicMax(status, 1);  // more candidates than the packed 16-bit counters allow
+  } else {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c = wv; c < L.nCells; c += kQtThreads / 64) {
+      const unsigned m = cnts[c], b = cellBase[c];
+      const uint32_t* src = cellCand + ((size_t)f * P.nCellsTotal + L.cellBegin + c) * P.cellCap;
+      for (unsigned i = lane; i < m; i += 64) G.cand[0][b + i] = src[i];
+    }
+    __syncthreads();
+    nOut = qt_distribute(cx, S, G, (int)n, L.w - 2 * kBorder, L.h - 2 * kBorder, L.quota, nodeCap,
+                         lvlKp + (size_t)f * P.sumQuota + L.kpOff);
+    if (nOut < 0) {
+      if (threadIdx.x == 0) atomicMax(status, 2);
+      nOut = 0;
+    }
+  }
+  if (threadIdx.x == 0) lvlCount[f * kMaxLevels + level] = nOut;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cv::GaussianBlur(level, 7x7, sigma 2, BORDER_REFLECT_101) in OpenCV's 8.8 fixed-point form
+// (orbExtractor.cpp:385-386).  The pyramid's own 19-px reflect-101 pad supplies the border.
+// 64x16 output tile per workgroup: LDS-staged source, separable 16-bit horizontal / 32-bit vertical.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, size_t pyrFrameStride, uint8_t* __restrict__ blur,
+                                              size_t blurFrameStride, PlanDev P) {
+  constexpr int TW = 64, TH = 16, SW = TW + 6, SH = TH + 6, SP = 72;
+  __shared__ uint8_t src[SH * SP];
+  __shared__ uint16_t hb[SH * TW];
+  const int level = blockIdx.y, f = blockIdx.z;
+  const LevelDev L = P.lv[level];
+  const int tilesX = (L.w + TW - 1) / TW, tilesY = (L.h + TH - 1) / TH;
+  if ((int)blockIdx.x >= tilesX * tilesY) return;
+  const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
+  const int x0 = tx * TW, y0 = ty * TH;
+  const uint8_t* roi = pyr + (size_t)f * pyrFrameStride + L.padOff + (size_t)kPad * L.pitch + kPad;
+  for (int i = threadIdx.x; i < SH * SW; i += 256) {
+    const int r = i / SW, cc = i - r * SW;
+    const int gy = min(y0 + r - 3, L.h + kPad - 1), gx = min(x0 + cc - 3, L.w + kPad - 1);
+    src[r * SP + cc] = roi[(ptrdiff_t)gy * L.pitch + gx];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < SH * TW; i += 256) {
+    const int r = i / TW, cc = i - r * TW;
+    const uint8_t* s = &src[r * SP + cc];
+    hb[i] = (uint16_t)(18 * (s[0] + s[6]) + 34 * (s[1] + s[5]) + 48 * (s[2] + s[4]) + 56 * s[3]);
+  }
+  __syncthreads();
+  const int r = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+  const int gy = y0 + r;
+  if (gy < L.h) {
+    uint32_t out = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const uint16_t* h = &hb[r * TW + c4 + b];
+      const uint32_t acc = 18u * (h[0] + h[6 * TW]) + 34u * (h[TW] + h[5 * TW]) + 48u * (h[2 * TW] + h[4 * TW]) + 56u * h[3 * TW];
+      out |= ((acc + 32768u) >> 16) << (8 * b);
+    }
+    uint8_t* dst = blur + (size_t)f * blurFrameStride + L.blurOff + (size_t)gy * L.blurPitch + x0 + c4;
+    if (x0 + c4 < L.blurPitch) *reinterpret_cast<uint32_t*>(dst) = out;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cv::fastAtan2 (float polynomial, degrees) — call site orbExtractor.cpp:419.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+  const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+  const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+  const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+  const float eps = (float)2.2204460492503131e-16;
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+    c2 = __fmul_rn(c, c);
+    a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+  } else {
+    c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+    c2 = __fmul_rn(c, c);
+    a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+  }
+  if (x < 0) a = __fsub_rn(180.f, a);
+  if (y < 0) a = __fsub_rn(360.f, a);
+  return a;
+}
+
+// Deterministic float cos/sin: fixed sequence of IEEE double operations (Cody-Waite by pi/2 + minimax
+// kernels), rounded once to float.  The reference calls libm cosf/sinf (orbExtractor.cpp:424-425), which
+// is platform code; DESIGN.md "steering trig" explains the contract.  The oracle restates the same
+// sequence independently in oracle/oracle_trig.h.
+__device__ __forceinline__ void sincos_det(float xf, float* sinOut, float* cosOut) {
+  const double x = (double)xf;
+  const double n = rint(__dmul_rn(x, 6.36619772367581382433e-01));
+  const double r = __dsub_rn(__dsub_rn(x, __dmul_rn(n, 1.57079632673412561417e+00)), __dmul_rn(n, 6.07710050650619224932e-11));
+  const double z = __dmul_rn(r, r);
+  double p = __dmul_rn(z, 1.58969099521155010221e-10);
+  p = __dadd_rn(p, -2.50507602534068634195e-08); p = __dmul_rn(p, z);
+  p = __dadd_rn(p, 2.75573137070700676789e-06);  p = __dmul_rn(p, z);
+  p = __dadd_rn(p, -1.98412698298579493134e-04); p = __dmul_rn(p, z);
+  p = __dadd_rn(p, 8.33333333332248946124e-03);  p = __dmul_rn(p, z);
+  p = __dadd_rn(p, -1.66666666666666324348e-01); p = __dmul_rn(p, z);
+  p = __dmul_rn(p, r); p = __dadd_rn(p, r);
+  double q = __dmul_rn(z, -1.13596475577881948265e-11);
+  q = __dadd_rn(q, 2.08757232129817482790e-09);  q = __dmul_rn(q, z);
+  q = __dadd_rn(q, -2.75573143513906633035e-07); q = __dmul_rn(q, z);
+  q = __dadd_rn(q, 2.48015872894767294178e-05);  q = __dmul_rn(q, z);
+  q = __dadd_rn(q, -1.38888888888741095749e-03); q = __dmul_rn(q, z);
+  q = __dadd_rn(q, 4.16666666666666019037e-02);  q = __dmul_rn(q, z);
+  q = __dmul_rn(q, z);
+  double h = __dmul_rn(z, 0.5);
+  h = __dsub_rn(h, q);
+  h = __dsub_rn(1.0, h);
+  const int quad = ((int)n) & 3;
+  const double sv = quad == 0 ? p : quad == 1 ? h : quad == 2 ? -p : -h;
+  const double cv = quad == 0 ? h : quad == 1 ? -p : quad == 2 ? -h : p;
+  *sinOut = (float)sv;
+  *cosOut = (float)cv;
+}
+
+__device__ const int8_t kPatternDev[1024] = {
+#include "orb_pattern_data.inc"
+};
+
+// ------------------------------------------------------------------------------------------------
+// One wave per keypoint: intensity-centroid orientation (orbExtractor.cpp:400-421, with the reference's
+// own m_v_maxXcords table), then steered rBRIEF on the blurred level (:422-454) and the final
+// cv::KeyPoint (:391-396, :595-601).  Lane l evaluates tests l, 64+l, 128+l, 192+l; a 64-bit ballot of
+// (t0 < t1) is exactly 8 consecutive descriptor bytes.
+// ------------------------------------------------------------------------------------------------
+struct YdKeyPointDev { float x, y, size, angle, response; int octave, class_id; };
+
+__global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restrict__ pyr, size_t pyrFrameStride,
+                                                         const uint8_t* __restrict__ blur, size_t blurFrameStride, PlanDev P,
+                                                         const uint32_t* __restrict__ lvlKp, const int* __restrict__ lvlCount,
+                                                         YdKeyPointDev* __restrict__ kps, uint8_t* __restrict__ desc, int cap,
+                                                         int* __restrict__ nOut, float* __restrict__ lvlAngle) {
+  const int lane = threadIdx.x & 63;
+  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int f = blockIdx.y;
+  if (slot >= P.sumQuota) return;
+  int level = 0, before = 0, tot = 0;
+  for (int l = 0; l < P.nLevels; l++) {
+    const int c = lvlCount[f * kMaxLevels + l];
+    if (slot >= P.lv[l].kpOff) { level = l; before = tot; }
+    tot += c;
+  }
+  if (slot == 0 && lane == 0) nOut[f] = min(tot, cap);
+  const LevelDev L = P.lv[level];
+  const int k = slot - L.kpOff;
+  if (k >= lvlCount[f * kMaxLevels + level]) return;
+  const int outIdx = before + k;
+  if (outIdx >= cap) return;
+  const uint32_t pk = lvlKp[(size_t)f * P.sumQuota + slot];
+  const int kx = qt_x(pk) + kBorder, ky = qt_y(pk) + kBorder;
+  const uint8_t* roi = pyr + (size_t)f * pyrFrameStride + L.padOff + (size_t)kPad * L.pitch + kPad;
+  const uint8_t* ctr = roi + (ptrdiff_t)ky * L.pitch + kx;
+  // --- orientation ---
+  const int u = lane - 32;
+  int m10 = 0, m01 = 0;
+  if (u >= -15 && u <= 15) m10 = u * ctr[u];
+  for (int v = 1; v <= 15; v++) {
+    const int d = P.maxX[v];
+    if (u >= -d && u <= d) {
+      const int pos = ctr[(ptrdiff_t)v * L.pitch + u], neg = ctr[-(ptrdiff_t)v * L.pitch + u];
+      m01 += v * (pos - neg);
+      m10 += u * (pos + neg);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    m10 += __shfl_xor(m10, o, 64);
+    m01 += __shfl_xor(m01, o, 64);
+  }
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+  // --- steered BRIEF ---
+  const float rad = __fmul_rn(angle, (float)(3.14159265358979323846 / 180.0));
+  float sinB, cosA;
+  sincos_det(rad, &sinB, &cosA);
+  const uint8_t* bl = blur + (size_t)f * blurFrameStride + L.blurOff + (size_t)ky * L.blurPitch + kx;
+  unsigned long long words[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const int8_t* pt = &kPatternDev[4 * (t * 64 + lane)];
+    const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+    const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sinB), __fmul_rn(y0, cosA)));
+    const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, cosA), __fmul_rn(y0, sinB)));
+    const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sinB), __fmul_rn(y1, cosA)));
+    const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, cosA), __fmul_rn(y1, sinB)));
+    const int t0 = bl[(ptrdiff_t)r0 * L.blurPitch + c0], t1 = bl[(ptrdiff_t)r1 * L.blurPitch + c1];
+    words[t] = __ballot(t0 < t1);
+  }
+  if (lane < 4) {
+    unsigned long long w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
+    reinterpret_cast<unsigned long long*>(desc + ((size_t)f * cap + outIdx) * 32)[lane] = w;
+  }
+  if (lane == 0) {
+    YdKeyPointDev kp;
+    kp.x = (float)kx;
+    kp.y = (float)ky;
+    if (level) { kp.x = __fmul_rn(kp.x, L.scale); kp.y = __fmul_rn(kp.y, L.scale); }
+    kp.size = L.size;
+    kp.angle = angle;
+    kp.response = (float)qt_r(pk);
+    kp.octave = level;
+    kp.class_id = -1;
+    kps[(size_t)f * cap + outIdx] = kp;
+    lvlAngle[(size_t)f * P.sumQuota + slot] = angle;
+  }
+}
+
+}  // namespace ydorb

@@ -1,0 +1,563 @@
+// Host side of the MI355X ORB extractor + its C ABI (include/ydorb/c_api.h).
+// Mirrors YDORBSLAM::OrbExtractor (reference src/orbExtractor.hpp:31-74, orbExtractor.cpp:315-399):
+// constructor tables on the host, everything per-frame on the GPU.  There is no CPU fallback: without
+// a usable HIP device every entry point returns YDORB_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ydorb/c_api.h"
+#include "extract_kernels.hip.h"
+#include "ydorb_host.h"
+
+using namespace ydorb;
+
+namespace {
+
+inline int cvRoundF(float v) { return (int)lrintf(v); }  // round-half-even (default rounding mode)
+inline int cvFloorF(float v) { int i = (int)v; return i - (i > v); }
+inline int alignUp(int v, int a) { return (v + a - 1) / a * a; }
+inline size_t alignUpZ(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct HostPlan {
+  int w = 0, h = 0;
+  PlanDev dev{};
+  std::vector<CellDev> cells;
+  size_t pyrFrameStride = 0, blurFrameStride = 0, qtFrameStride = 0;
+  int nodeCap = 0, maxCellsPerLevel = 0;
+  size_t qtLds = 0;
+  std::vector<int> tabInt;      // xofs|yofs per level
+  std::vector<short> tabShort;  // alpha|beta per level
+  struct TabOff { int xofs, yofs, alpha, beta; } tab[kMaxLevels]{};
+};
+
+enum Stage { ST_PYR = 0, ST_FAST, ST_QT, ST_BLUR, ST_DESC, ST_COUNT };
+const char* kStageNames[ST_COUNT] = {"pyramid", "fast_cells", "quadtree", "blur", "orient_describe"};
+
+}  // namespace
+
+struct ydorb_extractor {
+  YdExtractorConfig cfg{};
+  std::vector<float> sf, isf, sf2, isf2;
+  std::vector<int> perLevel;
+  int maxX[16]{};
+  int sumQuota = 0;
+  hipStream_t stream = nullptr;
+  HostPlan plan;
+  bool planValid = false;
+  int batchCap = 0;
+  // device buffers (sized for plan x batchCap)
+  uint8_t *d_img = nullptr, *d_pyr = nullptr, *d_blur = nullptr;
+  uint32_t *d_cellCount = nullptr, *d_cellCand = nullptr, *d_qtCand = nullptr, *d_qtKeys = nullptr, *d_lvlKp = nullptr;
+  uint16_t* d_qtNode = nullptr;
+  int *d_lvlCount = nullptr, *d_status = nullptr, *d_nOut = nullptr;
+  float* d_lvlAngle = nullptr;
+  CellDev* d_cells = nullptr;
+  int* d_tabInt = nullptr;
+  short* d_tabShort = nullptr;
+  YdKeyPointDev* d_kps = nullptr;
+  uint8_t* d_desc = nullptr;
+  size_t imgBytes = 0;
+  // pinned host staging for the host-pointer entry points
+  uint8_t* h_img = nullptr;
+  YdKeyPoint* h_kps = nullptr;
+  uint8_t* h_desc = nullptr;
+  int* h_nOut = nullptr;
+  int* h_status = nullptr;
+  int lastFrames = 0;
+  // profiling
+  bool profiling = false;
+  hipEvent_t ev[ST_COUNT + 1]{};
+  double stageMs[ST_COUNT]{};
+  int stageCalls = 0;
+};
+
+namespace {
+
+#define HIPCHK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      ydorb::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return YDORB_ERR_HIP;                                                                   \
+    }                                                                                         \
+  } while (0)
+
+void freeBuffers(ydorb_extractor* e) {
+  auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+  F(e->d_img); F(e->d_pyr); F(e->d_blur); F(e->d_cellCount); F(e->d_cellCand); F(e->d_qtCand); F(e->d_qtKeys);
+  F(e->d_lvlKp); F(e->d_qtNode); F(e->d_lvlCount); F(e->d_status); F(e->d_nOut); F(e->d_lvlAngle); F(e->d_cells);
+  F(e->d_tabInt); F(e->d_tabShort); F(e->d_kps); F(e->d_desc);
+  auto H = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
+  H(e->h_img); H(e->h_kps); H(e->h_desc); H(e->h_nOut); H(e->h_status);
+  e->planValid = false;
+}
+
+// Level sizes, cell grid, scratch layout, resize tables for a w x h input.
+int buildPlan(ydorb_extractor* e, int w, int h, HostPlan& P) {
+  P = HostPlan();
+  P.w = w; P.h = h;
+  PlanDev& D = P.dev;
+  D.nLevels = e->cfg.n_levels;
+  for (int v = 0; v < 16; v++) D.maxX[v] = e->maxX[v];
+  size_t padOff = 0, blurOff = 0;
+  int kpOff = 0, candOff = 0, maxCellDim = 0;
+  for (int l = 0; l < D.nLevels; l++) {
+    LevelDev& L = D.lv[l];
+    L.w = cvRoundF((float)w * e->isf[l]);   // orbExtractor.cpp:608-609
+    L.h = cvRoundF((float)h * e->isf[l]);
+    if (L.w < 1 || L.h < 1 || L.w > 4000 || L.h > 4000) {
+      set_error("level %d size %dx%d out of the supported range (1..4000)", l, L.w, L.h);
+      return YDORB_ERR_UNSUPPORTED;
+    }
+    L.pitch = alignUp(L.w + 2 * kPad, 64);
+    L.padOff = (int)padOff;
+    padOff += alignUpZ((size_t)(L.h + 2 * kPad) * L.pitch, 256);
+    L.blurPitch = alignUp(L.w, 64);
+    L.blurOff = (int)blurOff;
+    blurOff += alignUpZ((size_t)L.h * L.blurPitch, 256);
+    L.quota = e->perLevel[l];
+    L.kpOff = kpOff;
+    kpOff += L.quota;
+    L.scale = e->sf[l];
+    L.size = (float)(int)(31 * e->sf[l]);   // orbExtractor.cpp:595
+    // cell grid, orbExtractor.cpp:548-580
+    L.cellBegin = (int)P.cells.size();
+    const int minB = kBorder, maxBX = L.w - kBorder, maxBY = L.h - kBorder;
+    const float width = (float)(maxBX - minB), height = (float)(maxBY - minB);
+    const int colsNum = (int)(width / 30.0f), rowsNum = (int)(height / 30.0f);
+    if (colsNum > 0 && rowsNum > 0) {
+      const int cellW = (int)ceilf(width / colsNum), cellH = (int)ceilf(height / rowsNum);
+      maxCellDim = std::max(maxCellDim, std::max(cellW, cellH));
+      for (int i = 0; i < rowsNum; i++) {
+        const float iniY = (float)(minB + i * cellH);
+        float maxY = iniY + cellH + 6;
+        if (iniY >= maxBY - 3) continue;
+        if (maxY > maxBY) maxY = (float)maxBY;
+        for (int j = 0; j < colsNum; j++) {
+          const float iniX = (float)(minB + j * cellW);
+          float maxX = iniX + cellW + 6;
+          if (iniX >= maxBX - 6) continue;
+          if (maxX > maxBX) maxX = (float)maxBX;
+          CellDev c{};
+          c.level = (short)l;
+          c.x0 = (short)iniX; c.y0 = (short)iniY; c.x1 = (short)maxX; c.y1 = (short)maxY;
+          P.cells.push_back(c);
+        }
+      }
+    }
+    L.nCells = (int)P.cells.size() - L.cellBegin;
+    P.maxCellsPerLevel = std::max(P.maxCellsPerLevel, L.nCells);
+    // resize tables (cv::resize INTER_LINEAR 8U: float coordinate, 11-bit coefficients), level >= 1
+    if (l > 0) {
+      const LevelDev& Lp = D.lv[l - 1];
+      const double scale_x = 1. / ((double)L.w / Lp.w), scale_y = 1. / ((double)L.h / Lp.h);
+      P.tab[l].xofs = (int)P.tabInt.size();
+      P.tab[l].alpha = (int)P.tabShort.size();
+      for (int dx = 0; dx < L.w; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cvFloorF(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= Lp.w - 1) { fx = 0; sx = Lp.w - 1; }
+        P.tabInt.push_back(sx);
+        P.tabShort.push_back((short)cvRoundF((1.f - fx) * 2048));
+        P.tabShort.push_back((short)cvRoundF(fx * 2048));
+      }
+      P.tab[l].yofs = (int)P.tabInt.size();
+      P.tab[l].beta = (int)P.tabShort.size();
+      for (int dy = 0; dy < L.h; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cvFloorF(fy);
+        fy -= sy;
+        P.tabInt.push_back(sy);
+        P.tabShort.push_back((short)cvRoundF((1.f - fy) * 2048));
+        P.tabShort.push_back((short)cvRoundF(fy * 2048));
+      }
+    }
+  }
+  if (maxCellDim + 6 > kTileMax) {
+    set_error("cell size %d exceeds the FAST tile (%d)", maxCellDim, kTileMax - 6);
+    return YDORB_ERR_UNSUPPORTED;
+  }
+  D.nCellsTotal = (int)P.cells.size();
+  // NMS survivors are pairwise non-adjacent: at most ceil(w/2)*ceil(h/2) per cell band
+  D.cellCap = alignUp(std::max(((maxCellDim + 1) / 2) * ((maxCellDim + 1) / 2), 64), 64);
+  D.sumQuota = kpOff;
+  for (int l = 0; l < D.nLevels; l++) {
+    D.lv[l].candOff = candOff;
+    candOff += D.lv[l].nCells * D.cellCap;
+  }
+  P.pyrFrameStride = padOff;
+  P.blurFrameStride = blurOff;
+  P.qtFrameStride = (size_t)candOff;
+  int maxQuota = 1;
+  for (int l = 0; l < D.nLevels; l++) maxQuota = std::max(maxQuota, D.lv[l].quota);
+  P.nodeCap = 4 * maxQuota;
+  P.qtLds = (size_t)P.nodeCap * (8 + 8 + 8 + 8 + 4 + 4 + 4 + 4) + (size_t)(P.maxCellsPerLevel + 1) * 4;
+  if (P.qtLds > 150 * 1024) {
+    set_error("n_features=%d needs %zu B of LDS for the quad-tree (max 150 KiB)", e->cfg.n_features, P.qtLds);
+    return YDORB_ERR_UNSUPPORTED;
+  }
+  return YDORB_OK;
+}
+
+int ensurePlan(ydorb_extractor* e, int w, int h, int nFrames) {
+  if (e->planValid && e->plan.w == w && e->plan.h == h && nFrames <= e->batchCap) return YDORB_OK;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HostPlan P;
+  int rc = buildPlan(e, w, h, P);
+  if (rc) return rc;
+  freeBuffers(e);
+  const int B = std::max(nFrames, std::max(1, e->cfg.max_batch));
+  e->plan = P;
+  e->batchCap = B;
+  e->imgBytes = (size_t)w * h;
+  const PlanDev& D = P.dev;
+  HIPCHK(hipMalloc(&e->d_img, e->imgBytes * B));
+  HIPCHK(hipMalloc(&e->d_pyr, P.pyrFrameStride * B));
+  HIPCHK(hipMalloc(&e->d_blur, P.blurFrameStride * B));
+  HIPCHK(hipMalloc(&e->d_cellCount, sizeof(uint32_t) * D.nCellsTotal * B));
+  HIPCHK(hipMalloc(&e->d_cellCand, sizeof(uint32_t) * (size_t)D.nCellsTotal * D.cellCap * B));
+  HIPCHK(hipMalloc(&e->d_qtCand, sizeof(uint32_t) * 2 * P.qtFrameStride * B));
+  HIPCHK(hipMalloc(&e->d_qtNode, sizeof(uint16_t) * 2 * P.qtFrameStride * B));
+  HIPCHK(hipMalloc(&e->d_qtKeys, sizeof(uint32_t) * P.qtFrameStride * B));
+  HIPCHK(hipMalloc(&e->d_lvlKp, sizeof(uint32_t) * (size_t)D.sumQuota * B));
+  HIPCHK(hipMalloc(&e->d_lvlAngle, sizeof(float) * (size_t)D.sumQuota * B));
+  HIPCHK(hipMalloc(&e->d_lvlCount, sizeof(int) * kMaxLevels * B));
+  HIPCHK(hipMalloc(&e->d_status, sizeof(int)));
+  HIPCHK(hipMalloc(&e->d_nOut, sizeof(int) * B));
+  HIPCHK(hipMalloc(&e->d_cells, sizeof(CellDev) * std::max<size_t>(P.cells.size(), 1)));
+  HIPCHK(hipMalloc(&e->d_tabInt, sizeof(int) * std::max<size_t>(P.tabInt.size(), 1)));
+  HIPCHK(hipMalloc(&e->d_tabShort, sizeof(short) * std::max<size_t>(P.tabShort.size(), 1)));
+  HIPCHK(hipMalloc(&e->d_kps, sizeof(YdKeyPointDev) * (size_t)D.sumQuota * B));
+  HIPCHK(hipMalloc(&e->d_desc, (size_t)32 * D.sumQuota * B));
+  HIPCHK(hipHostMalloc(&e->h_img, e->imgBytes * B));
+  HIPCHK(hipHostMalloc(&e->h_kps, sizeof(YdKeyPoint) * (size_t)D.sumQuota * B));
+  HIPCHK(hipHostMalloc(&e->h_desc, (size_t)32 * D.sumQuota * B));
+  HIPCHK(hipHostMalloc(&e->h_nOut, sizeof(int) * B));
+  HIPCHK(hipHostMalloc(&e->h_status, sizeof(int)));
+  if (!P.cells.empty()) HIPCHK(hipMemcpyAsync(e->d_cells, P.cells.data(), sizeof(CellDev) * P.cells.size(), hipMemcpyHostToDevice, e->stream));
+  if (!P.tabInt.empty()) HIPCHK(hipMemcpyAsync(e->d_tabInt, P.tabInt.data(), sizeof(int) * P.tabInt.size(), hipMemcpyHostToDevice, e->stream));
+  if (!P.tabShort.empty()) HIPCHK(hipMemcpyAsync(e->d_tabShort, P.tabShort.data(), sizeof(short) * P.tabShort.size(), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemsetAsync(e->d_status, 0, sizeof(int), e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (P.qtLds > 48 * 1024)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.qtLds));
+  e->planValid = true;
+  return YDORB_OK;
+}
+
+// Enqueue the whole front-end for nFrames device-resident images on `s`.
+int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameStride, int nFrames, YdKeyPointDev* d_kps,
+            uint8_t* d_desc, int cap, int* d_nOut, hipStream_t s) {
+  const HostPlan& P = e->plan;
+  const PlanDev& D = P.dev;
+  const bool prof = e->profiling && s == e->stream;
+  if (prof) HIPCHK(hipEventRecord(e->ev[0], s));
+  {
+    const LevelDev& L0 = D.lv[0];
+    dim3 g((L0.pitch / 4 + 255) / 256, L0.h + 2 * kPad, nFrames);
+    hipLaunchKernelGGL(k_pyr_level0, g, dim3(256), 0, s, d_img, stride, frameStride, e->d_pyr, P.pyrFrameStride, L0);
+    for (int l = 1; l < D.nLevels; l++) {
+      const LevelDev& L = D.lv[l];
+      dim3 gl((L.pitch / 4 + 255) / 256, L.h + 2 * kPad, nFrames);
+      hipLaunchKernelGGL(k_pyr_resize, gl, dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, D.lv[l - 1], L,
+                         e->d_tabInt + P.tab[l].xofs, e->d_tabShort + P.tab[l].alpha, e->d_tabInt + P.tab[l].yofs,
+                         e->d_tabShort + P.tab[l].beta);
+    }
+  }
+  if (prof) HIPCHK(hipEventRecord(e->ev[1], s));
+  if (D.nCellsTotal > 0)
+    hipLaunchKernelGGL(k_fast_cells, dim3(D.nCellsTotal, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, D, e->d_cells,
+                       std::min(std::max(e->cfg.ini_fast_thr, 0), 255), e->d_cellCount, e->d_cellCand);
+  if (prof) HIPCHK(hipEventRecord(e->ev[2], s));
+  hipLaunchKernelGGL(k_quadtree, dim3(D.nLevels, nFrames), dim3(kQtThreads), P.qtLds, s, D, e->d_cellCount, e->d_cellCand,
+                     e->d_qtCand, e->d_qtNode, e->d_qtKeys, P.qtFrameStride, P.nodeCap, e->d_lvlKp, e->d_lvlCount, e->d_status);
+  if (prof) HIPCHK(hipEventRecord(e->ev[3], s));
+  {
+    int maxTiles = 0;
+    for (int l = 0; l < D.nLevels; l++) maxTiles = std::max(maxTiles, ((D.lv[l].w + 63) / 64) * ((D.lv[l].h + 15) / 16));
+    hipLaunchKernelGGL(k_blur, dim3(maxTiles, D.nLevels, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
+                       P.blurFrameStride, D);
+  }
+  if (prof) HIPCHK(hipEventRecord(e->ev[4], s));
+  hipLaunchKernelGGL(k_orient_describe, dim3((D.sumQuota + 3) / 4, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
+                     P.blurFrameStride, D, e->d_lvlKp, e->d_lvlCount, d_kps, d_desc, cap, d_nOut, e->d_lvlAngle);
+  if (prof) HIPCHK(hipEventRecord(e->ev[5], s));
+  HIPCHK(hipGetLastError());
+  e->lastFrames = nFrames;
+  return YDORB_OK;
+}
+
+int checkStatus(ydorb_extractor* e) {
+  if (*e->h_status == 1) { set_error("more than 65535 FAST candidates in one pyramid level"); return YDORB_ERR_CAPACITY; }
+  if (*e->h_status) { set_error("quad-tree node table overflow (status %d)", *e->h_status); return YDORB_ERR_CAPACITY; }
+  return YDORB_OK;
+}
+
+void collectProfile(ydorb_extractor* e) {
+  if (!e->profiling) return;
+  for (int i = 0; i < ST_COUNT; i++) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]) == hipSuccess) e->stageMs[i] += ms;
+  }
+  e->stageCalls++;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ydorb_extractor_create(const YdExtractorConfig* cfg, ydorb_extractor_t** out) {
+  if (!cfg || !out) { set_error("null argument"); return YDORB_ERR_INVALID_ARG; }
+  *out = nullptr;
+  if (cfg->n_levels < 1 || cfg->n_levels > kMaxLevels || cfg->n_features < 1 || !(cfg->scale_factor > 1.0f)) {
+    set_error("unsupported extractor config (n_levels 1..8, n_features >= 1, scale_factor > 1)");
+    return YDORB_ERR_INVALID_ARG;
+  }
+  int rc = ydorb::require_device(cfg->device);
+  if (rc) return rc;
+  ydorb_extractor* e = new ydorb_extractor();
+  e->cfg = *cfg;
+  e->cfg.min_fast_thr = cfg->ini_fast_thr;  // reference quirk, orbExtractor.cpp:318
+  // constructor tables, orbExtractor.cpp:319-353
+  const int L = cfg->n_levels;
+  const float s = cfg->scale_factor;
+  int per = (int)round(cfg->n_features * (1 - 1.0 / s) / (1.0 - pow(1.0 / s, L)));
+  int sum = 0;
+  for (int i = 0; i < L; i++) {
+    e->sf.push_back((float)pow(s, i));
+    e->sf2.push_back((float)pow(s, 2 * i));
+    e->isf.push_back((float)pow(s, -i));
+    e->isf2.push_back((float)pow(s, -2 * i));
+    if (i < L - 1) {
+      e->perLevel.push_back(per);
+      sum += per;
+      per = (int)round((float)per / s);
+    } else {
+      e->perLevel.push_back(std::max(cfg->n_features - sum, 0));
+    }
+  }
+  e->sumQuota = 0;
+  for (int q : e->perLevel) e->sumQuota += q;
+  {  // m_v_maxXcords as the reference actually builds it (resize(16) followed by push_back, :341-353)
+    const int half = 15;
+    std::vector<int> mx(half + 1, 0);
+    const int maxY = (int)floor(half * sqrt(2.0) / 2.0 + 1.0), minY = (int)ceil(half * sqrt(2.0) / 2.0);
+    for (int v = 0; v <= maxY; v++) mx.push_back((int)round(sqrt((double)half * half + (double)v * v)));
+    for (int v = half, i = 0; v >= minY; v--) {
+      while (mx[i] == mx[i + 1]) i++;
+      mx[v] = i;
+      i++;
+    }
+    for (int v = 0; v < 16; v++) e->maxX[v] = mx[v];
+  }
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+    set_error("hipStreamCreate failed");
+    delete e;
+    return YDORB_ERR_HIP;
+  }
+  for (auto& ev : e->ev) (void)hipEventCreate(&ev);
+  *out = e;
+  return YDORB_OK;
+}
+
+void ydorb_extractor_destroy(ydorb_extractor_t* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->cfg.device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  freeBuffers(e);
+  for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int ydorb_extractor_tables(const ydorb_extractor_t* e, float* scale, float* inv_scale, float* scale_sq, float* inv_scale_sq,
+                           int32_t* per_level) {
+  if (!e) { set_error("null handle"); return YDORB_ERR_INVALID_ARG; }
+  for (int i = 0; i < e->cfg.n_levels; i++) {
+    if (scale) scale[i] = e->sf[i];
+    if (inv_scale) inv_scale[i] = e->isf[i];
+    if (scale_sq) scale_sq[i] = e->sf2[i];
+    if (inv_scale_sq) inv_scale_sq[i] = e->isf2[i];
+    if (per_level) per_level[i] = e->perLevel[i];
+  }
+  return YDORB_OK;
+}
+
+int ydorb_extractor_max_keypoints(const ydorb_extractor_t* e) { return e ? e->sumQuota : YDORB_ERR_INVALID_ARG; }
+
+int ydorb_extract_batch_device(ydorb_extractor_t* e, const uint8_t* d_img, int32_t w, int32_t h, int32_t stride, size_t frame_stride,
+                               int32_t n_frames, YdKeyPoint* d_kps, uint8_t* d_desc, int32_t cap, int32_t* d_n_out, void* stream) {
+  if (!e || !d_img || !d_kps || !d_desc || !d_n_out || w <= 0 || h <= 0 || n_frames <= 0 || stride < w) {
+    set_error("invalid argument");
+    return YDORB_ERR_INVALID_ARG;
+  }
+  if (cap < e->sumQuota) { set_error("cap %d < max keypoints %d", cap, e->sumQuota); return YDORB_ERR_CAPACITY; }
+  HIPCHK(hipSetDevice(e->cfg.device));
+  int rc = ensurePlan(e, w, h, n_frames);
+  if (rc) return rc;
+  return enqueue(e, d_img, stride, frame_stride, n_frames, reinterpret_cast<YdKeyPointDev*>(d_kps), d_desc, cap, d_n_out,
+                 stream ? (hipStream_t)stream : e->stream);
+}
+
+int ydorb_extractor_synchronize(ydorb_extractor_t* e) {
+  if (!e) { set_error("null handle"); return YDORB_ERR_INVALID_ARG; }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return YDORB_OK;
+}
+
+int ydorb_extract_batch(ydorb_extractor_t* e, const uint8_t* img, int32_t w, int32_t h, int32_t stride, size_t frame_stride,
+                        int32_t n_frames, YdKeyPoint* kps, uint8_t* desc, int32_t cap, int32_t* n_out) {
+  if (!e || !n_out) { set_error("null argument"); return YDORB_ERR_INVALID_ARG; }
+  if (!img || w <= 0 || h <= 0 || n_frames <= 0) {  // empty image: silent return, orbExtractor.cpp:357-359
+    for (int f = 0; f < std::max(n_frames, 0); f++) n_out[f] = 0;
+    return YDORB_OK;
+  }
+  if (!kps || !desc || stride < w) { set_error("invalid argument"); return YDORB_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(e->cfg.device));
+  int rc = ensurePlan(e, w, h, n_frames);
+  if (rc) return rc;
+  const int Q = e->sumQuota;
+  for (int f = 0; f < n_frames; f++)
+    for (int y = 0; y < h; y++) memcpy(e->h_img + (size_t)f * e->imgBytes + (size_t)y * w, img + f * frame_stride + (size_t)y * stride, w);
+  HIPCHK(hipMemcpyAsync(e->d_img, e->h_img, e->imgBytes * n_frames, hipMemcpyHostToDevice, e->stream));
+  rc = enqueue(e, e->d_img, w, e->imgBytes, n_frames, e->d_kps, e->d_desc, Q, e->d_nOut, e->stream);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(e->h_nOut, e->d_nOut, sizeof(int) * n_frames, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_status, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_kps, e->d_kps, sizeof(YdKeyPoint) * (size_t)Q * n_frames, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_desc, e->d_desc, (size_t)32 * Q * n_frames, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  collectProfile(e);
+  rc = checkStatus(e);
+  if (rc) return rc;
+  for (int f = 0; f < n_frames; f++) {
+    const int n = e->h_nOut[f];
+    if (n > cap) { set_error("frame %d has %d keypoints, caller capacity %d", f, n, cap); return YDORB_ERR_CAPACITY; }
+    memcpy(kps + (size_t)f * cap, e->h_kps + (size_t)f * Q, sizeof(YdKeyPoint) * n);
+    memcpy(desc + (size_t)f * cap * 32, e->h_desc + (size_t)f * Q * 32, (size_t)32 * n);
+    n_out[f] = n;
+  }
+  return YDORB_OK;
+}
+
+int ydorb_extract(ydorb_extractor_t* e, const uint8_t* img, int32_t w, int32_t h, int32_t stride, YdKeyPoint* kps, uint8_t* desc,
+                  int32_t cap, int32_t* n_out) {
+  return ydorb_extract_batch(e, img, w, h, stride, 0, 1, kps, desc, cap, n_out);
+}
+
+int ydorb_extractor_pyramid(const ydorb_extractor_t* e, int32_t frame, int32_t level, const uint8_t** d_roi, int32_t* w, int32_t* h,
+                            int32_t* stride) {
+  if (!e || !e->planValid || frame < 0 || frame >= e->lastFrames || level < 0 || level >= e->cfg.n_levels) {
+    set_error("no pyramid for frame %d level %d", frame, level);
+    return YDORB_ERR_INVALID_ARG;
+  }
+  const LevelDev& L = e->plan.dev.lv[level];
+  if (d_roi) *d_roi = e->d_pyr + (size_t)frame * e->plan.pyrFrameStride + L.padOff + (size_t)kPad * L.pitch + kPad;
+  if (w) *w = L.w;
+  if (h) *h = L.h;
+  if (stride) *stride = L.pitch;
+  return YDORB_OK;
+}
+
+int ydorb_extractor_read_level(ydorb_extractor_t* e, int32_t frame, int32_t level, uint8_t* dst, size_t dst_bytes) {
+  const uint8_t* roi;
+  int w, h, stride;
+  int rc = ydorb_extractor_pyramid(e, frame, level, &roi, &w, &h, &stride);
+  if (rc) return rc;
+  const size_t need = (size_t)(w + 2 * kPad) * (h + 2 * kPad);
+  if (!dst || dst_bytes < need) { set_error("need %zu bytes", need); return YDORB_ERR_CAPACITY; }
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy2D(dst, w + 2 * kPad, roi - (size_t)kPad * stride - kPad, stride, w + 2 * kPad, h + 2 * kPad, hipMemcpyDeviceToHost));
+  return YDORB_OK;
+}
+
+int ydorb_extractor_debug_read(ydorb_extractor_t* e, int32_t what, int32_t frame, int32_t level, void* dst, size_t dst_bytes,
+                               size_t* written) {
+  if (!e || !e->planValid || frame < 0 || frame >= e->lastFrames || level < 0 || level >= e->cfg.n_levels || !dst || !written) {
+    set_error("invalid argument");
+    return YDORB_ERR_INVALID_ARG;
+  }
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const HostPlan& P = e->plan;
+  const PlanDev& D = P.dev;
+  const LevelDev& L = D.lv[level];
+  if (what == 0) {
+    const size_t need = (size_t)L.w * L.h;
+    if (dst_bytes < need) { set_error("need %zu bytes", need); return YDORB_ERR_CAPACITY; }
+    HIPCHK(hipMemcpy2D(dst, L.w, e->d_blur + (size_t)frame * P.blurFrameStride + L.blurOff, L.blurPitch, L.w, L.h, hipMemcpyDeviceToHost));
+    *written = need;
+    return YDORB_OK;
+  }
+  if (what == 1) {
+    std::vector<uint32_t> cnt(L.nCells), buf((size_t)L.nCells * D.cellCap);
+    if (L.nCells) {
+      HIPCHK(hipMemcpy(cnt.data(), e->d_cellCount + (size_t)frame * D.nCellsTotal + L.cellBegin, sizeof(uint32_t) * L.nCells, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(buf.data(), e->d_cellCand + ((size_t)frame * D.nCellsTotal + L.cellBegin) * D.cellCap,
+                       sizeof(uint32_t) * buf.size(), hipMemcpyDeviceToHost));
+    }
+    YdKeyPoint* o = (YdKeyPoint*)dst;
+    size_t n = 0;
+    for (int c = 0; c < L.nCells; c++)
+      for (uint32_t i = 0; i < cnt[c]; i++) {
+        if ((n + 1) * sizeof(YdKeyPoint) > dst_bytes) { set_error("candidate buffer too small"); return YDORB_ERR_CAPACITY; }
+        const uint32_t pk = buf[(size_t)c * D.cellCap + i];
+        o[n++] = YdKeyPoint{(float)qt_x(pk), (float)qt_y(pk), 7.f, -1.f, (float)qt_r(pk), 0, -1};
+      }
+    *written = n * sizeof(YdKeyPoint);
+    return YDORB_OK;
+  }
+  if (what == 2) {
+    int counts[kMaxLevels];
+    HIPCHK(hipMemcpy(counts, e->d_lvlCount + frame * kMaxLevels, sizeof(counts), hipMemcpyDeviceToHost));
+    const int n = counts[level];
+    if ((size_t)n * sizeof(YdKeyPoint) > dst_bytes) { set_error("keypoint buffer too small"); return YDORB_ERR_CAPACITY; }
+    std::vector<uint32_t> pk(std::max(n, 1));
+    std::vector<float> ang(std::max(n, 1));
+    if (n) {
+      HIPCHK(hipMemcpy(pk.data(), e->d_lvlKp + (size_t)frame * D.sumQuota + L.kpOff, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(ang.data(), e->d_lvlAngle + (size_t)frame * D.sumQuota + L.kpOff, sizeof(float) * n, hipMemcpyDeviceToHost));
+    }
+    YdKeyPoint* o = (YdKeyPoint*)dst;
+    for (int i = 0; i < n; i++)
+      o[i] = YdKeyPoint{(float)(qt_x(pk[i]) + kBorder), (float)(qt_y(pk[i]) + kBorder), L.size, ang[i], (float)qt_r(pk[i]), level, -1};
+    *written = (size_t)n * sizeof(YdKeyPoint);
+    return YDORB_OK;
+  }
+  set_error("unknown debug stage %d", what);
+  return YDORB_ERR_INVALID_ARG;
+}
+
+int ydorb_extractor_set_profiling(ydorb_extractor_t* e, int32_t on) {
+  if (!e) return YDORB_ERR_INVALID_ARG;
+  e->profiling = on != 0;
+  for (double& m : e->stageMs) m = 0;
+  e->stageCalls = 0;
+  return YDORB_OK;
+}
+
+int ydorb_extractor_stage_times(ydorb_extractor_t* e, int32_t max_stages, const char** names, float* ms, int32_t* n_stages) {
+  if (!e || !n_stages) return YDORB_ERR_INVALID_ARG;
+  if (e->profiling && e->stageCalls == 0 && e->lastFrames > 0) {  // device-resident path: collect after the caller synchronised
+    if (hipStreamSynchronize(e->stream) == hipSuccess) collectProfile(e);
+  }
+  const int n = std::min<int>(max_stages, ST_COUNT);
+  for (int i = 0; i < n; i++) {
+    if (names) names[i] = kStageNames[i];
+    if (ms) ms[i] = e->stageCalls ? (float)(e->stageMs[i] / e->stageCalls) : 0.f;
+  }
+  *n_stages = n;
+  return YDORB_OK;
+}
+
+}  // extern "C"
