@@ -116,6 +116,94 @@ int ydorb_extractor_set_profiling(ydorb_extractor_t* h, int32_t on);
 int ydorb_extractor_stage_times(ydorb_extractor_t* h, int32_t max_stages, const char** names, float* ms,
                                 int32_t* n_stages);
 
+/* ------------------------------------------------------------------------------------------
+ * Descriptor matcher.  Replaces YDORBSLAM::OrbMatcher (src/orbMatcher.hpp:24-66) for the
+ * search-by-projection and search-by-BoW families.  Frame / KeyFrame / MapPoint objects do not cross the
+ * ABI: a map point is a query row (descriptor + projected position + flags) and `assigned[idx]` stands
+ * for frame.m_v_sptrMapPoints[idx] (a query index, or -1 for null).  The float geometry that projects map
+ * points (cv::Mat products at orbMatcher.cpp:84-93,171-177; Frame::isInCameraFrustum, frame.cpp:295-326)
+ * stays in the adapter class, which fills YdQuery with the very floats the reference computes.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct YdQuery {
+  float u, v;          /* projected image position */
+  float r;             /* radius given to Frame::getKeyPointsInArea (frame.cpp:337) */
+  int32_t min_level, max_level; /* its _minScaleLevel/_maxScaleLevel arguments (-1 = open) */
+  float ur;            /* projected right-image x; stereo test |ur - rightX[idx]| <= rs (orbMatcher.cpp:41,109) */
+  float rs;
+  float angle;         /* angle of the source keypoint (rotation histogram, orbMatcher.cpp:121) */
+  int32_t level;       /* predicted / source scale level */
+  int32_t flags;       /* bit0: query takes part; bit1: its map point has observations > 0 */
+} YdQuery;
+
+typedef struct YdFrameView {   /* the parts of YDORBSLAM::Frame the searches read (src/frame.hpp) */
+  const YdKeyPoint* kps;       /* m_v_keyPoints (undistorted) */
+  const uint8_t* desc;         /* m_cvMat_descriptors, n x 32 */
+  const float* right_x;        /* m_v_rightXcords or NULL */
+  int32_t n;
+  float min_x, max_x, min_y, max_y; /* m_flt_minX.. (image bounds; the 64x48 grid spans them, frame.cpp:99-100) */
+} YdFrameView;
+
+typedef struct ydorb_matcher ydorb_matcher_t;
+int ydorb_matcher_create(int32_t device, ydorb_matcher_t** out);
+void ydorb_matcher_destroy(ydorb_matcher_t* h);
+
+/* static int OrbMatcher::computeDescriptorsDistance(a, b), src/orbMatcher.cpp:11-23 (one pair, host). */
+int ydorb_descriptor_distance(const uint8_t* a32, const uint8_t* b32);
+/* The same distance for n row pairs on the GPU: out[i] = d(a[i], b[i]) (host pointers). */
+int ydorb_descriptor_distance_rows(ydorb_matcher_t* h, const uint8_t* a, const uint8_t* b, int32_t n, int32_t* out);
+
+/* Frame::getKeyPointsInArea, src/frame.cpp:337-361, on the GPU grid (ordered as the reference returns them). */
+int ydorb_frame_keypoints_in_area(ydorb_matcher_t* h, const YdFrameView* frame, float x, float y, float r, int32_t min_level,
+                                  int32_t max_level, int32_t* out_idx, int32_t cap, int32_t* n_out);
+
+#define YDORB_SEARCH_FRAME_MAPPOINT 0   /* searchByProjectionInFrameAndMapPoint,       orbMatcher.cpp:24-64   */
+#define YDORB_SEARCH_LAST_CURRENT 1     /* searchByProjectionInLastAndCurrentFrame,    orbMatcher.cpp:65-155  */
+#define YDORB_SEARCH_KEYFRAME_CURRENT 2 /* searchByProjectionInKeyFrameAndCurrentFrame, orbMatcher.cpp:156-239 */
+#define YDORB_SEARCH_BOW_KEYFRAME_FRAME 3 /* searchByBowInKeyFrameAndFrame,            orbMatcher.cpp:303-379 */
+#define YDORB_SEARCH_BOW_TWO_KEYFRAMES 4  /* searchByBowInTwoKeyFrames,                orbMatcher.cpp:380-462 */
+
+/* Projection family.  taken[idx] (in/out, n bytes): 1 where the frame keypoint already holds a map point that
+ * blocks it (observations > 0 for modes 0/1, any map point for mode 2).  assigned[idx] (in/out, n ints): query
+ * index written where the reference writes frame.m_v_sptrMapPoints[bestIdx]; untouched entries keep their value.
+ * *n_matches = the int the reference returns (it counts overwrites and subtracts histogram culls exactly as
+ * orbMatcher.cpp does). */
+int ydorb_search_by_projection(ydorb_matcher_t* h, int32_t mode, const YdFrameView* frame, const YdQuery* queries,
+                               const uint8_t* qdesc, int32_t nq, float ratio, int32_t orb_dist, int32_t check_orientation,
+                               uint8_t* taken, int32_t* assigned, int32_t* n_matches);
+
+/* DBoW3::FeatureVector (std::map<node, vector<feature>>) as CSR: node_ids ascending, node_start[n_nodes+1], feat[]. */
+typedef struct YdFeatureVector {
+  const uint32_t* node_ids;
+  const int32_t* node_start;
+  const int32_t* feat;
+  int32_t n_nodes;
+} YdFeatureVector;
+typedef struct YdBowSide {
+  const YdKeyPoint* kps;
+  const uint8_t* desc;
+  const uint8_t* valid;   /* 1 where the feature has a good map point (may be NULL for the frame side of mode 3) */
+  int32_t n;
+  YdFeatureVector fv;
+} YdBowSide;
+/* BoW family.  mode 3: out[n_b] = keyframe-A feature whose map point goes to frame feature idx (or -1);
+ * mode 4: out[n_a] = matched feature of keyframe B (or -1). */
+int ydorb_search_by_bow(ydorb_matcher_t* h, int32_t mode, const YdBowSide* a, const YdBowSide* b, float ratio,
+                        int32_t check_orientation, int32_t* out, int32_t* n_matches);
+
+/* Device-resident streaming form used after ydorb_extract_batch_device: for f = 0..n_frames-2, the keypoints of
+ * frame f are searched in frame f+1 with the searchByProjectionInLastAndCurrentFrame rules (mode 1; position
+ * prediction = d_affine[f] (2x3, row-major) applied to the keypoint, NULL = identity; window th*scaleFactor[octave];
+ * levels octave-1..octave+1).  d_assigned: int32 [n_frames-1][cap] (query index per frame-f+1 keypoint or -1),
+ * d_counts: int32 [n_frames-1].  Asynchronous on `stream` (or the matcher's own). */
+int ydorb_match_consecutive_device(ydorb_matcher_t* h, const YdKeyPoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
+                                   int32_t cap, int32_t n_frames, int32_t width, int32_t height, float th,
+                                   const float* scale_factors, int32_t n_levels, const float* d_affine, int32_t check_orientation,
+                                   int32_t* d_assigned, int32_t* d_counts, void* stream);
+int ydorb_matcher_synchronize(ydorb_matcher_t* h);
+/* average device ms of grid build / gather / resolve over calls since enabling (HIP events on the launch stream) */
+int ydorb_matcher_set_profiling(ydorb_matcher_t* h, int32_t on);
+int ydorb_matcher_stage_times(ydorb_matcher_t* h, int32_t max_stages, const char** names, float* ms, int32_t* n_stages);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,259 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+//
+// CPU restatement of YDORBSLAM::OrbMatcher's search-by-projection / search-by-BoW family
+// (reference src/orbMatcher.cpp) and of the Frame candidate generator it depends on
+// (src/frame.cpp:249-264, 291-294, 327-361) on POD arrays.  The reference versions walk
+// Frame / KeyFrame / MapPoint objects; here a "map point" is a query row (descriptor + projected
+// position + flags) and `assigned[idx]` stands for frame.m_v_sptrMapPoints[idx] (query index or -1).
+// The float geometry that produces the projected positions (cv::Mat 3x3 products) stays in the caller,
+// exactly as the C ABI draws the boundary (include/ydorb/c_api.h, "matcher").
+//
+// PARITY STATUS: no reference test pins any matcher result and the reference cannot be
+// built here (needs OpenCV + DBoW3): "parity unpinned" beyond the line-by-line restatement; M0 is
+// cross-checked against a numpy popcount in tests/test_oracle_matcher.py.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct KeyPoint {
+  float x, y, size, angle, response;
+  int octave, class_id;
+};
+
+const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;  // orbMatcher.cpp:7-9
+const int GRID_COLS = 64, GRID_ROWS = 48;                 // frame.hpp:137-138
+
+// orbMatcher.cpp:11-23
+int descriptorDistance(const uint8_t* a, const uint8_t* b) {
+  const int32_t* pa = (const int32_t*)a;
+  const int32_t* pb = (const int32_t*)b;
+  int dist = 0;
+  for (int i = 0; i < 8; i++, pa++, pb++) {
+    unsigned int v = *pa ^ *pb;
+    v = v - ((v >> 1) & 0x55555555);
+    v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+    dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+  }
+  return dist;
+}
+
+struct Frame {
+  int n = 0;
+  std::vector<KeyPoint> kps;
+  std::vector<uint8_t> desc;
+  std::vector<float> rightX;
+  float minX, maxX, minY, maxY, gridWInv, gridHInv;
+  std::vector<int> grid[GRID_COLS][GRID_ROWS];
+
+  // frame.cpp:327-336 (rounds instead of flooring, and uses minX for y — both kept)
+  bool locationInGrid(const KeyPoint& kp, int& lx, int& ly) const {
+    lx = (int)roundf((kp.x - minX) * gridWInv);
+    ly = (int)roundf((kp.y - minX) * gridHInv);
+    return !(lx < 0 || lx >= GRID_COLS || ly < 0 || ly >= GRID_ROWS);
+  }
+  // frame.cpp:249-264
+  void assignToGrid() {
+    for (int i = 0; i < n; i++) {
+      int lx, ly;
+      if (locationInGrid(kps[i], lx, ly)) grid[lx][ly].push_back(i);
+    }
+  }
+  // frame.cpp:337-361 (per-axis test `|dx| > r && |dy| < r` and the `octave < maxLevel` skip are as written)
+  std::vector<int> keyPointsInArea(float x, float y, float r, int minLevel, int maxLevel) const {
+    std::vector<int> out;
+    const int minCellX = std::max(0, (int)floorf((x - minX - r) * gridWInv));
+    const int maxCellX = std::min(GRID_COLS - 1, (int)ceilf((x - minX + r) * gridWInv));
+    const int minCellY = std::max(0, (int)floorf((y - minY - r) * gridHInv));
+    const int maxCellY = std::min(GRID_ROWS - 1, (int)ceilf((y - minY + r) * gridHInv));
+    if (minCellX < GRID_COLS && maxCellX >= 0 && minCellY < GRID_ROWS && maxCellY >= 0) {
+      for (int ix = minCellX; ix <= maxCellX; ix++)
+        for (int iy = minCellY; iy <= maxCellY; iy++)
+          for (int idx : grid[ix][iy]) {
+            if (minLevel > 0 || maxLevel >= 0) {
+              if (kps[idx].octave < minLevel || (maxLevel >= 0 && kps[idx].octave < maxLevel)) continue;
+            }
+            if (fabsf(kps[idx].x - x) > r && fabsf(kps[idx].y - y) < r) out.push_back(idx);
+          }
+    }
+    return out;
+  }
+};
+
+// orbMatcher.cpp:827-854
+void threeMaxima(const std::vector<std::vector<int>>& hist, int L, int& i1, int& i2, int& i3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = (int)hist[i].size();
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+    else if (s > max3) { max3 = s; i3 = i; }
+  }
+  if (max2 < max1 / 10) { i3 = -1; i2 = -1; }
+  else if (max3 < max1 / 10) { i3 = -1; }
+}
+
+// rotation-histogram bin, orbMatcher.cpp:121-130 (factor = 1/30, so only bins 0..12 are reachable)
+int rotBin(float a1, float a2) {
+  const float factor = 1.0 / HISTO_LENGTH;
+  float rot = a1 - a2;
+  if (rot < 0.0) rot += 360.0;
+  int bin = (int)round(rot * factor);
+  if (bin == HISTO_LENGTH) bin = 0;
+  return bin;
+}
+
+// One projected query == one MapPoint seen by the search (all derived floats computed by the caller).
+struct Query {
+  float u, v;          // projected position
+  float r;             // window radius handed to getKeyPointsInArea
+  int minLevel, maxLevel;
+  float ur;            // projected right-image x (stereo consistency)
+  float rs;            // stereo tolerance
+  float angle;         // keypoint angle of the source observation (rotation histogram)
+  int level;           // predicted / source scale level (M1 acceptance compares levels of best & second)
+  int flags;           // bit0 valid, bit1 the map point has observations > 0
+};
+
+}  // namespace
+
+extern "C" {
+
+int yo_descriptor_distance(const uint8_t* a, const uint8_t* b) { return descriptorDistance(a, b); }
+
+void* yo_frame_create(const void* kps, int n, const uint8_t* desc, const float* rightX, float minX, float maxX, float minY,
+                      float maxY) {
+  Frame* f = new Frame();
+  f->n = n;
+  f->kps.assign((const KeyPoint*)kps, (const KeyPoint*)kps + n);
+  f->desc.assign(desc, desc + (size_t)n * 32);
+  if (rightX) f->rightX.assign(rightX, rightX + n);
+  else f->rightX.assign(n, -1.f);
+  f->minX = minX; f->maxX = maxX; f->minY = minY; f->maxY = maxY;
+  f->gridWInv = static_cast<float>(GRID_COLS) / (maxX - minX);  // frame.cpp:99-100
+  f->gridHInv = static_cast<float>(GRID_ROWS) / (maxY - minY);
+  f->assignToGrid();
+  return f;
+}
+void yo_frame_destroy(void* f) { delete (Frame*)f; }
+
+int yo_frame_keypoints_in_area(void* fp, float x, float y, float r, int minLevel, int maxLevel, int* out, int cap) {
+  std::vector<int> v = ((Frame*)fp)->keyPointsInArea(x, y, r, minLevel, maxLevel);
+  memcpy(out, v.data(), sizeof(int) * std::min((int)v.size(), cap));
+  return (int)v.size();
+}
+
+// mode 0: searchByProjectionInFrameAndMapPoint      orbMatcher.cpp:24-64   (best + second, level rule, <= TH_HIGH)
+// mode 1: searchByProjectionInLastAndCurrentFrame   orbMatcher.cpp:65-155  (best only, < TH_HIGH, rotation histogram)
+// mode 2: searchByProjectionInKeyFrameAndCurrentFrame  :156-239            (best only, <= orbDist, rotation histogram)
+// taken[idx] != 0  <=>  frame.m_v_sptrMapPoints[idx] holds a point with observations > 0 (modes 0,1) or any point (mode 2).
+// assigned[idx]: query index written at :57 / :118 / :203 (or -1).  Returns matchNum.
+int yo_search_by_projection(void* fp, int mode, const void* queries, const uint8_t* qdesc, int nq, float ratio, int orbDist,
+                            int checkOrientation, uint8_t* taken, int* assigned) {
+  Frame& F = *(Frame*)fp;
+  const Query* Q = (const Query*)queries;
+  int matchNum = 0;
+  std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+  for (int q = 0; q < nq; q++) {
+    if (!(Q[q].flags & 1)) continue;
+    const std::vector<int> vIdx = F.keyPointsInArea(Q[q].u, Q[q].v, Q[q].r, Q[q].minLevel, Q[q].maxLevel);
+    if (vIdx.empty()) continue;
+    int bestDist = 256, bestLevel = -1, secondDist = 256, secondLevel = -1, bestIdx = -1;
+    for (int idx : vIdx) {
+      if (taken[idx]) continue;
+      if (mode != 2 && !(F.rightX[idx] <= 0 || fabsf(Q[q].ur - F.rightX[idx]) <= Q[q].rs)) continue;
+      const int dist = descriptorDistance(qdesc + (size_t)q * 32, &F.desc[(size_t)idx * 32]);
+      if (dist < bestDist) {
+        secondDist = bestDist; bestDist = dist;
+        secondLevel = bestLevel; bestLevel = F.kps[idx].octave;
+        bestIdx = idx;
+      } else if (dist < secondDist) {
+        secondLevel = F.kps[idx].octave;
+        secondDist = dist;
+      }
+    }
+    bool accept;
+    if (mode == 0) accept = bestDist <= TH_HIGH && (bestLevel != secondLevel || bestDist <= ratio * secondDist);
+    else if (mode == 1) accept = bestDist < TH_HIGH;
+    else accept = bestDist <= orbDist;
+    if (!accept) continue;
+    assigned[bestIdx] = q;
+    taken[bestIdx] = mode == 2 ? 1 : ((Q[q].flags & 2) ? 1 : 0);
+    matchNum++;
+    if (mode != 0 && checkOrientation) rotHist[rotBin(Q[q].angle, F.kps[bestIdx].angle)].push_back(bestIdx);
+  }
+  if (mode != 0 && checkOrientation) {
+    int i1 = -1, i2 = -1, i3 = -1;
+    threeMaxima(rotHist, HISTO_LENGTH, i1, i2, i3);
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != i1 && i != i2 && i != i3)
+        for (int idx : rotHist[i]) { assigned[idx] = -1; matchNum--; }
+  }
+  return matchNum;
+}
+
+// DBoW3::FeatureVector as CSR: nodeIds ascending (std::map order), nodeStart[nNodes+1], feat[] in append order.
+// mode 3: searchByBowInKeyFrameAndFrame  orbMatcher.cpp:303-379 — out[frameIdx] = keyframe feature index (stands for its MapPoint)
+// mode 4: searchByBowInTwoKeyFrames      orbMatcher.cpp:380-462 — out[firstIdx] = second-keyframe feature index
+// validA[i] != 0 <=> keyframe A's feature i has a good MapPoint; validB likewise (mode 4 only).
+int yo_search_by_bow(int mode, const void* kpsA, const uint8_t* descA, int nA, const uint8_t* validA, const uint32_t* nodeIdsA,
+                     const int* nodeStartA, int nNodesA, const int* featA, const void* kpsB, const uint8_t* descB, int nB,
+                     const uint8_t* validB, const uint32_t* nodeIdsB, const int* nodeStartB, int nNodesB, const int* featB,
+                     float ratio, int checkOrientation, int* out) {
+  const KeyPoint* KA = (const KeyPoint*)kpsA;
+  const KeyPoint* KB = (const KeyPoint*)kpsB;
+  const int nOut = mode == 3 ? nB : nA;
+  for (int i = 0; i < nOut; i++) out[i] = -1;
+  std::vector<uint8_t> matchedB(nB, 0);
+  std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+  int matchNum = 0;
+  int a = 0, b = 0;
+  while (a < nNodesA && b < nNodesB) {
+    if (nodeIdsA[a] == nodeIdsB[b]) {
+      for (int ia = nodeStartA[a]; ia < nodeStartA[a + 1]; ia++) {
+        const int idxA = featA[ia];
+        if (!validA[idxA]) continue;
+        int bestDist = 256, secondDist = 256, bestIdx = -1;
+        for (int ib = nodeStartB[b]; ib < nodeStartB[b + 1]; ib++) {
+          const int idxB = featB[ib];
+          if (matchedB[idxB]) continue;
+          if (mode == 4 && !validB[idxB]) continue;
+          const int dist = descriptorDistance(descA + (size_t)idxA * 32, descB + (size_t)idxB * 32);
+          if (dist < bestDist) { secondDist = bestDist; bestDist = dist; bestIdx = idxB; }
+          else if (dist < secondDist) secondDist = dist;
+        }
+        if (bestDist <= TH_LOW && static_cast<float>(bestDist) < ratio * static_cast<float>(secondDist)) {
+          matchedB[bestIdx] = 1;
+          if (mode == 3) out[bestIdx] = idxA; else out[idxA] = bestIdx;
+          if (checkOrientation) rotHist[rotBin(KA[idxA].angle, KB[bestIdx].angle)].push_back(mode == 3 ? bestIdx : idxA);
+          matchNum++;
+        }
+      }
+      a++; b++;
+    } else if (nodeIdsA[a] < nodeIdsB[b]) {
+      a = (int)(std::lower_bound(nodeIdsA, nodeIdsA + nNodesA, nodeIdsB[b]) - nodeIdsA);
+    } else {
+      b = (int)(std::lower_bound(nodeIdsB, nodeIdsB + nNodesB, nodeIdsA[a]) - nodeIdsB);
+    }
+  }
+  if (checkOrientation) {
+    int i1 = -1, i2 = -1, i3 = -1;
+    threeMaxima(rotHist, HISTO_LENGTH, i1, i2, i3);
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != i1 && i != i2 && i != i3)
+        for (int idx : rotHist[i]) { out[idx] = -1; matchNum--; }
+  }
+  return matchNum;
+}
+
+void yo_three_maxima(const int* sizes, int L, int* idx3) {
+  std::vector<std::vector<int>> h(L);
+  for (int i = 0; i < L; i++) h[i].assign(sizes[i], 0);
+  idx3[0] = idx3[1] = idx3[2] = -1;
+  threeMaxima(h, L, idx3[0], idx3[1], idx3[2]);
+}
+int yo_rot_bin(float a1, float a2) { return rotBin(a1, a2); }
+}

@@ -62,6 +62,20 @@ def lib():
         L.yo_sinf_det.argtypes = [C.c_float]
         L.yo_trig_mismatch_count.restype = C.c_long
         L.yo_trig_mismatch_count.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        L.yo_descriptor_distance.restype = C.c_int
+        L.yo_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.yo_frame_create.restype = C.c_void_p
+        L.yo_frame_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float]
+        L.yo_frame_destroy.argtypes = [C.c_void_p]
+        L.yo_frame_keypoints_in_area.restype = C.c_int
+        L.yo_frame_keypoints_in_area.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.yo_search_by_projection.restype = C.c_int
+        L.yo_search_by_projection.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.yo_search_by_bow.restype = C.c_int
+        L.yo_search_by_bow.argtypes = [C.c_int] + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] * 2 + [C.c_float, C.c_int, C.c_void_p]
+        L.yo_three_maxima.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.yo_rot_bin.restype = C.c_int
+        L.yo_rot_bin.argtypes = [C.c_float, C.c_float]
         _LIB = L
     return _LIB
 
@@ -176,3 +190,57 @@ def gauss_kernel_fixed(n, sigma, bits):
 
 def fast_atan2(y, x):
     return lib().yo_fast_atan2(float(y), float(x))
+
+
+# ---------------------------------------------------------------------------------------------
+# matcher oracle (oracle/matcher_oracle.cpp)
+# ---------------------------------------------------------------------------------------------
+QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("r", "<f4"), ("min_level", "<i4"), ("max_level", "<i4"),
+                        ("ur", "<f4"), ("rs", "<f4"), ("angle", "<f4"), ("level", "<i4"), ("flags", "<i4")])
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib().yo_descriptor_distance(_p(a), _p(b))
+
+
+class FrameOracle:
+    """POD stand-in for YDORBSLAM::Frame: keypoints, descriptors, right x, bounds, 64x48 grid (frame.cpp:249-264)."""
+
+    def __init__(self, kps, desc, bounds, right_x=None):
+        self.kps = np.ascontiguousarray(kps, KP_DTYPE)
+        self.desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        self.right_x = None if right_x is None else np.ascontiguousarray(right_x, np.float32)
+        self.n = len(self.kps)
+        self.h = lib().yo_frame_create(_p(self.kps), self.n, _p(self.desc), None if self.right_x is None else _p(self.right_x), *[float(b) for b in bounds])
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().yo_frame_destroy(self.h)
+            self.h = None
+
+    def keypoints_in_area(self, x, y, r, min_level=-1, max_level=-1):
+        out = np.zeros(max(self.n, 1), np.int32)
+        n = lib().yo_frame_keypoints_in_area(self.h, x, y, r, min_level, max_level, _p(out), len(out))
+        return out[:n].copy()
+
+    def search_by_projection(self, mode, queries, qdesc, ratio, check_orientation, taken=None, assigned=None, orb_dist=0):
+        queries = np.ascontiguousarray(queries, QUERY_DTYPE)
+        qdesc = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
+        taken = np.zeros(self.n, np.uint8) if taken is None else np.ascontiguousarray(taken, np.uint8).copy()
+        assigned = np.full(self.n, -1, np.int32) if assigned is None else np.ascontiguousarray(assigned, np.int32).copy()
+        n = lib().yo_search_by_projection(self.h, mode, _p(queries), _p(qdesc), len(queries), ratio, orb_dist, int(check_orientation), _p(taken), _p(assigned))
+        return n, assigned, taken
+
+
+def search_by_bow(mode, kps_a, desc_a, valid_a, fv_a, kps_b, desc_b, valid_b, fv_b, ratio, check_orientation):
+    """fv_* = (node_ids u32 ascending, node_start i32, feat i32)."""
+    ka = np.ascontiguousarray(kps_a, KP_DTYPE); kb = np.ascontiguousarray(kps_b, KP_DTYPE)
+    da = np.ascontiguousarray(desc_a, np.uint8); db = np.ascontiguousarray(desc_b, np.uint8)
+    va = np.ascontiguousarray(valid_a, np.uint8)
+    vb = np.ones(len(kb), np.uint8) if valid_b is None else np.ascontiguousarray(valid_b, np.uint8)
+    ia, sa, fa = (np.ascontiguousarray(fv_a[0], np.uint32), np.ascontiguousarray(fv_a[1], np.int32), np.ascontiguousarray(fv_a[2], np.int32))
+    ib, sb, fb = (np.ascontiguousarray(fv_b[0], np.uint32), np.ascontiguousarray(fv_b[1], np.int32), np.ascontiguousarray(fv_b[2], np.int32))
+    out = np.full(len(kb) if mode == 3 else len(ka), -1, np.int32)
+    n = lib().yo_search_by_bow(mode, _p(ka), _p(da), len(ka), _p(va), _p(ia), _p(sa), len(ia), _p(fa), _p(kb), _p(db), len(kb), _p(vb), _p(ib), _p(sb), len(ib), _p(fb), ratio, int(check_orientation), _p(out))
+    return n, out

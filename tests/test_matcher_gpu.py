@@ -1,0 +1,138 @@
+"""GPU parity: HIP matcher (C ABI) vs the CPU oracle restatement of orbMatcher.cpp.  Bar: identical integers."""
+import numpy as np
+import pytest
+
+from helpers import bow_nodes, feature_vector, projection_queries, shifted_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scene(oracle_lib):
+    from oracle.orb_oracle import OrbExtractorOracle
+    ex = OrbExtractorOracle(1000)
+    out = []
+    for idx, (dx, dy) in enumerate([(5, -3), (-7, 4)]):
+        a, b = shifted_pair(640, 480, 50 + idx, dx, dy)
+        ka, da = ex.extract(a)
+        kb, db = ex.extract(b)
+        out.append(dict(ka=ka, da=da, kb=kb, db=db, dx=dx, dy=dy, sf=ex.tables()["scale"]))
+    return out
+
+
+def test_descriptor_distance(oracle_lib, scene):
+    import ydorbslam_amd as y
+    s = scene[0]
+    n = min(len(s["ka"]), len(s["kb"]))
+    m = y.OrbMatcher()
+    gpu = m.descriptor_distance_rows(s["da"][:n], s["db"][:n])
+    ref = np.unpackbits(s["da"][:n] ^ s["db"][:n], axis=1).sum(axis=1)
+    assert np.array_equal(gpu, ref)
+    for i in range(0, n, 97):
+        assert y.OrbMatcher.descriptor_distance(s["da"][i], s["db"][i]) == ref[i] == oracle_lib.descriptor_distance(s["da"][i], s["db"][i])
+
+
+def test_keypoints_in_area(oracle_lib, scene):
+    import ydorbslam_amd as y
+    s = scene[0]
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    fo = oracle_lib.FrameOracle(s["kb"], s["db"], bounds)
+    fg = y.FrameView(s["kb"], s["db"], bounds)
+    m = y.OrbMatcher()
+    rng = np.random.default_rng(3)
+    total = 0
+    for _ in range(60):
+        x, yy, r = float(rng.uniform(-20, 660)), float(rng.uniform(-20, 500)), float(rng.uniform(2, 120))
+        lo, hi = [(-1, -1), (0, 3), (2, -1), (1, 2)][int(rng.integers(0, 4))]
+        ref = fo.keypoints_in_area(np.float32(x), np.float32(yy), np.float32(r), lo, hi)
+        got = m.keypoints_in_area(fg, np.float32(x), np.float32(yy), np.float32(r), lo, hi)
+        assert np.array_equal(ref, got)
+        total += len(ref)
+    assert total > 200
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("stereo", [False, True])
+def test_search_by_projection(oracle_lib, scene, mode, stereo):
+    import ydorbslam_amd as y
+    for si, s in enumerate(scene):
+        bounds = (0.0, 640.0, 0.0, 480.0)
+        rng = np.random.default_rng(100 * mode + si)
+        right = None
+        if stereo:
+            right = np.where(rng.random(len(s["kb"])) > 0.3, s["kb"]["x"] - 20 + rng.normal(0, 6, len(s["kb"])), -1).astype(np.float32)
+        for th, ratio, check in [(15, 0.9, True), (3, 0.8, False), (7, 0.6, True)]:
+            q = projection_queries(s["ka"], s["sf"], s["dx"], s["dy"], th, mode, seed=11 * mode + si, stereo=stereo)
+            taken0 = (rng.random(len(s["kb"])) < 0.1).astype(np.uint8)
+            assigned0 = np.where(taken0 > 0, 100000 + np.arange(len(taken0)), -1).astype(np.int32)
+            fo = oracle_lib.FrameOracle(s["kb"], s["db"], bounds, right)
+            n_ref, a_ref, t_ref = fo.search_by_projection(mode, q, s["da"], ratio, check, taken0, assigned0, orb_dist=64)
+            m = y.OrbMatcher(ratio, check)
+            n_gpu, a_gpu, t_gpu = m.search_by_projection(mode, y.FrameView(s["kb"], s["db"], bounds, right), q, s["da"], taken0, assigned0, orb_dist=64)
+            assert n_gpu == n_ref
+            assert np.array_equal(a_gpu, a_ref)
+            assert np.array_equal(t_gpu, t_ref)
+            if th == 15 and not stereo:
+                assert n_ref > (50 if mode < 2 else 0)  # real matches exist (mode 2 keeps dist<=64; the |dx|>r test of frame.cpp:353 rarely offers true pairs)
+
+
+@pytest.mark.parametrize("mode", [3, 4])
+def test_search_by_bow(oracle_lib, scene, mode):
+    import ydorbslam_amd as y
+    for si, s in enumerate(scene):
+        rng = np.random.default_rng(40 + si)
+        fa, fb = feature_vector(bow_nodes(s["da"])), feature_vector(bow_nodes(s["db"]))
+        va = (rng.random(len(s["ka"])) > 0.15).astype(np.uint8)
+        vb = (rng.random(len(s["kb"])) > 0.15).astype(np.uint8)
+        for ratio, check in [(0.7, True), (0.9, False), (0.75, True)]:
+            n_ref, o_ref = oracle_lib.search_by_bow(mode, s["ka"], s["da"], va, fa, s["kb"], s["db"], vb, fb, ratio, check)
+            m = y.OrbMatcher(ratio, check)
+            n_gpu, o_gpu = m.search_by_bow(mode, s["ka"], s["da"], va, y.FeatureVector(*fa), s["kb"], s["db"], vb if mode == 4 else None,
+                                           y.FeatureVector(*fb))
+            assert n_gpu == n_ref
+            assert np.array_equal(o_gpu, o_ref)
+        assert n_ref > 20
+
+
+def test_consecutive_device_matches_host_call(oracle_lib):
+    """The device-resident streaming search equals per-pair mode-1 searches built on the host (and so the oracle)."""
+    import torch
+    import ydorbslam_amd as y
+    from ydorbslam_amd.synth import synth_frame
+    F, W, H = 4, 640, 480
+    base = synth_frame(W + 32, H + 32, 60)
+    imgs = np.stack([np.ascontiguousarray(base[16 + 2 * i:16 + 2 * i + H, 16 + 3 * i:16 + 3 * i + W]) for i in range(F)])
+    ex = y.OrbExtractor(1000, max_batch=F)
+    cap = ex.max_keypoints
+    dev = torch.device("cuda:0")
+    d_img = torch.from_numpy(imgs).to(dev)
+    d_kps = torch.zeros((F, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((F, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(F, dtype=torch.int32, device=dev)
+    ex.extract_batch_device(d_img.data_ptr(), W, H, W, W * H, F, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr())
+    ex.synchronize()
+    m = y.OrbMatcher(0.9, True)
+    d_assigned = torch.zeros((F - 1, cap), dtype=torch.int32, device=dev)
+    d_counts = torch.zeros(F - 1, dtype=torch.int32, device=dev)
+    sf = ex.tables()["scale"]
+    m.match_consecutive_device(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, F, W, H, 15.0, sf, d_assigned.data_ptr(), d_counts.data_ptr())
+    m.synchronize()
+    n = d_n.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(np.uint8).reshape(F, cap, 28).view(y.KP_DTYPE).reshape(F, cap)
+    desc = d_desc.cpu().numpy()
+    assigned = d_assigned.cpu().numpy()
+    counts = d_counts.cpu().numpy()
+    bounds = (0.0, float(W), 0.0, float(H))
+    for f in range(F - 1):
+        ka, kb = kps[f, :n[f]], kps[f + 1, :n[f + 1]]
+        q = np.zeros(n[f], y.QUERY_DTYPE)
+        q["u"], q["v"] = ka["x"], ka["y"]
+        q["r"] = (np.float32(15.0) * sf[ka["octave"]]).astype(np.float32)
+        q["min_level"], q["max_level"] = ka["octave"] - 1, ka["octave"] + 1
+        q["angle"], q["level"] = ka["angle"], ka["octave"]
+        q["flags"] = np.where((q["u"] >= 0) & (q["u"] < W) & (q["v"] >= 0) & (q["v"] < H), 3, 0)
+        fo = oracle_lib.FrameOracle(kb, desc[f + 1, :n[f + 1]], bounds)
+        n_ref, a_ref, _ = fo.search_by_projection(1, q, desc[f, :n[f]], 0.9, True)
+        assert counts[f] == n_ref
+        assert np.array_equal(assigned[f, :n[f + 1]], a_ref)
+        assert n_ref > 20  # (few survive: frame.cpp:353 offers only |dx| > r candidates, then the 3-bin histogram cull)

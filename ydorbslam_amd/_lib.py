@@ -51,7 +51,31 @@ SYMBOLS = {
     "ydorb_extractor_debug_read": (C.c_int, [_VP, _I, _I, _I, _VP, _Z, C.POINTER(_Z)]),
     "ydorb_extractor_set_profiling": (C.c_int, [_VP, _I]),
     "ydorb_extractor_stage_times": (C.c_int, [_VP, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_I)]),
+    "ydorb_matcher_create": (C.c_int, [_I, C.POINTER(_VP)]),
+    "ydorb_matcher_destroy": (None, [_VP]),
+    "ydorb_descriptor_distance": (C.c_int, [_VP, _VP]),
+    "ydorb_descriptor_distance_rows": (C.c_int, [_VP, _VP, _VP, _I, _VP]),
+    "ydorb_frame_keypoints_in_area": (C.c_int, [_VP, _VP, C.c_float, C.c_float, C.c_float, _I, _I, _VP, _I, C.POINTER(_I)]),
+    "ydorb_search_by_projection": (C.c_int, [_VP, _I, _VP, _VP, _VP, _I, C.c_float, _I, _I, _VP, _VP, C.POINTER(_I)]),
+    "ydorb_search_by_bow": (C.c_int, [_VP, _I, _VP, _VP, C.c_float, _I, _VP, C.POINTER(_I)]),
+    "ydorb_match_consecutive_device": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, C.c_float, _VP, _I, _VP, _I, _VP, _VP, _VP]),
+    "ydorb_matcher_synchronize": (C.c_int, [_VP]),
+    "ydorb_matcher_set_profiling": (C.c_int, [_VP, _I]),
+    "ydorb_matcher_stage_times": (C.c_int, [_VP, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_I)]),
 }
+
+
+class YdFrameView(C.Structure):
+    _fields_ = [("kps", _VP), ("desc", _VP), ("right_x", _VP), ("n", _I), ("min_x", C.c_float), ("max_x", C.c_float),
+                ("min_y", C.c_float), ("max_y", C.c_float)]
+
+
+class YdFeatureVector(C.Structure):
+    _fields_ = [("node_ids", _VP), ("node_start", _VP), ("feat", _VP), ("n_nodes", _I)]
+
+
+class YdBowSide(C.Structure):
+    _fields_ = [("kps", _VP), ("desc", _VP), ("valid", _VP), ("n", _I), ("fv", YdFeatureVector)]
 
 
 def lib():
@@ -61,6 +85,13 @@ def lib():
         path = library_path()
         if not os.path.exists(path):
             raise YdorbError("%s is missing: build it with ydorbslam_amd.build_library(); the hot path has no CPU fallback" % path)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64; loading it
+        # first lets libydorb.so bind to that same copy (same SONAME) instead of bringing /opt/rocm's beside it,
+        # which leaves torch with "No HIP GPUs are available".  Plumbing only: nothing here computes with torch.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         try:
             L = C.CDLL(path)
         except OSError as e:

@@ -1,0 +1,427 @@
+// gfx950 HIP kernels of the descriptor matcher (reference src/orbMatcher.cpp + the Frame grid of
+// src/frame.cpp:249-264,327-361).
+//
+// The reference's searches are sequential and greedy: a keypoint that receives a map point is skipped by
+// every later query (orbMatcher.cpp:40,106,194,325), so the result depends on query order.  The GPU design
+// splits each search into
+//   (1) k_grid_build      one workgroup per frame: the 64x48 candidate grid as a CSR (counting sort that keeps
+//                         ascending keypoint index inside a cell, i.e. push_back order);
+//   (2) k_gather_*        one 64-lane wave per query, all queries of all calls in parallel: candidate list in
+//                         the reference's scan order + 256-bit Hamming distance (4 x 64-bit popcount per pair),
+//                         appended to a record pool as (dist << 16 | idx);
+//   (3) k_resolve         one wave per search call: replays the queries in order; per query a wavefront
+//                         min-reduction over (dist, scan position) of the not-yet-taken candidates gives exactly
+//                         the best / second-best the sequential loop would keep, then the acceptance rule,
+//                         the "taken" update and the rotation histogram are applied.
+// Everything is integer except the window arithmetic, which uses the same single float operations as the CPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace ydorb {
+
+constexpr int kGridCols = 64, kGridRows = 48, kGridCells = kGridCols * kGridRows;  // frame.hpp:137-138
+constexpr int kHistLen = 30, kThHigh = 100, kThLow = 50;                             // orbMatcher.cpp:7-9
+
+struct KeyPointDev { float x, y, size, angle, response; int octave, class_id; };
+struct QueryDev {  // == YdQuery
+  float u, v, r;
+  int minLevel, maxLevel;
+  float ur, rs, angle;
+  int level, flags;
+};
+struct FrameDev {  // one target frame of a batched call
+  const KeyPointDev* kps;
+  const uint8_t* desc;
+  const float* rightX;  // may be null (monocular: every entry <= 0)
+  const int* nPtr;      // device count (batched pipeline) or null
+  int n;                // used when nPtr is null
+  float minX, minY, gridWInv, gridHInv;
+  int* cellStart;       // [kGridCells + 1]
+  int* cellIdx;         // [cap]
+};
+__device__ __forceinline__ int frame_n(const FrameDev& F) { return F.nPtr ? *F.nPtr : F.n; }
+
+// ---------------------------------------------------------------------------------------------------
+// Frame::assignKeyPointsToGrid + computeLocationInGrid (frame.cpp:249-264,327-336): rounds, and uses minX for y.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_grid_build(const FrameDev* __restrict__ frames, int cap) {
+  __shared__ int hist[kGridCells];
+  __shared__ int wsum[4];
+  extern __shared__ int16_t cellOf[];  // [cap]
+  const FrameDev F = frames[blockIdx.x];
+  const int n = min(frame_n(F), cap);
+  for (int c = threadIdx.x; c < kGridCells; c += 256) hist[c] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const KeyPointDev kp = F.kps[i];
+    const int lx = (int)roundf(__fmul_rn(__fsub_rn(kp.x, F.minX), F.gridWInv));
+    const int ly = (int)roundf(__fmul_rn(__fsub_rn(kp.y, F.minX), F.gridHInv));
+    int cell = -1;
+    if (!(lx < 0 || lx >= kGridCols || ly < 0 || ly >= kGridRows)) {
+      cell = lx * kGridRows + ly;
+      atomicAdd(&hist[cell], 1);
+    }
+    cellOf[i] = (int16_t)cell;
+  }
+  __syncthreads();
+  // exclusive scan of 3072 counts: 12 per thread
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int local[12], s = 0;
+#pragma unroll
+  for (int k = 0; k < 12; k++) { local[k] = s; s += hist[threadIdx.x * 12 + k]; }
+  int x = s;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+  if (lane == 63) wsum[wv] = x;
+  __syncthreads();
+  int off = x - s;
+  for (int j = 0; j < wv; j++) off += wsum[j];
+#pragma unroll
+  for (int k = 0; k < 12; k++) F.cellStart[threadIdx.x * 12 + k] = off + local[k];
+  if (threadIdx.x == 255) F.cellStart[kGridCells] = off + s;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 12; k++) hist[threadIdx.x * 12 + k] = off + local[k];  // now: start offsets
+  __syncthreads();
+  // stable fill: rank inside the cell = number of earlier keypoints with the same cell
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int cell = cellOf[i];
+    if (cell < 0) continue;
+    int rank = 0;
+    for (int j = 0; j < i; j++) rank += cellOf[j] == cell;
+    F.cellIdx[hist[cell] + rank] = i;
+  }
+}
+
+__device__ __forceinline__ int hamming256(const uint8_t* a, const uint8_t* b) {
+  const uint4 a0 = *reinterpret_cast<const uint4*>(a), a1 = *reinterpret_cast<const uint4*>(a + 16);
+  const uint4 b0 = *reinterpret_cast<const uint4*>(b), b1 = *reinterpret_cast<const uint4*>(b + 16);
+  return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
+         __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+struct CallDev {          // one search call (one target frame, one ordered query list)
+  int frame;              // index into frames[] (projection family)
+  const KeyPointDev* tkps; // target keypoints (octave / angle of the winners)
+  const float* qAngle;    // per-query source angle (BoW family); null -> queries[q].angle
+  const QueryDev* queries;
+  const uint8_t* qdesc;   // [nq][32]
+  const int* nqPtr;       // device query count or null
+  int nq;
+  int2* qInfo;            // [nq] (pool base, record count)
+  uint8_t* taken;         // [n] in/out
+  int* assigned;          // [n] in/out (query index or -1)
+  int* matchQ;            // [nq] scratch: accepted target index per query (or -1), used by the histogram cull
+  int* count;             // out: matchNum
+  int mode;               // 0 M1, 1 M3, 2 M4 (projection family); 3 M5, 4 M6 (BoW family)
+  float ratio;
+  int orbDist, checkOri;
+};
+__device__ __forceinline__ int call_nq(const CallDev& C) { return C.nqPtr ? *C.nqPtr : C.nq; }
+
+// ---------------------------------------------------------------------------------------------------
+// Projection family, phase 1: Frame::getKeyPointsInArea (frame.cpp:337-361) for one query per wave, with the
+// static part of the candidate test (level window, per-axis distance test, stereo consistency) and the
+// descriptor distance.  Records keep the reference's scan order (ix, iy, insertion).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_projection(const CallDev* __restrict__ calls, const FrameDev* __restrict__ frames,
+                                                           int maxQ, uint32_t* __restrict__ pool, unsigned* __restrict__ poolHead,
+                                                           unsigned poolCap, int* __restrict__ status) {
+  __shared__ int pref[4][64];
+  __shared__ int sStart[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int q = blockIdx.x * 4 + wv;
+  const CallDev C = calls[blockIdx.y];
+  if (q >= maxQ || q >= call_nq(C)) return;
+  const FrameDev F = frames[C.frame];
+  const QueryDev Q = C.queries[q];
+  int2 info = make_int2(0, 0);
+  if (Q.flags & 1) {
+    const int minCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.u, F.minX), Q.r), F.gridWInv)));
+    const int maxCellX = min(kGridCols - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.u, F.minX), Q.r), F.gridWInv)));
+    const int minCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.v, F.minY), Q.r), F.gridHInv)));
+    const int maxCellY = min(kGridRows - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.v, F.minY), Q.r), F.gridHInv)));
+    if (minCellX < kGridCols && maxCellX >= 0 && minCellY < kGridRows && maxCellY >= 0 && minCellX <= maxCellX && minCellY <= maxCellY) {
+      const int ny = maxCellY - minCellY + 1, nCells = (maxCellX - minCellX + 1) * ny;
+      // upper bound of records = keypoints in the window -> one pool allocation per query
+      int total = 0;
+      for (int c0 = 0; c0 < nCells; c0 += 64) {
+        const int c = c0 + lane;
+        int cnt = 0;
+        if (c < nCells) {
+          const int cell = (minCellX + c / ny) * kGridRows + minCellY + c % ny;
+          cnt = F.cellStart[cell + 1] - F.cellStart[cell];
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        total += cnt;
+      }
+      if (total > 0) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(poolHead, (unsigned)total);
+        base = __shfl(base, 0, 64);
+        if (base + (unsigned)total > poolCap) {
+          if (lane == 0) atomicMax(status, 1);
+        } else {
+          int written = 0;
+          const uint8_t* qd = C.qdesc + (size_t)q * 32;
+          for (int c0 = 0; c0 < nCells; c0 += 64) {
+            const int c = c0 + lane;
+            int cnt = 0, start = 0;
+            if (c < nCells) {
+              const int cell = (minCellX + c / ny) * kGridRows + minCellY + c % ny;
+              start = F.cellStart[cell];
+              cnt = F.cellStart[cell + 1] - start;
+            }
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+            pref[wv][lane] = incl;
+            sStart[wv][lane] = start;
+            __builtin_amdgcn_wave_barrier();
+            const int chunkTotal = __shfl(incl, 63, 64);
+            for (int t0 = 0; t0 < chunkTotal; t0 += 64) {
+              const int t = t0 + lane;
+              bool pass = false;
+              int idx = 0, dist = 0;
+              if (t < chunkTotal) {
+                int lo = 0, hi = 63;  // first lane whose inclusive prefix exceeds t
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (pref[wv][mid] > t) hi = mid; else lo = mid + 1; }
+                const int cExcl = lo ? pref[wv][lo - 1] : 0;
+                idx = F.cellIdx[sStart[wv][lo] + (t - cExcl)];
+                const KeyPointDev kp = F.kps[idx];
+                pass = true;
+                if (Q.minLevel > 0 || Q.maxLevel >= 0)
+                  if (kp.octave < Q.minLevel || (Q.maxLevel >= 0 && kp.octave < Q.maxLevel)) pass = false;
+                if (!(fabsf(__fsub_rn(kp.x, Q.u)) > Q.r && fabsf(__fsub_rn(kp.y, Q.v)) < Q.r)) pass = false;
+                if (pass && C.mode != 2 && F.rightX) {
+                  const float rx = F.rightX[idx];
+                  if (!(rx <= 0 || fabsf(__fsub_rn(Q.ur, rx)) <= Q.rs)) pass = false;
+                }
+                if (pass) dist = hamming256(qd, F.desc + (size_t)idx * 32);
+              }
+              const unsigned long long m = __ballot(pass);
+              if (pass) pool[base + written + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)dist << 16) | (uint32_t)idx;
+              written += __popcll(m);
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+          info = make_int2((int)base, written);
+        }
+      }
+    }
+  }
+  if (lane == 0) C.qInfo[q] = info;
+}
+
+// BoW family, phase 1: the candidate list of a query is a vocabulary-node bucket of the other frame
+// (orbMatcher.cpp:323-335, 404-417): qRange[q] = [begin,end) into featB, qFeat[q] = feature index in A.
+struct BowCallDev {
+  const uint8_t* descA; const uint8_t* descB;
+  const int* qFeat; const int2* qRange; const int* featB; const uint8_t* validB;  // validB null for mode 3
+  int nq;
+  int2* qInfo;
+};
+__global__ __launch_bounds__(256) void k_gather_bow(BowCallDev B, uint32_t* __restrict__ pool, unsigned* __restrict__ poolHead,
+                                                    unsigned poolCap, int* __restrict__ status) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int q = blockIdx.x * 4 + wv;
+  if (q >= B.nq) return;
+  const int2 rg = B.qRange[q];
+  const int total = rg.y - rg.x;
+  int2 info = make_int2(0, 0);
+  if (total > 0) {
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(poolHead, (unsigned)total);
+    base = __shfl(base, 0, 64);
+    if (base + (unsigned)total > poolCap) {
+      if (lane == 0) atomicMax(status, 1);
+    } else {
+      const uint8_t* qd = B.descA + (size_t)B.qFeat[q] * 32;
+      int written = 0;
+      for (int t0 = 0; t0 < total; t0 += 64) {
+        const int t = t0 + lane;
+        bool pass = false;
+        int idx = 0, dist = 0;
+        if (t < total) {
+          idx = B.featB[rg.x + t];
+          pass = !B.validB || B.validB[idx];
+          if (pass) dist = hamming256(qd, B.descB + (size_t)idx * 32);
+        }
+        const unsigned long long m = __ballot(pass);
+        if (pass) pool[base + written + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)dist << 16) | (uint32_t)idx;
+        written += __popcll(m);
+      }
+      info = make_int2((int)base, written);
+    }
+  }
+  if (lane == 0) B.qInfo[q] = info;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Phase 2: ordered replay.  best = first minimum over the not-taken candidates in scan order; second = first
+// minimum of the rest — which is exactly what the if / else-if chain at orbMatcher.cpp:44-53 leaves behind.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o, 64));
+  return v;
+}
+
+__global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ calls, const FrameDev* __restrict__ frames,
+                                                const uint32_t* __restrict__ pool, int takenWords) {
+  extern __shared__ unsigned takenBits[];  // [takenWords]
+  __shared__ int hist[kHistLen];
+  const int lane = threadIdx.x;
+  const CallDev C = calls[blockIdx.x];
+  const int nq = call_nq(C);
+  const bool bow = C.mode >= 3;
+  const KeyPointDev* kps = C.tkps;
+  const int n = takenWords * 32;
+  for (int w = lane; w < takenWords; w += 64) {
+    unsigned bits = 0;
+    for (int b = 0; b < 32; b++) {
+      const int i = w * 32 + b;
+      if (C.taken && i < n && C.taken[i]) bits |= 1u << b;
+    }
+    takenBits[w] = bits;
+  }
+  if (lane < kHistLen) hist[lane] = 0;
+  __syncthreads();
+  int matchNum = 0;
+  for (int q = 0; q < nq; q++) {
+    const int2 info = C.qInfo[q];
+    int myMatch = -1;
+    if (info.y > 0) {
+      unsigned best = 0xFFFFFFFFu, second = 0xFFFFFFFFu;  // key = dist(9) << 23 | scan position(23)
+      unsigned bestRec = 0, secondRec = 0;
+      for (int t0 = 0; t0 < info.y; t0 += 64) {
+        const int t = t0 + lane;
+        unsigned key = 0xFFFFFFFFu, rec = 0;
+        if (t < info.y) {
+          rec = pool[info.x + t];
+          const unsigned idx = rec & 0xFFFFu;
+          if (!((takenBits[idx >> 5] >> (idx & 31)) & 1u)) key = ((rec >> 16) << 23) | (unsigned)t;
+        }
+        const unsigned b1 = wave_min_u32(key);
+        const unsigned b2 = wave_min_u32(key == b1 ? 0xFFFFFFFFu : key);
+        const unsigned long long m1 = __ballot(key == b1 && b1 != 0xFFFFFFFFu), m2 = __ballot(key == b2 && b2 != 0xFFFFFFFFu);
+        const unsigned r1 = m1 ? (unsigned)__shfl((int)rec, __ffsll((long long)m1) - 1, 64) : 0u;
+        const unsigned r2 = m2 ? (unsigned)__shfl((int)rec, __ffsll((long long)m2) - 1, 64) : 0u;
+        // merge (best, second) with the chunk's (b1, b2); keys are unique so min/max order them totally
+        if (b1 < best) {
+          if (best < b2) { second = best; secondRec = bestRec; } else { second = b2; secondRec = r2; }
+          best = b1; bestRec = r1;
+        } else {
+          if (b1 < second) { second = b1; secondRec = r1; }
+        }
+      }
+      if (best != 0xFFFFFFFFu) {
+        const int bestDist = (int)(best >> 23), secondDist = second == 0xFFFFFFFFu ? 256 : (int)(second >> 23);
+        const int bestIdx = (int)(bestRec & 0xFFFFu);
+        bool accept;
+        if (C.mode == 0) {
+          const int bestLevel = kps[bestIdx].octave, secondLevel = second == 0xFFFFFFFFu ? -1 : kps[secondRec & 0xFFFFu].octave;
+          accept = bestDist <= kThHigh && (bestLevel != secondLevel || (float)bestDist <= __fmul_rn(C.ratio, (float)secondDist));
+        } else if (C.mode == 1) accept = bestDist < kThHigh;
+        else if (C.mode == 2) accept = bestDist <= C.orbDist;
+        else accept = bestDist <= kThLow && (float)bestDist < __fmul_rn(C.ratio, (float)secondDist);
+        if (accept) {
+          matchNum++;
+          myMatch = bestIdx;
+          const int qflags = bow ? 3 : C.queries[q].flags;
+          if (lane == 0) {
+            if (C.mode == 4) C.assigned[q] = bestIdx;   // out[firstIdx] = second-keyframe index; q is remapped by the host
+            else C.assigned[bestIdx] = q;
+            const bool nowTaken = C.mode >= 2 ? true : (qflags & 2) != 0;
+            if (nowTaken) takenBits[bestIdx >> 5] |= 1u << (bestIdx & 31);
+          }
+        }
+      }
+    }
+    if (lane == 0) C.matchQ[q] = myMatch;
+    __syncthreads();
+  }
+  // rotation histogram (orbMatcher.cpp:119-153): bin = round((a1 - a2 [+360]) / 30), keep the three largest bins
+  if (C.mode != 0 && C.checkOri) {
+    const float factor = (float)(1.0 / kHistLen);
+    for (int q = lane; q < nq; q += 64) {
+      const int t = C.matchQ[q];
+      if (t < 0) continue;
+      const float a1 = C.qAngle ? C.qAngle[q] : C.queries[q].angle;
+      const float a2 = kps[t].angle;
+      float rot = __fsub_rn(a1, a2);
+      if (rot < 0.0f) rot = (float)((double)rot + 360.0);
+      int bin = (int)roundf(__fmul_rn(rot, factor));
+      if (bin == kHistLen) bin = 0;
+      atomicAdd(&hist[bin], 1);
+      C.matchQ[q] = t | (bin << 24);
+    }
+    __syncthreads();
+    int i1 = -1, i2 = -1, i3 = -1, max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < kHistLen; i++) {  // computeThreeMaxima, orbMatcher.cpp:827-854 (redundantly per lane)
+      const int s = hist[i];
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+      else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+      else if (s > max3) { max3 = s; i3 = i; }
+    }
+    if (max2 < max1 / 10) { i3 = -1; i2 = -1; }
+    else if (max3 < max1 / 10) { i3 = -1; }
+    int culled = 0;
+    for (int q = lane; q < nq; q += 64) {
+      const int v = C.matchQ[q];
+      if (v < 0) continue;
+      const int bin = v >> 24, t = v & 0xFFFFFF;
+      if (bin != i1 && bin != i2 && bin != i3) {
+        if (C.mode == 4) C.assigned[q] = -1; else C.assigned[t] = -1;
+        culled++;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) culled += __shfl_xor(culled, o, 64);
+    matchNum -= culled;
+  }
+  __syncthreads();
+  if (C.taken)
+    for (int i = lane; i < n; i += 64) {
+      const int w = i >> 5;
+      if (w < takenWords) C.taken[i] = (takenBits[w] >> (i & 31)) & 1u;
+    }
+  if (lane == 0) *C.count = matchNum;
+}
+
+// queries for the device-resident consecutive-frame search (bench / streaming pipeline): the "projection" of a
+// last-frame keypoint is its own position moved by a per-pair 2x3 affine map (identity = constant-position
+// motion model); window th * scaleFactor[octave], level window octave-1..octave+1 — the non-forward /
+// non-backward branch of orbMatcher.cpp:95-101.
+__global__ __launch_bounds__(256) void k_queries_from_keypoints(const KeyPointDev* __restrict__ kps, const int* __restrict__ nPtr,
+                                                                int cap, const float* __restrict__ affine, float th,
+                                                                const float* __restrict__ scaleFactors, int nLevels,
+                                                                float minX, float maxX, float minY, float maxY,
+                                                                QueryDev* __restrict__ out) {
+  const int f = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cap) return;
+  QueryDev Q{};
+  if (i < nPtr[f]) {
+    const KeyPointDev kp = kps[(size_t)f * cap + i];
+    const float* A = affine + (size_t)f * 6;
+    Q.u = __fadd_rn(__fadd_rn(__fmul_rn(A[0], kp.x), __fmul_rn(A[1], kp.y)), A[2]);
+    Q.v = __fadd_rn(__fadd_rn(__fmul_rn(A[3], kp.x), __fmul_rn(A[4], kp.y)), A[5]);
+    const int oct = min(max(kp.octave, 0), nLevels - 1);
+    Q.r = __fmul_rn(th, scaleFactors[oct]);
+    Q.minLevel = oct - 1;
+    Q.maxLevel = oct + 1;
+    Q.ur = 0; Q.rs = 0;
+    Q.angle = kp.angle;
+    Q.level = oct;
+    const bool inImage = Q.u >= minX && Q.u < maxX && Q.v >= minY && Q.v < maxY;  // Frame::isInImage, frame.cpp:291-294
+    Q.flags = inImage ? 3 : 0;
+  }
+  out[(size_t)f * cap + i] = Q;
+}
+
+}  // namespace ydorb

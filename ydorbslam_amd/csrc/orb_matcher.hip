@@ -1,0 +1,479 @@
+// Host side of the MI355X descriptor matcher + its C ABI (include/ydorb/c_api.h, "Descriptor matcher").
+// Mirrors YDORBSLAM::OrbMatcher's search-by-projection / search-by-BoW entry points
+// (reference src/orbMatcher.cpp:24-239, 303-462) on POD views; all searching runs in the HIP kernels of
+// match_kernels.hip.h.  No CPU fallback: the only host arithmetic is the one-pair popcount that the
+// reference exposes as a static helper (orbMatcher.cpp:11-23) and the vocabulary-node merge-join that
+// decides which buckets meet (a walk over two sorted id lists, orbMatcher.cpp:317-361).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "../../include/ydorb/c_api.h"
+#include "match_kernels.hip.h"
+#include "ydorb_host.h"
+
+using namespace ydorb;
+
+namespace {
+
+#define HIPCHK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      ydorb::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return YDORB_ERR_HIP;                                                                   \
+    }                                                                                         \
+  } while (0)
+
+struct Buf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return YDORB_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 2, 4096);
+    if (hipMalloc(&p, want) != hipSuccess) { set_error("hipMalloc(%zu) failed", want); return YDORB_ERR_HIP; }
+    cap = want;
+    return YDORB_OK;
+  }
+  template <class T> T* as() { return reinterpret_cast<T*>(p); }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+__global__ void k_hamming_rows(const uint8_t* a, const uint8_t* b, int n, int* out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = hamming256(a + (size_t)i * 32, b + (size_t)i * 32);
+}
+
+enum { MS_GRID = 0, MS_GATHER, MS_RESOLVE, MS_COUNT };
+const char* kMatchStageNames[MS_COUNT] = {"grid_build", "gather_distances", "resolve"};
+
+}  // namespace
+
+struct ydorb_matcher {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  Buf kps, desc, rightX, queries, qdesc, taken, assigned, matchQ, qInfo, cellStart, cellIdx, pool, frames, calls, misc, kps2,
+      desc2, feat, valid, qFeat, qRange, qAngle, sf;
+  size_t poolRecords = 1u << 20;
+  // cached descriptors of the last batched launch (re-uploaded only when they change)
+  std::vector<FrameDev> hFrames;
+  std::vector<CallDev> hCalls;
+  bool profiling = false;
+  hipEvent_t ev[MS_COUNT + 1]{};
+  double stageMs[MS_COUNT]{};
+  int stageCalls = 0;
+  bool evPending = false;
+};
+
+namespace {
+
+void collect(ydorb_matcher* m) {
+  if (!m->profiling || !m->evPending) return;
+  for (int i = 0; i < MS_COUNT; i++) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, m->ev[i], m->ev[i + 1]) == hipSuccess) m->stageMs[i] += ms;
+  }
+  m->stageCalls++;
+  m->evPending = false;
+}
+
+// misc layout: [0] poolHead (unsigned), [1] status (int), [2] count (int)
+int resetMisc(ydorb_matcher* m, hipStream_t s) {
+  int rc = m->misc.ensure(64);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(m->misc.p, 0, 64, s));
+  return YDORB_OK;
+}
+
+FrameDev makeFrame(const YdFrameView& v, const KeyPointDev* dk, const uint8_t* dd, const float* drx, int* cellStart, int* cellIdx) {
+  FrameDev F{};
+  F.kps = dk; F.desc = dd; F.rightX = drx; F.nPtr = nullptr; F.n = v.n;
+  F.minX = v.min_x; F.minY = v.min_y;
+  F.gridWInv = static_cast<float>(kGridCols) / (v.max_x - v.min_x);  // frame.cpp:99-100
+  F.gridHInv = static_cast<float>(kGridRows) / (v.max_y - v.min_y);
+  F.cellStart = cellStart; F.cellIdx = cellIdx;
+  return F;
+}
+
+int uploadFrame(ydorb_matcher* m, const YdFrameView* fv, FrameDev* out) {
+  const int n = std::max(fv->n, 1);
+  int rc;
+  if ((rc = m->kps.ensure(sizeof(YdKeyPoint) * n)) || (rc = m->desc.ensure((size_t)32 * n)) || (rc = m->cellStart.ensure(sizeof(int) * (kGridCells + 1))) ||
+      (rc = m->cellIdx.ensure(sizeof(int) * n)) || (rc = m->frames.ensure(sizeof(FrameDev))))
+    return rc;
+  if (fv->right_x && (rc = m->rightX.ensure(sizeof(float) * n))) return rc;
+  if (fv->n > 0) {
+    HIPCHK(hipMemcpyAsync(m->kps.p, fv->kps, sizeof(YdKeyPoint) * fv->n, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->desc.p, fv->desc, (size_t)32 * fv->n, hipMemcpyHostToDevice, m->stream));
+    if (fv->right_x) HIPCHK(hipMemcpyAsync(m->rightX.p, fv->right_x, sizeof(float) * fv->n, hipMemcpyHostToDevice, m->stream));
+  }
+  *out = makeFrame(*fv, m->kps.as<KeyPointDev>(), m->desc.as<uint8_t>(), fv->right_x ? m->rightX.as<float>() : nullptr,
+                   m->cellStart.as<int>(), m->cellIdx.as<int>());
+  HIPCHK(hipMemcpyAsync(m->frames.p, out, sizeof(FrameDev), hipMemcpyHostToDevice, m->stream));
+  hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), sizeof(int16_t) * n, m->stream, m->frames.as<FrameDev>(), n);
+  return YDORB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ydorb_matcher_destroy(ydorb_matcher_t* m);
+
+int ydorb_matcher_create(int32_t device, ydorb_matcher_t** out) {
+  if (!out) { set_error("null argument"); return YDORB_ERR_INVALID_ARG; }
+  *out = nullptr;
+  int rc = require_device(device);
+  if (rc) return rc;
+  ydorb_matcher* m = new ydorb_matcher();
+  m->device = device;
+  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+    set_error("hipStreamCreate failed");
+    delete m;
+    return YDORB_ERR_HIP;
+  }
+  for (auto& e : m->ev) (void)hipEventCreate(&e);
+  if (m->misc.ensure(64) != YDORB_OK || hipMemset(m->misc.p, 0, 64) != hipSuccess) {
+    set_error("matcher scratch allocation failed");
+    ydorb_matcher_destroy(m);
+    return YDORB_ERR_HIP;
+  }
+  *out = m;
+  return YDORB_OK;
+}
+
+void ydorb_matcher_destroy(ydorb_matcher_t* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  (void)hipStreamSynchronize(m->stream);
+  for (Buf* b : {&m->kps, &m->desc, &m->rightX, &m->queries, &m->qdesc, &m->taken, &m->assigned, &m->matchQ, &m->qInfo, &m->cellStart,
+                 &m->cellIdx, &m->pool, &m->frames, &m->calls, &m->misc, &m->kps2, &m->desc2, &m->feat, &m->valid, &m->qFeat, &m->qRange,
+                 &m->qAngle, &m->sf})
+    b->release();
+  for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(m->stream);
+  delete m;
+}
+
+int ydorb_descriptor_distance(const uint8_t* a, const uint8_t* b) {
+  int d = 0;
+  for (int i = 0; i < 32; i += 8) {
+    uint64_t x, y;
+    memcpy(&x, a + i, 8);
+    memcpy(&y, b + i, 8);
+    d += __builtin_popcountll(x ^ y);
+  }
+  return d;
+}
+
+int ydorb_descriptor_distance_rows(ydorb_matcher_t* m, const uint8_t* a, const uint8_t* b, int32_t n, int32_t* out) {
+  if (!m || !a || !b || !out || n < 0) { set_error("invalid argument"); return YDORB_ERR_INVALID_ARG; }
+  if (n == 0) return YDORB_OK;
+  HIPCHK(hipSetDevice(m->device));
+  int rc;
+  if ((rc = m->desc.ensure((size_t)32 * n)) || (rc = m->desc2.ensure((size_t)32 * n)) || (rc = m->assigned.ensure(sizeof(int) * n))) return rc;
+  HIPCHK(hipMemcpyAsync(m->desc.p, a, (size_t)32 * n, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(m->desc2.p, b, (size_t)32 * n, hipMemcpyHostToDevice, m->stream));
+  hipLaunchKernelGGL(k_hamming_rows, dim3((n + 255) / 256), dim3(256), 0, m->stream, m->desc.as<uint8_t>(), m->desc2.as<uint8_t>(), n, m->assigned.as<int>());
+  HIPCHK(hipMemcpyAsync(out, m->assigned.p, sizeof(int) * n, hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  return YDORB_OK;
+}
+
+static int searchProjectionImpl(ydorb_matcher_t* m, int32_t mode, const YdFrameView* fv, const YdQuery* queries, const uint8_t* qdesc,
+                                int32_t nq, float ratio, int32_t orbDist, int32_t checkOri, uint8_t* taken, int32_t* assigned,
+                                int32_t* nMatches, std::vector<uint32_t>* recordsOut) {
+  HIPCHK(hipSetDevice(m->device));
+  const int n = fv->n;
+  if (n > 65535) { set_error("frames with more than 65535 keypoints are not supported"); return YDORB_ERR_UNSUPPORTED; }
+  if (nq == 0 || n == 0) { *nMatches = 0; return YDORB_OK; }
+  for (int attempt = 0; attempt < 6; attempt++) {
+    int rc;
+    FrameDev F;
+    if ((rc = uploadFrame(m, fv, &F))) return rc;
+    if ((rc = m->queries.ensure(sizeof(YdQuery) * nq)) || (rc = m->qdesc.ensure((size_t)32 * nq)) || (rc = m->taken.ensure(n)) ||
+        (rc = m->assigned.ensure(sizeof(int) * n)) || (rc = m->matchQ.ensure(sizeof(int) * nq)) || (rc = m->qInfo.ensure(sizeof(int2) * nq)) ||
+        (rc = m->pool.ensure(sizeof(uint32_t) * m->poolRecords)) || (rc = m->calls.ensure(sizeof(CallDev))) || (rc = resetMisc(m, m->stream)))
+      return rc;
+    HIPCHK(hipMemcpyAsync(m->queries.p, queries, sizeof(YdQuery) * nq, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->qdesc.p, qdesc, (size_t)32 * nq, hipMemcpyHostToDevice, m->stream));
+    if (taken) HIPCHK(hipMemcpyAsync(m->taken.p, taken, n, hipMemcpyHostToDevice, m->stream));
+    else HIPCHK(hipMemsetAsync(m->taken.p, 0, n, m->stream));
+    if (assigned) HIPCHK(hipMemcpyAsync(m->assigned.p, assigned, sizeof(int) * n, hipMemcpyHostToDevice, m->stream));
+    CallDev C{};
+    C.frame = 0; C.tkps = F.kps; C.qAngle = nullptr;
+    C.queries = m->queries.as<QueryDev>(); C.qdesc = m->qdesc.as<uint8_t>(); C.nqPtr = nullptr; C.nq = nq;
+    C.qInfo = m->qInfo.as<int2>(); C.taken = m->taken.as<uint8_t>(); C.assigned = m->assigned.as<int>(); C.matchQ = m->matchQ.as<int>();
+    C.count = m->misc.as<int>() + 2; C.mode = mode; C.ratio = ratio; C.orbDist = orbDist; C.checkOri = checkOri;
+    HIPCHK(hipMemcpyAsync(m->calls.p, &C, sizeof(CallDev), hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(k_gather_projection, dim3((nq + 3) / 4, 1), dim3(256), 0, m->stream, m->calls.as<CallDev>(), m->frames.as<FrameDev>(), nq,
+                       m->pool.as<uint32_t>(), m->misc.as<unsigned>(), (unsigned)m->poolRecords, m->misc.as<int>() + 1);
+    int hmisc[3];
+    if (!recordsOut) {
+      const int takenWords = (n + 31) / 32;
+      hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), sizeof(unsigned) * takenWords, m->stream, m->calls.as<CallDev>(), m->frames.as<FrameDev>(),
+                         m->pool.as<uint32_t>(), takenWords);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(hmisc, m->misc.p, sizeof(hmisc), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (hmisc[1] != 0) {  // record pool too small: grow and replay (the kernels wrote nothing past the pool)
+      m->poolRecords = std::max<size_t>(m->poolRecords * 4, (size_t)(unsigned)hmisc[0] + 1024);
+      continue;
+    }
+    if (recordsOut) {
+      std::vector<int2> info(nq);
+      HIPCHK(hipMemcpy(info.data(), m->qInfo.p, sizeof(int2) * nq, hipMemcpyDeviceToHost));
+      recordsOut->resize(info[0].y);
+      if (info[0].y) HIPCHK(hipMemcpy(recordsOut->data(), m->pool.as<uint32_t>() + info[0].x, sizeof(uint32_t) * info[0].y, hipMemcpyDeviceToHost));
+      return YDORB_OK;
+    }
+    if (taken) HIPCHK(hipMemcpy(taken, m->taken.p, n, hipMemcpyDeviceToHost));
+    if (assigned) HIPCHK(hipMemcpy(assigned, m->assigned.p, sizeof(int) * n, hipMemcpyDeviceToHost));
+    *nMatches = hmisc[2];
+    return YDORB_OK;
+  }
+  set_error("candidate record pool kept overflowing");
+  return YDORB_ERR_CAPACITY;
+}
+
+int ydorb_search_by_projection(ydorb_matcher_t* m, int32_t mode, const YdFrameView* fv, const YdQuery* queries, const uint8_t* qdesc,
+                               int32_t nq, float ratio, int32_t orbDist, int32_t checkOri, uint8_t* taken, int32_t* assigned,
+                               int32_t* nMatches) {
+  if (!m || !fv || !nMatches || mode < 0 || mode > 2 || nq < 0 || fv->n < 0 || (nq > 0 && (!queries || !qdesc)) ||
+      (fv->n > 0 && (!fv->kps || !fv->desc || !assigned)) || !(fv->max_x > fv->min_x) || !(fv->max_y > fv->min_y)) {
+    set_error("invalid argument");
+    return YDORB_ERR_INVALID_ARG;
+  }
+  return searchProjectionImpl(m, mode, fv, queries, qdesc, nq, ratio, orbDist, checkOri, taken, assigned, nMatches, nullptr);
+}
+
+int ydorb_frame_keypoints_in_area(ydorb_matcher_t* m, const YdFrameView* fv, float x, float y, float r, int32_t minLevel, int32_t maxLevel,
+                                  int32_t* outIdx, int32_t cap, int32_t* nOut) {
+  if (!m || !fv || !nOut || (cap > 0 && !outIdx) || fv->n < 0 || !(fv->max_x > fv->min_x) || !(fv->max_y > fv->min_y)) {
+    set_error("invalid argument");
+    return YDORB_ERR_INVALID_ARG;
+  }
+  *nOut = 0;
+  if (fv->n == 0) return YDORB_OK;
+  YdQuery q{};
+  q.u = x; q.v = y; q.r = r; q.min_level = minLevel; q.max_level = maxLevel; q.flags = 1;
+  uint8_t zero[32] = {0};
+  std::vector<uint32_t> rec;
+  int dummy = 0;
+  int rc = searchProjectionImpl(m, 2, fv, &q, zero, 1, 0.f, 0, 0, nullptr, nullptr, &dummy, &rec);
+  if (rc) return rc;
+  if ((int)rec.size() > cap) { set_error("%zu candidates, capacity %d", rec.size(), cap); return YDORB_ERR_CAPACITY; }
+  for (size_t i = 0; i < rec.size(); i++) outIdx[i] = (int)(rec[i] & 0xFFFFu);
+  *nOut = (int)rec.size();
+  return YDORB_OK;
+}
+
+int ydorb_search_by_bow(ydorb_matcher_t* m, int32_t mode, const YdBowSide* A, const YdBowSide* B, float ratio, int32_t checkOri, int32_t* out,
+                        int32_t* nMatches) {
+  if (!m || !A || !B || !out || !nMatches || (mode != 3 && mode != 4) || A->n < 0 || B->n < 0 || (A->n > 0 && (!A->kps || !A->desc || !A->valid)) ||
+      (B->n > 0 && (!B->kps || !B->desc)) || (mode == 4 && B->n > 0 && !B->valid)) {
+    set_error("invalid argument");
+    return YDORB_ERR_INVALID_ARG;
+  }
+  HIPCHK(hipSetDevice(m->device));
+  const int nOutLen = mode == 3 ? B->n : A->n;
+  for (int i = 0; i < nOutLen; i++) out[i] = -1;
+  *nMatches = 0;
+  if (A->n == 0 || B->n == 0) return YDORB_OK;
+  if (B->n > 65535) { set_error("more than 65535 features per frame are not supported"); return YDORB_ERR_UNSUPPORTED; }
+  // which vocabulary nodes meet: merge-join of the two ascending id lists (orbMatcher.cpp:317-361)
+  std::vector<int> qFeat;
+  std::vector<int2> qRange;
+  std::vector<float> qAngle;
+  size_t records = 0;
+  {
+    int a = 0, b = 0;
+    const YdFeatureVector &fa = A->fv, &fb = B->fv;
+    while (a < fa.n_nodes && b < fb.n_nodes) {
+      if (fa.node_ids[a] == fb.node_ids[b]) {
+        for (int ia = fa.node_start[a]; ia < fa.node_start[a + 1]; ia++) {
+          const int idxA = fa.feat[ia];
+          if (!A->valid[idxA]) continue;
+          qFeat.push_back(idxA);
+          qRange.push_back(make_int2(fb.node_start[b], fb.node_start[b + 1]));
+          qAngle.push_back(A->kps[idxA].angle);
+          records += (size_t)(fb.node_start[b + 1] - fb.node_start[b]);
+        }
+        a++; b++;
+      } else if (fa.node_ids[a] < fb.node_ids[b]) {
+        a = (int)(std::lower_bound(fa.node_ids, fa.node_ids + fa.n_nodes, fb.node_ids[b]) - fa.node_ids);
+      } else {
+        b = (int)(std::lower_bound(fb.node_ids, fb.node_ids + fb.n_nodes, fa.node_ids[a]) - fb.node_ids);
+      }
+    }
+  }
+  const int nq = (int)qFeat.size();
+  if (nq == 0) return YDORB_OK;
+  const int nFeatB = B->fv.node_start[B->fv.n_nodes];
+  m->poolRecords = std::max<size_t>(m->poolRecords, records + 1024);
+  int rc;
+  if ((rc = m->desc.ensure((size_t)32 * A->n)) || (rc = m->desc2.ensure((size_t)32 * B->n)) || (rc = m->kps2.ensure(sizeof(YdKeyPoint) * B->n)) ||
+      (rc = m->feat.ensure(sizeof(int) * std::max(nFeatB, 1))) || (rc = m->valid.ensure(B->n)) || (rc = m->qFeat.ensure(sizeof(int) * nq)) ||
+      (rc = m->qRange.ensure(sizeof(int2) * nq)) || (rc = m->qAngle.ensure(sizeof(float) * nq)) || (rc = m->qInfo.ensure(sizeof(int2) * nq)) ||
+      (rc = m->matchQ.ensure(sizeof(int) * nq)) || (rc = m->assigned.ensure(sizeof(int) * std::max(nq, B->n))) ||
+      (rc = m->pool.ensure(sizeof(uint32_t) * m->poolRecords)) || (rc = m->calls.ensure(sizeof(CallDev))) || (rc = resetMisc(m, m->stream)))
+    return rc;
+  HIPCHK(hipMemcpyAsync(m->desc.p, A->desc, (size_t)32 * A->n, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(m->desc2.p, B->desc, (size_t)32 * B->n, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(m->kps2.p, B->kps, sizeof(YdKeyPoint) * B->n, hipMemcpyHostToDevice, m->stream));
+  if (nFeatB) HIPCHK(hipMemcpyAsync(m->feat.p, B->fv.feat, sizeof(int) * nFeatB, hipMemcpyHostToDevice, m->stream));
+  if (mode == 4) HIPCHK(hipMemcpyAsync(m->valid.p, B->valid, B->n, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(m->qFeat.p, qFeat.data(), sizeof(int) * nq, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(m->qRange.p, qRange.data(), sizeof(int2) * nq, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(m->qAngle.p, qAngle.data(), sizeof(float) * nq, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemsetAsync(m->assigned.p, 0xFF, sizeof(int) * std::max(nq, B->n), m->stream));
+  BowCallDev BC{};
+  BC.descA = m->desc.as<uint8_t>(); BC.descB = m->desc2.as<uint8_t>(); BC.qFeat = m->qFeat.as<int>(); BC.qRange = m->qRange.as<int2>();
+  BC.featB = m->feat.as<int>(); BC.validB = mode == 4 ? m->valid.as<uint8_t>() : nullptr; BC.nq = nq; BC.qInfo = m->qInfo.as<int2>();
+  hipLaunchKernelGGL(k_gather_bow, dim3((nq + 3) / 4), dim3(256), 0, m->stream, BC, m->pool.as<uint32_t>(), m->misc.as<unsigned>(),
+                     (unsigned)m->poolRecords, m->misc.as<int>() + 1);
+  CallDev C{};
+  C.frame = 0; C.tkps = m->kps2.as<KeyPointDev>(); C.qAngle = m->qAngle.as<float>(); C.queries = nullptr; C.qdesc = nullptr; C.nqPtr = nullptr;
+  C.nq = nq; C.qInfo = m->qInfo.as<int2>(); C.taken = nullptr; C.assigned = m->assigned.as<int>(); C.matchQ = m->matchQ.as<int>();
+  C.count = m->misc.as<int>() + 2; C.mode = mode; C.ratio = ratio; C.orbDist = 0; C.checkOri = checkOri;
+  HIPCHK(hipMemcpyAsync(m->calls.p, &C, sizeof(CallDev), hipMemcpyHostToDevice, m->stream));
+  const int takenWords = (B->n + 31) / 32;
+  hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), sizeof(unsigned) * takenWords, m->stream, m->calls.as<CallDev>(), (const FrameDev*)nullptr,
+                     m->pool.as<uint32_t>(), takenWords);
+  HIPCHK(hipGetLastError());
+  int hmisc[3];
+  std::vector<int> res(std::max(nq, B->n));
+  HIPCHK(hipMemcpyAsync(hmisc, m->misc.p, sizeof(hmisc), hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipMemcpyAsync(res.data(), m->assigned.p, sizeof(int) * res.size(), hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  if (hmisc[1] != 0) { set_error("bow record pool overflow"); return YDORB_ERR_CAPACITY; }
+  if (mode == 3) {
+    for (int i = 0; i < B->n; i++) out[i] = res[i] >= 0 ? qFeat[res[i]] : -1;
+  } else {
+    for (int q = 0; q < nq; q++) out[qFeat[q]] = res[q];
+  }
+  *nMatches = hmisc[2];
+  return YDORB_OK;
+}
+
+int ydorb_match_consecutive_device(ydorb_matcher_t* m, const YdKeyPoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int32_t cap,
+                                   int32_t nFrames, int32_t width, int32_t height, float th, const float* scaleFactors, int32_t nLevels,
+                                   const float* d_affine, int32_t checkOri, int32_t* d_assigned, int32_t* d_counts, void* stream) {
+  if (!m || !d_kps || !d_desc || !d_n || !d_assigned || !d_counts || !scaleFactors || cap < 1 || cap > 65535 || nFrames < 2 || nLevels < 1 ||
+      nLevels > 8 || width < 1 || height < 1) {
+    set_error("invalid argument");
+    return YDORB_ERR_INVALID_ARG;
+  }
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t s = stream ? (hipStream_t)stream : m->stream;
+  const int nCalls = nFrames - 1;
+  const size_t poolPerCall = (size_t)cap * 48;
+  int rc;
+  if ((rc = m->queries.ensure(sizeof(QueryDev) * (size_t)cap * nCalls)) || (rc = m->taken.ensure((size_t)cap * nCalls)) ||
+      (rc = m->matchQ.ensure(sizeof(int) * (size_t)cap * nCalls)) || (rc = m->qInfo.ensure(sizeof(int2) * (size_t)cap * nCalls)) ||
+      (rc = m->cellStart.ensure(sizeof(int) * (size_t)(kGridCells + 1) * nFrames)) || (rc = m->cellIdx.ensure(sizeof(int) * (size_t)cap * nFrames)) ||
+      (rc = m->pool.ensure(sizeof(uint32_t) * poolPerCall * nCalls)) || (rc = m->frames.ensure(sizeof(FrameDev) * nFrames)) ||
+      (rc = m->calls.ensure(sizeof(CallDev) * nCalls)) || (rc = m->sf.ensure(sizeof(float) * 8 + sizeof(float) * 6 * nCalls)) || (rc = m->misc.ensure(64)))
+    return rc;
+  std::vector<FrameDev> hf(nFrames);
+  std::vector<CallDev> hc(nCalls);
+  const float minX = 0.f, minY = 0.f, maxX = (float)width, maxY = (float)height;  // Frame::computeImageBounds without distortion
+  for (int f = 0; f < nFrames; f++) {
+    FrameDev F{};
+    F.kps = reinterpret_cast<const KeyPointDev*>(d_kps) + (size_t)f * cap; F.desc = d_desc + (size_t)f * cap * 32; F.rightX = nullptr;
+    F.nPtr = d_n + f; F.n = 0; F.minX = minX; F.minY = minY;
+    F.gridWInv = static_cast<float>(kGridCols) / (maxX - minX); F.gridHInv = static_cast<float>(kGridRows) / (maxY - minY);
+    F.cellStart = m->cellStart.as<int>() + (size_t)f * (kGridCells + 1); F.cellIdx = m->cellIdx.as<int>() + (size_t)f * cap;
+    hf[f] = F;
+  }
+  for (int c = 0; c < nCalls; c++) {
+    CallDev C{};
+    C.frame = c + 1; C.tkps = hf[c + 1].kps; C.qAngle = nullptr; C.queries = m->queries.as<QueryDev>() + (size_t)c * cap;
+    C.qdesc = d_desc + (size_t)c * cap * 32; C.nqPtr = d_n + c; C.nq = 0; C.qInfo = m->qInfo.as<int2>() + (size_t)c * cap;
+    C.taken = m->taken.as<uint8_t>() + (size_t)c * cap; C.assigned = d_assigned + (size_t)c * cap; C.matchQ = m->matchQ.as<int>() + (size_t)c * cap;
+    C.count = d_counts + c; C.mode = 1; C.ratio = 0.9f; C.orbDist = 0; C.checkOri = checkOri;
+    hc[c] = C;
+  }
+  float hsf[8] = {0};
+  for (int l = 0; l < nLevels; l++) hsf[l] = scaleFactors[l];
+  const bool same = m->hFrames.size() == hf.size() && m->hCalls.size() == hc.size() && !memcmp(m->hFrames.data(), hf.data(), sizeof(FrameDev) * hf.size()) &&
+                    !memcmp(m->hCalls.data(), hc.data(), sizeof(CallDev) * hc.size());
+  if (!same) {
+    HIPCHK(hipStreamSynchronize(s));
+    m->hFrames = hf;
+    m->hCalls = hc;
+    HIPCHK(hipMemcpy(m->frames.p, m->hFrames.data(), sizeof(FrameDev) * nFrames, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m->calls.p, m->hCalls.data(), sizeof(CallDev) * nCalls, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m->sf.p, hsf, sizeof(hsf), hipMemcpyHostToDevice));
+    if (!d_affine) {
+      std::vector<float> ident((size_t)6 * nCalls, 0.f);
+      for (int c = 0; c < nCalls; c++) { ident[6 * c] = 1.f; ident[6 * c + 4] = 1.f; }
+      HIPCHK(hipMemcpy(m->sf.as<float>() + 8, ident.data(), sizeof(float) * ident.size(), hipMemcpyHostToDevice));
+    }
+  }
+  const float* aff = d_affine ? d_affine : m->sf.as<float>() + 8;
+  const bool prof = m->profiling;
+  collect(m);
+  HIPCHK(hipMemsetAsync(m->misc.p, 0, 4, s));  // pool head; the overflow status is sticky until synchronize reads it
+  HIPCHK(hipMemsetAsync(m->taken.p, 0, (size_t)cap * nCalls, s));
+  HIPCHK(hipMemsetAsync(d_assigned, 0xFF, sizeof(int) * (size_t)cap * nCalls, s));
+  if (prof) HIPCHK(hipEventRecord(m->ev[0], s));
+  hipLaunchKernelGGL(k_queries_from_keypoints, dim3((cap + 255) / 256, nCalls), dim3(256), 0, s, reinterpret_cast<const KeyPointDev*>(d_kps), d_n, cap,
+                     aff, th, m->sf.as<float>(), nLevels, minX, maxX, minY, maxY, m->queries.as<QueryDev>());
+  hipLaunchKernelGGL(k_grid_build, dim3(nFrames), dim3(256), sizeof(int16_t) * cap, s, m->frames.as<FrameDev>(), cap);
+  if (prof) HIPCHK(hipEventRecord(m->ev[1], s));
+  hipLaunchKernelGGL(k_gather_projection, dim3((cap + 3) / 4, nCalls), dim3(256), 0, s, m->calls.as<CallDev>(), m->frames.as<FrameDev>(), cap,
+                     m->pool.as<uint32_t>(), m->misc.as<unsigned>(), (unsigned)(poolPerCall * nCalls), m->misc.as<int>() + 1);
+  if (prof) HIPCHK(hipEventRecord(m->ev[2], s));
+  const int takenWords = (cap + 31) / 32;
+  hipLaunchKernelGGL(k_resolve, dim3(nCalls), dim3(64), sizeof(unsigned) * takenWords, s, m->calls.as<CallDev>(), m->frames.as<FrameDev>(),
+                     m->pool.as<uint32_t>(), takenWords);
+  if (prof) { HIPCHK(hipEventRecord(m->ev[3], s)); m->evPending = true; }
+  HIPCHK(hipGetLastError());
+  return YDORB_OK;
+}
+
+int ydorb_matcher_synchronize(ydorb_matcher_t* m) {
+  if (!m) { set_error("null handle"); return YDORB_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipDeviceSynchronize());
+  collect(m);
+  if (m->misc.p) {
+    int hmisc[2];
+    HIPCHK(hipMemcpy(hmisc, m->misc.p, sizeof(hmisc), hipMemcpyDeviceToHost));
+    if (hmisc[1] != 0) {
+      (void)hipMemset(m->misc.p, 0, 8);
+      set_error("candidate record pool overflow in the batched search (%u records)", (unsigned)hmisc[0]);
+      return YDORB_ERR_CAPACITY;
+    }
+  }
+  return YDORB_OK;
+}
+
+int ydorb_matcher_set_profiling(ydorb_matcher_t* m, int32_t on) {
+  if (!m) return YDORB_ERR_INVALID_ARG;
+  m->profiling = on != 0;
+  for (double& v : m->stageMs) v = 0;
+  m->stageCalls = 0;
+  m->evPending = false;
+  return YDORB_OK;
+}
+
+int ydorb_matcher_stage_times(ydorb_matcher_t* m, int32_t maxStages, const char** names, float* ms, int32_t* nStages) {
+  if (!m || !nStages) return YDORB_ERR_INVALID_ARG;
+  const int n = std::min<int>(maxStages, MS_COUNT);
+  for (int i = 0; i < n; i++) {
+    if (names) names[i] = kMatchStageNames[i];
+    if (ms) ms[i] = m->stageCalls ? (float)(m->stageMs[i] / m->stageCalls) : 0.f;
+  }
+  *nStages = n;
+  return YDORB_OK;
+}
+
+}  // extern "C"

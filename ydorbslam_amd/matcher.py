@@ -1,0 +1,137 @@
+"""Python mirror of YDORBSLAM::OrbMatcher's search families (reference src/orbMatcher.hpp:24-66) over the C ABI."""
+import ctypes as C
+import numpy as np
+
+from ._lib import YdBowSide, YdFeatureVector, YdFrameView, YdorbError, check, lib
+from .extractor import KP_DTYPE
+
+QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("r", "<f4"), ("min_level", "<i4"), ("max_level", "<i4"),
+                        ("ur", "<f4"), ("rs", "<f4"), ("angle", "<f4"), ("level", "<i4"), ("flags", "<i4")])
+assert QUERY_DTYPE.itemsize == 40
+
+TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30  # orbMatcher.cpp:7-9
+FRAME_MAPPOINT, LAST_CURRENT, KEYFRAME_CURRENT, BOW_KEYFRAME_FRAME, BOW_TWO_KEYFRAMES = range(5)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class FrameView:
+    """The parts of YDORBSLAM::Frame the searches read (keypoints, descriptors, right x, image bounds)."""
+
+    def __init__(self, kps, desc, bounds, right_x=None):
+        self.kps = np.ascontiguousarray(kps, KP_DTYPE)
+        self.desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        self.right_x = None if right_x is None else np.ascontiguousarray(right_x, np.float32)
+        self.bounds = tuple(float(b) for b in bounds)  # min_x, max_x, min_y, max_y
+        self.n = len(self.kps)
+
+    def c(self):
+        return YdFrameView(_p(self.kps), _p(self.desc), _p(self.right_x), self.n, *self.bounds)
+
+
+class FeatureVector:
+    """DBoW3::FeatureVector (std::map<node, vector<feature>>) as CSR arrays."""
+
+    def __init__(self, node_ids, node_start, feat):
+        self.node_ids = np.ascontiguousarray(node_ids, np.uint32)
+        self.node_start = np.ascontiguousarray(node_start, np.int32)
+        self.feat = np.ascontiguousarray(feat, np.int32)
+
+    @staticmethod
+    def from_nodes(node_of_feature):
+        """Group features by node id; inside a node features keep ascending index (FeatureVector::addFeature appends)."""
+        node_of_feature = np.asarray(node_of_feature)
+        ids = np.unique(node_of_feature)
+        order = np.argsort(node_of_feature, kind="stable")
+        counts = np.array([(node_of_feature == i).sum() for i in ids], np.int64)
+        start = np.concatenate([[0], np.cumsum(counts)])
+        return FeatureVector(ids, start, order)
+
+    def c(self):
+        return YdFeatureVector(_p(self.node_ids), _p(self.node_start), _p(self.feat), len(self.node_ids))
+
+
+class OrbMatcher:
+    """OrbMatcher(ratio=0.6, checkOrientation=true) — orbMatcher.hpp:26."""
+
+    def __init__(self, ratio=0.6, check_orientation=True, device=0):
+        self._L = lib()
+        self._h = C.c_void_p()
+        check(self._L.ydorb_matcher_create(device, C.byref(self._h)))
+        self.ratio = float(ratio)
+        self.check_orientation = bool(check_orientation)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ydorb_matcher_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @staticmethod
+    def descriptor_distance(a, b):
+        """static computeDescriptorsDistance (orbMatcher.cpp:11-23)."""
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        return lib().ydorb_descriptor_distance(_p(a), _p(b))
+
+    def descriptor_distance_rows(self, a, b):
+        a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32)
+        b = np.ascontiguousarray(b, np.uint8).reshape(-1, 32)
+        out = np.zeros(len(a), np.int32)
+        check(self._L.ydorb_descriptor_distance_rows(self._h, _p(a), _p(b), len(a), _p(out)))
+        return out
+
+    def keypoints_in_area(self, frame, x, y, r, min_level=-1, max_level=-1):
+        """Frame::getKeyPointsInArea (frame.cpp:337-361)."""
+        out = np.zeros(max(frame.n, 1), np.int32)
+        n = C.c_int32(0)
+        fv = frame.c()
+        check(self._L.ydorb_frame_keypoints_in_area(self._h, C.byref(fv), x, y, r, min_level, max_level, _p(out), len(out), C.byref(n)))
+        return out[:n.value].copy()
+
+    def search_by_projection(self, mode, frame, queries, qdesc, taken=None, assigned=None, orb_dist=0):
+        """modes 0..2 = the three searchByProjection* overloads.  Returns (n_matches, assigned, taken)."""
+        queries = np.ascontiguousarray(queries, QUERY_DTYPE)
+        qdesc = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
+        taken = np.zeros(frame.n, np.uint8) if taken is None else np.ascontiguousarray(taken, np.uint8).copy()
+        assigned = np.full(frame.n, -1, np.int32) if assigned is None else np.ascontiguousarray(assigned, np.int32).copy()
+        n = C.c_int32(0)
+        fv = frame.c()
+        check(self._L.ydorb_search_by_projection(self._h, mode, C.byref(fv), _p(queries), _p(qdesc), len(queries), self.ratio, orb_dist,
+                                                 int(self.check_orientation), _p(taken), _p(assigned), C.byref(n)))
+        return n.value, assigned, taken
+
+    def search_by_bow(self, mode, kps_a, desc_a, valid_a, fv_a, kps_b, desc_b, valid_b, fv_b):
+        """mode 3 = searchByBowInKeyFrameAndFrame, mode 4 = searchByBowInTwoKeyFrames.  Returns (n_matches, out)."""
+        ka = np.ascontiguousarray(kps_a, KP_DTYPE); kb = np.ascontiguousarray(kps_b, KP_DTYPE)
+        da = np.ascontiguousarray(desc_a, np.uint8); db = np.ascontiguousarray(desc_b, np.uint8)
+        va = np.ascontiguousarray(valid_a, np.uint8)
+        vb = None if valid_b is None else np.ascontiguousarray(valid_b, np.uint8)
+        A = YdBowSide(_p(ka), _p(da), _p(va), len(ka), fv_a.c())
+        B = YdBowSide(_p(kb), _p(db), _p(vb), len(kb), fv_b.c())
+        out = np.full(len(kb) if mode == 3 else len(ka), -1, np.int32)
+        n = C.c_int32(0)
+        check(self._L.ydorb_search_by_bow(self._h, mode, C.byref(A), C.byref(B), self.ratio, int(self.check_orientation), _p(out), C.byref(n)))
+        return n.value, out
+
+    def match_consecutive_device(self, d_kps, d_desc, d_n, cap, n_frames, width, height, th, scale_factors, d_assigned, d_counts,
+                                 d_affine=None, stream=None):
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        check(self._L.ydorb_match_consecutive_device(self._h, d_kps, d_desc, d_n, cap, n_frames, width, height, th, _p(sf), len(sf), d_affine,
+                                                     int(self.check_orientation), d_assigned, d_counts, stream))
+
+    def synchronize(self):
+        check(self._L.ydorb_matcher_synchronize(self._h))
+
+    def set_profiling(self, on=True):
+        check(self._L.ydorb_matcher_set_profiling(self._h, int(on)))
+
+    def stage_times(self):
+        names = (C.c_char_p * 8)()
+        ms = (C.c_float * 8)()
+        n = C.c_int32(0)
+        check(self._L.ydorb_matcher_stage_times(self._h, 8, names, ms, C.byref(n)))
+        return {names[i].decode(): ms[i] for i in range(n.value)}
