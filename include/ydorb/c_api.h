@@ -204,6 +204,62 @@ int ydorb_matcher_synchronize(ydorb_matcher_t* h);
 int ydorb_matcher_set_profiling(ydorb_matcher_t* h, int32_t on);
 int ydorb_matcher_stage_times(ydorb_matcher_t* h, int32_t max_stages, const char** names, float* ms, int32_t* n_stages);
 
+/* ------------------------------------------------------------------------------------------
+ * Local bundle adjustment.  Replaces the g2o work inside
+ *   static void Optimizer::localBundleAdjust(shared_ptr<KeyFrame>, shared_ptr<Map>, bool& stop)   src/optimizer.cpp:138-352
+ * (and the shared BA kernel of Optimizer::bundleAdjust, :7-137).  The covisibility walk that collects local /
+ * fixed keyframes and map points (:140-173) and the write-back under Map::m_mutex_updateMap (:336-351) stay in the
+ * adapter; this call receives the flat graph that :175-283 would hand to g2o and runs :284-334 on the GPU:
+ * optimize(5) with Huber kernels -> mark edges with chi2 > 5.991 (mono) / 7.815 (stereo) or non-positive depth and drop
+ * the kernels -> optimize(10) on the inliers -> final outlier list.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct YdBaProblem {
+  int32_t n_poses, n_points, n_edges;
+  double* poses;                 /* [n_poses][7] tx,ty,tz,qx,qy,qz,qw = g2o::SE3Quat of T_c2w (Converter, converter.cpp:12-19); in/out */
+  const uint8_t* pose_fixed;     /* [n_poses] setFixed(): keyframe id 0 and the "fixed keyframes" (optimizer.cpp:191,204) */
+  double* points;                /* [n_points][3] world position; in/out */
+  const int32_t* edge_pose;      /* [n_edges] index into poses */
+  const int32_t* edge_point;     /* [n_edges] index into points */
+  const double* edge_meas;       /* [n_edges][3] u, v, u_right; u_right < 0 selects the monocular 2-D edge (optimizer.cpp:239) */
+  const double* edge_inv_sigma2; /* [n_edges] m_v_invScaleFactorSquares[octave] (information = I * this, :248,268) */
+  double fx, fy, cx, cy, bf;     /* Frame::m_flt_* statics (:254-257, :275-279) */
+  const volatile uint8_t* stop;  /* the reference's `bool& _bIsStopping`; NULL = the null-reference default (optimizer.hpp:34) */
+} YdBaProblem;
+
+typedef struct YdBaOptions {
+  int32_t iters1, iters2;        /* 5 and 10 (optimizer.cpp:288,314) */
+  double chi2_mono, chi2_stereo; /* 5.991, 7.815 (:296,306) */
+  double delta_mono, delta_stereo; /* Huber delta: (double)(float)sqrt(5.991|7.815) (:223-224) */
+  int32_t max_trials;            /* maxTrialsAfterFailure = 10 (optimization_algorithm_levenberg.cpp:50) */
+  int32_t device;
+  /* multi-GPU (landmarks sharded over ranks, every rank holds all poses): called on device buffer d_buf holding
+   * `count` doubles; op 0 = sum, 1 = max over ranks.  NULL = single GPU. */
+  int32_t (*allreduce)(void* user, void* d_buf, int64_t count, int32_t op);
+  void* allreduce_user;
+  void* d_comm_buf;              /* device workspace the callback can address (e.g. a torch tensor), >= comm_doubles doubles */
+  int64_t comm_doubles;
+  int32_t rank, world;
+} YdBaOptions;
+
+typedef struct YdBaResult {
+  int32_t n_trials;              /* LM trials executed (each = linearise/Schur/solve/update/chi2) */
+  int32_t n_iterations;          /* outer LM iterations over both stages */
+  int32_t n_log;
+  int32_t stopped;               /* 1 if the stop flag ended the run early */
+  double log_chi2[32];           /* robust chi2 after each outer iteration */
+  double log_lambda[32];
+  int32_t log_trials[32];
+  int32_t log_stage[32];
+  uint8_t* edge_outlier;         /* [n_edges] caller buffer: 1 = erase the observation (optimizer.cpp:316-334); may be NULL */
+  float ms_total, ms_errors, ms_build, ms_schur, ms_solve, ms_update; /* device time per phase, summed over trials (HIP events) */
+} YdBaResult;
+
+/* default options as the reference uses them */
+void ydorb_ba_default_options(YdBaOptions* opt);
+int ydorb_ba_solve(const YdBaProblem* prob, const YdBaOptions* opt, YdBaResult* res);
+/* dense SPD solve with the BA's blocked Cholesky (known-answer tests; A is n x n row-major, host pointers) */
+int ydorb_ba_dense_solve(int32_t device, const double* A, int32_t n, const double* b, double* x, int32_t* ok);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,14 @@ def lib():
         L.yo_three_maxima.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.yo_rot_bin.restype = C.c_int
         L.yo_rot_bin.argtypes = [C.c_float, C.c_float]
+        L.yo_ba_solve.restype = C.c_int
+        L.yo_ba_solve.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 12 + [C.c_int, C.c_void_p]
+        L.yo_ba_residual.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.yo_ba_jacobians.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.yo_ba_pose_oplus.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.yo_ba_chol_solve.restype = C.c_int
+        L.yo_ba_chol_solve.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.yo_ba_huber.argtypes = [C.c_double, C.c_double, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -244,3 +252,39 @@ def search_by_bow(mode, kps_a, desc_a, valid_a, fv_a, kps_b, desc_b, valid_b, fv
     out = np.full(len(kb) if mode == 3 else len(ka), -1, np.int32)
     n = lib().yo_search_by_bow(mode, _p(ka), _p(da), len(ka), _p(va), _p(ia), _p(sa), len(ia), _p(fa), _p(kb), _p(db), len(kb), _p(vb), _p(ib), _p(sb), len(ib), _p(fb), ratio, int(check_orientation), _p(out))
     return n, out
+
+
+# ---------------------------------------------------------------------------------------------
+# local-BA oracle (oracle/ba_oracle.cpp)
+# ---------------------------------------------------------------------------------------------
+BA_OPTIONS_DTYPE = np.dtype([("iters1", "<i4"), ("iters2", "<i4"), ("chi2_mono", "<f8"), ("chi2_stereo", "<f8"),
+                             ("delta_mono", "<f8"), ("delta_stereo", "<f8"), ("max_trials", "<i4"), ("reserved", "<i4")])
+
+
+def ba_default_options(iters1=5, iters2=10):
+    o = np.zeros(1, BA_OPTIONS_DTYPE)
+    o["iters1"], o["iters2"] = iters1, iters2
+    o["chi2_mono"], o["chi2_stereo"] = 5.991, 7.815                      # optimizer.cpp:296,306
+    o["delta_mono"] = float(np.float32(np.sqrt(5.991)))                  # `const float monoDelta = sqrt(5.991)`, :223
+    o["delta_stereo"] = float(np.float32(np.sqrt(7.815)))
+    o["max_trials"] = 10                                                 # levenberg.cpp:50
+    return o
+
+
+def ba_solve(prob, options=None, stop=None):
+    """prob: dict as ydorbslam_amd.synth.synth_ba_problem.  Returns dict(poses, points, outlier, log, trials)."""
+    o = ba_default_options() if options is None else options
+    poses = np.ascontiguousarray(prob["poses"], np.float64).copy()
+    points = np.ascontiguousarray(prob["points"], np.float64).copy()
+    fixed = np.ascontiguousarray(prob["fixed"], np.uint8)
+    ep = np.ascontiguousarray(prob["edge_pose"], np.int32); eq = np.ascontiguousarray(prob["edge_point"], np.int32)
+    meas = np.ascontiguousarray(prob["meas"], np.float64); info = np.ascontiguousarray(prob["info"], np.float64)
+    cam = np.ascontiguousarray(prob["camera"], np.float64)
+    E = len(ep)
+    outlier = np.zeros(E, np.uint8)
+    log = np.zeros((64, 4), np.float64)
+    nlog = C.c_int(0)
+    stop_p = None if stop is None else _p(stop)
+    trials = lib().yo_ba_solve(len(poses), len(points), E, _p(poses), _p(fixed), _p(points), _p(ep), _p(eq), _p(meas), _p(info), _p(cam),
+                               stop_p, _p(o), _p(outlier), _p(log), 64, C.byref(nlog))
+    return dict(poses=poses, points=points, outlier=outlier, log=log[:nlog.value].copy(), trials=trials)

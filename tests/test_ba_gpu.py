@@ -1,0 +1,79 @@
+"""GPU parity: HIP local BA (C ABI) vs the CPU oracle restatement of the g2o arithmetic.
+
+Floating point: tolerance as BASELINE.md states it — poses/points |delta| <= 1e-4 relative on the float32 outputs,
+robust chi2 trajectory within 1e-6 relative; the outlier mask (integer decisions) must be identical.
+"""
+import numpy as np
+import pytest
+
+from ydorbslam_amd.synth import synth_ba_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(prob, oracle_lib, options=None):
+    import ydorbslam_amd as y
+    ref = oracle_lib.ba_solve(prob)
+    got = y.Optimizer.local_bundle_adjust(prob, options)
+    assert got["trials"] == ref["trials"]
+    assert len(got["log"]) == len(ref["log"])
+    assert np.allclose(got["log"][:, 0], ref["log"][:, 0], rtol=1e-6, atol=0)       # chi2 per outer iteration
+    assert np.allclose(got["log"][:, 1], ref["log"][:, 1], rtol=1e-6, atol=0)       # lambda
+    assert np.array_equal(got["log"][:, 2:], ref["log"][:, 2:])                     # trials, stage
+    assert np.array_equal(got["outlier"], ref["outlier"])
+    p32, r32 = got["poses"].astype(np.float32), ref["poses"].astype(np.float32)     # what Converter hands back (float cv::Mat)
+    assert np.allclose(p32, r32, rtol=1e-4, atol=1e-6)
+    assert np.allclose(got["points"].astype(np.float32), ref["points"].astype(np.float32), rtol=1e-4, atol=1e-6)
+    return ref, got
+
+
+def test_small_stereo(oracle_lib):
+    _check(synth_ba_problem(6, 120, 4, seed=3), oracle_lib)
+
+
+def test_mono_stereo_mix_with_outliers(oracle_lib):
+    prob = synth_ba_problem(20, 800, 8, seed=5, outlier_frac=0.05, mono_frac=0.4)
+    ref, got = _check(prob, oracle_lib)
+    assert 10 < ref["outlier"].sum() < 0.2 * len(ref["outlier"])                   # the chi2 cull really fires
+
+
+def test_fixed_keyframes(oracle_lib):
+    _check(synth_ba_problem(12, 400, 6, seed=7, n_fixed=4), oracle_lib)
+
+
+def test_c5_shape(oracle_lib):
+    """BASELINE config 5: 100 keyframes x 10 000 points, 8 observations each (80 000 stereo edges)."""
+    prob = synth_ba_problem(100, 10000, 8, seed=1)
+    ref, got = _check(prob, oracle_lib)
+    assert got["log"][-1, 0] < 0.5 * got["log"][0, 0]
+    # BA really moved the estimate toward the truth (free gauge: compare the chi2 instead of absolute error)
+
+
+def test_stop_flag_and_empty(oracle_lib):
+    import ydorbslam_amd as y
+    prob = synth_ba_problem(6, 120, 4, seed=3)
+    stop = np.ones(1, np.uint8)
+    got = y.Optimizer.local_bundle_adjust(prob, stop=stop)
+    assert got["stopped"] and got["trials"] == 0
+    assert np.array_equal(got["poses"], prob["poses"]) and np.array_equal(got["points"], prob["points"])
+    empty = dict(prob)
+    empty["edge_pose"] = np.zeros(0, np.int32); empty["edge_point"] = np.zeros(0, np.int32)
+    empty["meas"] = np.zeros((0, 3)); empty["info"] = np.zeros(0)
+    got = y.Optimizer.local_bundle_adjust(empty)
+    assert got["trials"] == 0
+
+
+def test_dense_solve_known_answer(oracle_lib):
+    """Reduced-system solver against numpy and against the SPD system pattern of g2o's linear_solver_test."""
+    import ydorbslam_amd as y
+    rng = np.random.default_rng(0)
+    for n in (6, 36, 100, 594):
+        M = rng.normal(size=(n, n))
+        A = M @ M.T + n * np.eye(n)
+        b = rng.normal(size=n)
+        x, ok = y.Optimizer.dense_solve(A, b)
+        assert ok
+        assert np.allclose(x, np.linalg.solve(A, b), rtol=1e-9, atol=1e-12)
+    A = np.eye(8); A[3, 3] = -1.0
+    _, ok = y.Optimizer.dense_solve(A, np.ones(8))
+    assert not ok   # not positive definite -> the LM step is rejected (linear_solver_eigen.h:118-126)

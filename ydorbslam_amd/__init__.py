@@ -9,6 +9,7 @@ succeeds without the library, but every operator raises YdorbError until it is b
 from ._lib import YdorbError, lib, library_path, build_library  # noqa: F401
 from .extractor import OrbExtractor, KP_DTYPE  # noqa: F401
 from .matcher import OrbMatcher, FrameView, FeatureVector, QUERY_DTYPE  # noqa: F401
+from .optimizer import Optimizer  # noqa: F401
 
 __all__ = ["YdorbError", "lib", "library_path", "build_library", "OrbExtractor", "KP_DTYPE", "OrbMatcher", "FrameView",
-           "FeatureVector", "QUERY_DTYPE"]
+           "FeatureVector", "QUERY_DTYPE", "Optimizer"]

@@ -62,7 +62,32 @@ SYMBOLS = {
     "ydorb_matcher_synchronize": (C.c_int, [_VP]),
     "ydorb_matcher_set_profiling": (C.c_int, [_VP, _I]),
     "ydorb_matcher_stage_times": (C.c_int, [_VP, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_I)]),
+    "ydorb_ba_default_options": (None, [_VP]),
+    "ydorb_ba_solve": (C.c_int, [_VP, _VP, _VP]),
+    "ydorb_ba_dense_solve": (C.c_int, [_I, _VP, _I, _VP, _VP, C.POINTER(_I)]),
 }
+
+BA_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
+
+
+class YdBaProblem(C.Structure):
+    _fields_ = [("n_poses", _I), ("n_points", _I), ("n_edges", _I), ("poses", _VP), ("pose_fixed", _VP), ("points", _VP),
+                ("edge_pose", _VP), ("edge_point", _VP), ("edge_meas", _VP), ("edge_inv_sigma2", _VP),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double), ("stop", _VP)]
+
+
+class YdBaOptions(C.Structure):
+    _fields_ = [("iters1", _I), ("iters2", _I), ("chi2_mono", C.c_double), ("chi2_stereo", C.c_double),
+                ("delta_mono", C.c_double), ("delta_stereo", C.c_double), ("max_trials", _I), ("device", _I),
+                ("allreduce", BA_ALLREDUCE_FN), ("allreduce_user", _VP), ("d_comm_buf", _VP), ("comm_doubles", C.c_int64),
+                ("rank", _I), ("world", _I)]
+
+
+class YdBaResult(C.Structure):
+    _fields_ = [("n_trials", _I), ("n_iterations", _I), ("n_log", _I), ("stopped", _I), ("log_chi2", C.c_double * 32),
+                ("log_lambda", C.c_double * 32), ("log_trials", _I * 32), ("log_stage", _I * 32), ("edge_outlier", _VP),
+                ("ms_total", C.c_float), ("ms_errors", C.c_float), ("ms_build", C.c_float), ("ms_schur", C.c_float),
+                ("ms_solve", C.c_float), ("ms_update", C.c_float)]
 
 
 class YdFrameView(C.Structure):

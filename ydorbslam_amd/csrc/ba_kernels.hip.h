@@ -1,0 +1,613 @@
+// gfx950 HIP kernels of the local-BA back-end (double precision throughout, like g2o's number_t).
+//
+// Arithmetic restated from the g2o subset that Optimizer::localBundleAdjust executes (reference
+// src/optimizer.cpp:138-352): residuals/Jacobians thirdParty/g2o/g2o/types/sba/types_six_dof_expmap.{h,cpp},
+// SE3 algebra types/slam3d/se3quat.h, quadratic form core/base_binary_edge.hpp:64-136, Huber
+// core/robust_kernel_impl.cpp:65-78, Schur complement + back-substitution core/block_solver.hpp:315-444.
+// The structure is GPU-first instead of g2o's edge loop over a sparse block matrix:
+//   * edges are sorted by (landmark, pose): one thread owns a landmark and accumulates H_ll, b_l and the
+//     6x3 H_pl blocks of its observations in registers (no atomics);
+//   * one workgroup owns a free pose and reduces its 6x6 H_pp and b_p over that pose's observations;
+//   * the Schur complement  S = H_pp + lambda*I - sum_l W_l (H_ll + lambda*I)^-1 W_l^T  is formed directly in a
+//     dense (6K)^2 buffer (K = 100 keyframes -> 2.9 MB, L2-resident) by one thread per (landmark, pose)
+//     pair block, FP64 atomics into the lower triangle;
+//   * the reduced system is factorised by a blocked left-looking dense Cholesky (one launch per 32-column
+//     panel, one workgroup per 32x32 tile) and solved by a single-workgroup blocked substitution;
+//   * LM control (lambda, accept/reject, chi2 cull) stays on the host exactly as
+//     core/optimization_algorithm_levenberg.cpp:57-148 sequences it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace ydorb {
+namespace ba {
+
+typedef double R;
+struct V3 { R x, y, z; };
+struct Q4 { R x, y, z, w; };
+
+__device__ __forceinline__ V3 add(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ V3 scale(V3 a, R s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ V3 qrot(Q4 q, V3 v) {  // Eigen quaternion * vector
+  V3 qv{q.x, q.y, q.z};
+  V3 uv = cross(qv, v);
+  uv = add(uv, uv);
+  return add(add(v, scale(uv, q.w)), cross(qv, uv));
+}
+__device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
+  return {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+          a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+__device__ __forceinline__ void qToR(Q4 q, R m[3][3]) {
+  const R tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+  const R twx = tx * q.w, twy = ty * q.w, twz = tz * q.w, txx = tx * q.x, txy = ty * q.x, txz = tz * q.x, tyy = ty * q.y,
+          tyz = tz * q.y, tzz = tz * q.z;
+  m[0][0] = 1 - (tyy + tzz); m[0][1] = txy - twz; m[0][2] = txz + twy;
+  m[1][0] = txy + twz; m[1][1] = 1 - (txx + tzz); m[1][2] = tyz - twx;
+  m[2][0] = txz - twy; m[2][1] = tyz + twx; m[2][2] = 1 - (txx + tyy);
+}
+__device__ __forceinline__ Q4 rToQ(const R a[3][3]) {  // Eigen Quaternion(Matrix3)
+  Q4 q;
+  R t = a[0][0] + a[1][1] + a[2][2];
+  if (t > 0) {
+    t = sqrt(t + 1.0);
+    q.w = 0.5 * t;
+    t = 0.5 / t;
+    q.x = (a[2][1] - a[1][2]) * t;
+    q.y = (a[0][2] - a[2][0]) * t;
+    q.z = (a[1][0] - a[0][1]) * t;
+  } else {
+    int i = 0;
+    if (a[1][1] > a[0][0]) i = 1;
+    if (a[2][2] > a[i][i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(a[i][i] - a[j][j] - a[k][k] + 1.0);
+    R c[3];
+    c[i] = 0.5 * t;
+    t = 0.5 / t;
+    q.w = (a[k][j] - a[j][k]) * t;
+    c[j] = (a[j][i] + a[i][j]) * t;
+    c[k] = (a[k][i] + a[i][k]) * t;
+    q.x = c[0]; q.y = c[1]; q.z = c[2];
+  }
+  return q;
+}
+__device__ __forceinline__ void qnormalize(Q4& q) {  // se3quat.h:280-285
+  if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
+  const R n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  q.x /= n; q.y /= n; q.z /= n; q.w /= n;
+}
+
+struct Cam { R fx, fy, cx, cy, bf; };
+
+struct EdgeSoA {          // active edges sorted by (landmark index, pose index)
+  const int* pose;        // index into the pose array
+  const int* pidx;        // free-pose (Hessian) index or -1 when the pose is fixed
+  const int* pt;          // index into the point array
+  const R* meas;          // [E][3] u, v, ur (ur < 0: monocular edge, optimizer.cpp:239)
+  const R* info;          // [E] invSigma2 (information = I * invSigma2, optimizer.cpp:248,268)
+  const uint8_t* robust;  // [E] Huber kernel attached
+  int n;
+};
+
+__device__ __forceinline__ void load_pose(const R* poses, int k, V3& t, Q4& q) {
+  const R* p = poses + 7 * k;
+  t = {p[0], p[1], p[2]};
+  q = {p[3], p[4], p[5], p[6]};
+}
+
+// computeError (types_six_dof_expmap.h:208-213, 269-274; cam_project .cpp:327-342)
+__device__ __forceinline__ void residual(V3 t, Q4 q, V3 X, const R* z, bool stereo, const Cam& c, R e[3], R* depth) {
+  const V3 p = add(qrot(q, X), t);
+  *depth = p.z;
+  if (stereo) {
+    const R invz = 1.0f / p.z;
+    const R u = p.x * invz * c.fx + c.cx, v = p.y * invz * c.fy + c.cy;
+    const float bf = (float)c.bf;
+    e[0] = z[0] - u; e[1] = z[1] - v; e[2] = z[2] - (u - bf * invz);
+  } else {
+    e[0] = z[0] - (p.x / p.z * c.fx + c.cx);
+    e[1] = z[1] - (p.y / p.z * c.fy + c.cy);
+    e[2] = 0;
+  }
+}
+// linearizeOplus (types_six_dof_expmap.cpp:289-325, 357-403): A = de/dX (3x3, third row 0 for mono), B = de/dxi (3x6)
+__device__ __forceinline__ void jacobians(V3 t, Q4 q, V3 X, bool stereo, const Cam& c, R A[3][3], R B[3][6]) {
+  const V3 p = add(qrot(q, X), t);
+  R Rm[3][3];
+  qToR(q, Rm);
+  const R x = p.x, y = p.y, z = p.z, z2 = z * z;
+  if (stereo) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      A[0][j] = -c.fx * Rm[0][j] / z + c.fx * x * Rm[2][j] / z2;
+      A[1][j] = -c.fy * Rm[1][j] / z + c.fy * y * Rm[2][j] / z2;
+      A[2][j] = A[0][j] - c.bf * Rm[2][j] / z2;
+    }
+  } else {
+    const R tmp[2][3] = {{c.fx, 0, -x / z * c.fx}, {0, c.fy, -y / z * c.fy}};
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        R s = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) s += (-1. / z * tmp[i][k]) * Rm[k][j];
+        A[i][j] = s;
+      }
+    A[2][0] = A[2][1] = A[2][2] = 0;
+  }
+  B[0][0] = x * y / z2 * c.fx; B[0][1] = -(1 + (x * x / z2)) * c.fx; B[0][2] = y / z * c.fx;
+  B[0][3] = -1. / z * c.fx; B[0][4] = 0; B[0][5] = x / z2 * c.fx;
+  B[1][0] = (1 + y * y / z2) * c.fy; B[1][1] = -x * y / z2 * c.fy; B[1][2] = -x / z * c.fy;
+  B[1][3] = 0; B[1][4] = -1. / z * c.fy; B[1][5] = y / z2 * c.fy;
+  if (stereo) {
+    B[2][0] = B[0][0] - c.bf * y / z2; B[2][1] = B[0][1] + c.bf * x / z2; B[2][2] = B[0][2];
+    B[2][3] = B[0][3]; B[2][4] = 0; B[2][5] = B[0][5] - c.bf / z2;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 6; j++) B[2][j] = 0;
+  }
+}
+__device__ __forceinline__ void huber(R e, R delta, R* rho0, R* rho1) {  // robust_kernel_impl.cpp:65-78
+  const R dsqr = delta * delta;
+  if (e <= dsqr) { *rho0 = e; *rho1 = 1.; }
+  else { const R s = sqrt(e); *rho0 = 2 * s * delta - dsqr; *rho1 = delta / s; }
+}
+
+__device__ __forceinline__ R block_sum(R v, R* lds) {  // deterministic workgroup sum (blockDim.x multiple of 64, <= 1024)
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) lds[wv] = v;
+  __syncthreads();
+  R s = 0;
+  for (int i = 0; i < nw; i++) s += lds[i];
+  return s;
+}
+
+// computeActiveErrors + activeRobustChi2 (sparse_optimizer.cpp:63-116): err[e], per-workgroup partial chi2
+__global__ __launch_bounds__(256) void k_errors(EdgeSoA Ed, const R* __restrict__ poses, const R* __restrict__ pts, Cam cam,
+                                                R deltaMono, R deltaStereo, R* __restrict__ err, R* __restrict__ partial) {
+  __shared__ R lds[4];
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  R chi = 0;
+  if (e < Ed.n) {
+    V3 t; Q4 q;
+    load_pose(poses, Ed.pose[e], t, q);
+    const R* X = pts + 3 * Ed.pt[e];
+    const R* z = Ed.meas + 3 * e;
+    const bool st = z[2] >= 0;
+    R r[3], d;
+    residual(t, q, V3{X[0], X[1], X[2]}, z, st, cam, r, &d);
+    err[3 * e] = r[0]; err[3 * e + 1] = r[1]; err[3 * e + 2] = r[2];
+    const R c2 = Ed.info[e] * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (Ed.robust[e]) { R r0, r1; huber(c2, st ? deltaStereo : deltaMono, &r0, &r1); chi = r0; }
+    else chi = c2;
+  }
+  const R s = block_sum(chi, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// final ordered sum of the partials: out[slot] = sum(partial[0..n))
+__global__ __launch_bounds__(256) void k_sum_partials(const R* __restrict__ partial, int n, R* __restrict__ out, int slot) {
+  __shared__ R lds[4];
+  R v = 0;
+  for (int i = threadIdx.x; i < n; i += 256) v += partial[i];
+  const R s = block_sum(v, lds);
+  if (threadIdx.x == 0) out[slot] = s;
+}
+
+// buildSystem, landmark side (constructQuadraticForm for `from` = point): one thread per active landmark.
+// Hll[l] = sum A^T W A (6 unique), bl[l] = sum A^T (-rho' Omega e), Hpl[e] = B^T W A (6x3) for free poses.
+__global__ __launch_bounds__(128) void k_build_points(EdgeSoA Ed, const int* __restrict__ ptStart, int nL, const R* __restrict__ poses,
+                                                      const R* __restrict__ pts, Cam cam, R deltaMono, R deltaStereo,
+                                                      const R* __restrict__ err, R* __restrict__ Hll, R* __restrict__ bl,
+                                                      R* __restrict__ Hpl) {
+  const int l = blockIdx.x * 128 + threadIdx.x;
+  if (l >= nL) return;
+  R h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+  for (int e = ptStart[l]; e < ptStart[l + 1]; e++) {
+    V3 t; Q4 q;
+    load_pose(poses, Ed.pose[e], t, q);
+    const R* X = pts + 3 * Ed.pt[e];
+    const bool st = Ed.meas[3 * e + 2] >= 0;
+    R A[3][3], B[3][6];
+    jacobians(t, q, V3{X[0], X[1], X[2]}, st, cam, A, B);
+    const R w = Ed.info[e];
+    const R r0 = err[3 * e], r1 = err[3 * e + 1], r2 = err[3 * e + 2];
+    R rho1 = 1;
+    if (Ed.robust[e]) { R rr; huber(w * (r0 * r0 + r1 * r1 + r2 * r2), st ? deltaStereo : deltaMono, &rr, &rho1); }
+    const R W = rho1 * w;
+    const R omr[3] = {-w * r0 * rho1, -w * r1 * rho1, -w * r2 * rho1};
+    int k = 0;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = r; c < 3; c++, k++) h[k] += A[0][r] * W * A[0][c] + A[1][r] * W * A[1][c] + A[2][r] * W * A[2][c];
+#pragma unroll
+    for (int r = 0; r < 3; r++) b[r] += A[0][r] * omr[0] + A[1][r] * omr[1] + A[2][r] * omr[2];
+    if (Ed.pidx[e] >= 0) {
+      R* hp = Hpl + (size_t)18 * e;
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) hp[r * 3 + c] = B[0][r] * W * A[0][c] + B[1][r] * W * A[1][c] + B[2][r] * W * A[2][c];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) Hll[(size_t)6 * l + k] = h[k];
+  bl[3 * l] = b[0]; bl[3 * l + 1] = b[1]; bl[3 * l + 2] = b[2];
+}
+
+// buildSystem, pose side: one workgroup per free pose, threads over that pose's edges; Hpp[i] (6x6) and bp[6i..].
+__global__ __launch_bounds__(256) void k_build_poses(EdgeSoA Ed, const int* __restrict__ poseStart, const int* __restrict__ poseEdges,
+                                                     const R* __restrict__ poses, const R* __restrict__ pts, Cam cam, R deltaMono,
+                                                     R deltaStereo, const R* __restrict__ err, R* __restrict__ Hpp,
+                                                     R* __restrict__ bp) {
+  __shared__ R lds[4];
+  const int i = blockIdx.x;
+  R h[21], b[6];
+#pragma unroll
+  for (int k = 0; k < 21; k++) h[k] = 0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) b[k] = 0;
+  for (int j = poseStart[i] + threadIdx.x; j < poseStart[i + 1]; j += 256) {
+    const int e = poseEdges[j];
+    V3 t; Q4 q;
+    load_pose(poses, Ed.pose[e], t, q);
+    const R* X = pts + 3 * Ed.pt[e];
+    const bool st = Ed.meas[3 * e + 2] >= 0;
+    R A[3][3], B[3][6];
+    jacobians(t, q, V3{X[0], X[1], X[2]}, st, cam, A, B);
+    const R w = Ed.info[e];
+    const R r0 = err[3 * e], r1 = err[3 * e + 1], r2 = err[3 * e + 2];
+    R rho1 = 1;
+    if (Ed.robust[e]) { R rr; huber(w * (r0 * r0 + r1 * r1 + r2 * r2), st ? deltaStereo : deltaMono, &rr, &rho1); }
+    const R W = rho1 * w;
+    const R omr[3] = {-w * r0 * rho1, -w * r1 * rho1, -w * r2 * rho1};
+    int k = 0;
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = r; c < 6; c++, k++) h[k] += B[0][r] * W * B[0][c] + B[1][r] * W * B[1][c] + B[2][r] * W * B[2][c];
+#pragma unroll
+    for (int r = 0; r < 6; r++) b[r] += B[0][r] * omr[0] + B[1][r] * omr[1] + B[2][r] * omr[2];
+  }
+  int k = 0;
+  for (int r = 0; r < 6; r++)
+    for (int c = r; c < 6; c++, k++) {
+      const R s = block_sum(h[k], lds);
+      if (threadIdx.x == 0) { Hpp[(size_t)36 * i + r * 6 + c] = s; Hpp[(size_t)36 * i + c * 6 + r] = s; }
+    }
+  for (int r = 0; r < 6; r++) {
+    const R s = block_sum(b[r], lds);
+    if (threadIdx.x == 0) bp[6 * i + r] = s;
+  }
+}
+
+// max |diagonal| of the Hessian (computeLambdaInit, levenberg.cpp:150-164) -> out[slot]
+__global__ __launch_bounds__(256) void k_max_diag(const R* __restrict__ Hpp, int nP, const R* __restrict__ Hll, int nL, R* __restrict__ out,
+                                                  int slot) {
+  __shared__ R lds[4];
+  R m = 0;
+  for (int i = threadIdx.x; i < 6 * nP; i += 256) m = fmax(m, fabs(Hpp[(size_t)36 * (i / 6) + (i % 6) * 7]));
+  for (int i = threadIdx.x; i < 3 * nL; i += 256) {
+    const int l = i / 3, d = i % 3;
+    m = fmax(m, fabs(Hll[(size_t)6 * l + (d == 0 ? 0 : d == 1 ? 3 : 5)]));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[slot] = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
+}
+
+// S <- blockdiag(Hpp) + lambda*I (dense n x n, n = padded 6*nP; identity on the padding), bs <- bp
+// contrib = 1 on a single GPU; with landmark sharding only rank 0 passes 1 so the all-reduced sum holds Hpp, lambda and bp once.
+__global__ __launch_bounds__(256) void k_schur_init(const R* __restrict__ Hpp, const R* __restrict__ bp, int nP, int n, R lambda, R contrib,
+                                                    R* __restrict__ S, R* __restrict__ bs) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)n * n) return;
+  const int r = (int)(idx / n), c = (int)(idx % n);
+  R v = 0;
+  if (r < 6 * nP && c < 6 * nP) {
+    if (r / 6 == c / 6) v = Hpp[(size_t)36 * (r / 6) + (r % 6) * 6 + (c % 6)];
+    if (r == c) v += lambda;
+  } else if (r == c) v = 1;
+  S[idx] = v * contrib;
+  if (c == 0) bs[r] = r < 6 * nP ? bp[r] * contrib : 0;
+}
+
+// D^-1 = (Hll + lambda I)^-1 (Eigen cofactor inverse, block_solver.hpp:350) and db = D^-1 b_l, per landmark
+__global__ __launch_bounds__(256) void k_dinv(const R* __restrict__ Hll, const R* __restrict__ bl, int nL, R lambda, R* __restrict__ Dinv,
+                                              R* __restrict__ db) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= nL) return;
+  const R* d = Hll + (size_t)6 * l;
+  const R a = d[0] + lambda, b = d[1], c = d[2], e = d[3] + lambda, f = d[4], i = d[5] + lambda;
+  const R c00 = e * i - f * f, c01 = c * f - b * i, c02 = b * f - c * e;
+  const R id = 1.0 / (a * c00 + b * c01 + c * c02);
+  R o[6] = {c00 * id, c01 * id, c02 * id, (a * i - c * c) * id, (b * c - a * f) * id, (a * e - b * b) * id};
+#pragma unroll
+  for (int k = 0; k < 6; k++) Dinv[(size_t)6 * l + k] = o[k];
+  const R b0 = bl[3 * l], b1 = bl[3 * l + 1], b2 = bl[3 * l + 2];
+  db[3 * l] = o[0] * b0 + o[1] * b1 + o[2] * b2;
+  db[3 * l + 1] = o[1] * b0 + o[3] * b1 + o[4] * b2;
+  db[3 * l + 2] = o[2] * b0 + o[4] * b1 + o[5] * b2;
+}
+
+// Schur complement (block_solver.hpp:342-393): thread = one observation (landmark l, free pose i1); it subtracts
+// (B_i1 D^-1) B_i2^T for every observation i2 >= i1 of the same landmark into the LOWER triangle of S
+// (block row i2, block column i1, transposed) and (B_i1 D^-1 b_l) from bs.  FP64 atomics: addends commute only up
+// to rounding, which is inside the BA tolerance (the reference's own sum order is heap-address dependent).
+__global__ __launch_bounds__(256) void k_schur(EdgeSoA Ed, const int* __restrict__ ptStart, const int* __restrict__ edgeLm,
+                                               const R* __restrict__ Hpl, const R* __restrict__ Dinv, const R* __restrict__ db, int n,
+                                               R* __restrict__ S, R* __restrict__ bs) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= Ed.n) return;
+  const int i1 = Ed.pidx[e];
+  if (i1 < 0) return;
+  const int l = edgeLm[e];
+  const R* di = Dinv + (size_t)6 * l;
+  const R* Bi = Hpl + (size_t)18 * e;
+  R BD[6][3];
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    BD[r][0] = Bi[r * 3] * di[0] + Bi[r * 3 + 1] * di[1] + Bi[r * 3 + 2] * di[2];
+    BD[r][1] = Bi[r * 3] * di[1] + Bi[r * 3 + 1] * di[3] + Bi[r * 3 + 2] * di[4];
+    BD[r][2] = Bi[r * 3] * di[2] + Bi[r * 3 + 1] * di[4] + Bi[r * 3 + 2] * di[5];
+    const R cf = Bi[r * 3] * db[3 * l] + Bi[r * 3 + 1] * db[3 * l + 1] + Bi[r * 3 + 2] * db[3 * l + 2];
+    unsafeAtomicAdd(&bs[6 * i1 + r], -cf);
+  }
+  for (int e2 = e; e2 < ptStart[l + 1]; e2++) {
+    const int i2 = Ed.pidx[e2];
+    if (i2 < 0) continue;
+    const R* Bj = Hpl + (size_t)18 * e2;
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      const R b0 = Bj[q * 3], b1 = Bj[q * 3 + 1], b2 = Bj[q * 3 + 2];
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        const R v = BD[r][0] * b0 + BD[r][1] * b1 + BD[r][2] * b2;
+        unsafeAtomicAdd(&S[(size_t)(6 * i2 + q) * n + 6 * i1 + r], -v);
+      }
+    }
+  }
+}
+
+// ---- dense blocked left-looking Cholesky of S (n multiple of 32, lower triangle, row-major) -----------------
+// Launch kb: workgroup r handles tile (block row kb + r, block column kb).  Every workgroup recomputes the
+// 32x32 diagonal tile, factorises it in LDS, and (r > 0) solves its own tile against it, so a block column needs
+// one launch and no inter-workgroup hand-off.  status[0] is set when a pivot is not positive
+// (LinearSolverEigen reports failure -> the LM step is rejected, linear_solver_eigen.h:118-126).
+constexpr int NB = 32;
+__global__ __launch_bounds__(256) void k_chol_panel(R* __restrict__ S, R* __restrict__ diagL, int n, int kb, int* __restrict__ status) {
+  __shared__ R Dg[NB][NB + 1];   // diagonal tile / its factor
+  __shared__ R Tl[NB][NB + 1];   // this workgroup's tile
+  __shared__ R La[NB][NB + 1];   // staged L[rowblk, j]
+  __shared__ R Lb[NB][NB + 1];   // staged L[kb, j]
+  const int tid = threadIdx.x, tr = tid >> 3, tc4 = (tid & 7) * 4;  // thread -> row tr, columns tc4..tc4+3
+  const int rb = kb + blockIdx.x;
+  const bool own = blockIdx.x > 0;
+  R accD[4], accT[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    accD[c] = S[(size_t)(kb * NB + tr) * n + kb * NB + tc4 + c];
+    accT[c] = own ? S[(size_t)(rb * NB + tr) * n + kb * NB + tc4 + c] : 0;
+  }
+  for (int j = 0; j < kb; j++) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      Lb[tr][tc4 + c] = S[(size_t)(kb * NB + tr) * n + j * NB + tc4 + c];
+      if (own) La[tr][tc4 + c] = S[(size_t)(rb * NB + tr) * n + j * NB + tc4 + c];
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < NB; k++) {
+      const R lbk = Lb[tr][k], lak = own ? La[tr][k] : 0;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const R lc = Lb[tc4 + c][k];
+        accD[c] -= lbk * lc;
+        accT[c] -= lak * lc;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 4; c++) { Dg[tr][tc4 + c] = accD[c]; Tl[tr][tc4 + c] = accT[c]; }
+  __syncthreads();
+  // unblocked LL^T of the diagonal tile (lower part of Dg)
+  for (int j = 0; j < NB; j++) {
+    const R d = Dg[j][j];
+    __syncthreads();
+    if (!(d > 0)) {
+      if (tid == 0) atomicMax(status, 1);
+      return;
+    }
+    const R sd = sqrt(d);
+    if (tid < NB) {
+      if (tid == j) Dg[j][j] = sd;
+      else if (tid > j) Dg[tid][j] = Dg[tid][j] / sd;
+    }
+    __syncthreads();
+    // trailing update: rows i > j, cols j < c <= i
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+      const int i = idx >> 5, c = idx & 31;
+      if (i > j && c > j && c <= i) Dg[i][c] -= Dg[i][j] * Dg[c][j];
+    }
+    __syncthreads();
+  }
+  if (!own) {  // the factor of the diagonal tile lives in diagL: S's own diagonal tile is still being read by the other workgroups
+#pragma unroll
+    for (int c = 0; c < 4; c++) diagL[(size_t)kb * NB * NB + tr * NB + tc4 + c] = tc4 + c <= tr ? Dg[tr][tc4 + c] : 0;
+    return;
+  }
+  // X * Lkk^T = T  ->  row-wise forward substitution, one thread per row of the tile
+  if (tid < NB) {
+    for (int c = 0; c < NB; c++) {
+      R s = Tl[tid][c];
+      for (int k = 0; k < c; k++) s -= Tl[tid][k] * Dg[c][k];
+      Tl[tid][c] = s / Dg[c][c];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 4; c++) S[(size_t)(rb * NB + tr) * n + kb * NB + tc4 + c] = Tl[tr][tc4 + c];
+}
+
+// x = S^-1 b with S = L L^T (single workgroup, blocked by 32): forward then backward substitution.
+__global__ __launch_bounds__(256) void k_chol_solve(const R* __restrict__ L, const R* __restrict__ diagL, int n, const R* __restrict__ b, R* __restrict__ x) {
+  extern __shared__ R y[];  // [n]
+  __shared__ R blk[NB][NB + 1];
+  const int tid = threadIdx.x, nb = n / NB;
+  for (int i = tid; i < n; i += 256) y[i] = b[i];
+  __syncthreads();
+  for (int kb = 0; kb < nb; kb++) {
+    for (int idx = tid; idx < NB * NB; idx += 256) blk[idx >> 5][idx & 31] = diagL[(size_t)kb * NB * NB + idx];
+    __syncthreads();
+    if (tid < 64) {  // one wave: sequential substitution inside the diagonal block
+      for (int j = 0; j < NB; j++) {
+        const R yj = y[kb * NB + j] / blk[j][j];
+        __builtin_amdgcn_wave_barrier();
+        if (tid == j) y[kb * NB + j] = yj;
+        else if (tid > j && tid < NB) y[kb * NB + tid] -= blk[tid][j] * yj;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+    for (int i = (kb + 1) * NB + tid; i < n; i += 256) {
+      R s = y[i];
+      const R* row = L + (size_t)i * n + kb * NB;
+#pragma unroll 8
+      for (int k = 0; k < NB; k++) s -= row[k] * y[kb * NB + k];
+      y[i] = s;
+    }
+    __syncthreads();
+  }
+  for (int kb = nb - 1; kb >= 0; kb--) {
+    for (int idx = tid; idx < NB * NB; idx += 256) blk[idx >> 5][idx & 31] = diagL[(size_t)kb * NB * NB + idx];
+    __syncthreads();
+    if (tid < 64) {
+      for (int j = NB - 1; j >= 0; j--) {
+        const R yj = y[kb * NB + j] / blk[j][j];
+        __builtin_amdgcn_wave_barrier();
+        if (tid == j) y[kb * NB + j] = yj;
+        else if (tid < j) y[kb * NB + tid] -= blk[j][tid] * yj;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < kb * NB; i += 256) {
+      R s = y[i];
+#pragma unroll 8
+      for (int k = 0; k < NB; k++) s -= L[(size_t)(kb * NB + k) * n + i] * y[kb * NB + k];
+      y[i] = s;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += 256) x[i] = y[i];
+}
+
+// landmark step (block_solver.hpp:420-444): xl = D^-1 (b_l - sum_e Hpl_e^T xp[pose(e)])
+__global__ __launch_bounds__(128) void k_backsub(EdgeSoA Ed, const int* __restrict__ ptStart, int nL, const R* __restrict__ Hpl,
+                                                 const R* __restrict__ Dinv, const R* __restrict__ bl, const R* __restrict__ xp,
+                                                 R* __restrict__ xl) {
+  const int l = blockIdx.x * 128 + threadIdx.x;
+  if (l >= nL) return;
+  R c0 = bl[3 * l], c1 = bl[3 * l + 1], c2 = bl[3 * l + 2];
+  for (int e = ptStart[l]; e < ptStart[l + 1]; e++) {
+    const int i1 = Ed.pidx[e];
+    if (i1 < 0) continue;
+    const R* B = Hpl + (size_t)18 * e;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const R xv = xp[6 * i1 + r];
+      c0 -= B[r * 3] * xv; c1 -= B[r * 3 + 1] * xv; c2 -= B[r * 3 + 2] * xv;
+    }
+  }
+  const R* di = Dinv + (size_t)6 * l;
+  xl[3 * l] = di[0] * c0 + di[1] * c1 + di[2] * c2;
+  xl[3 * l + 1] = di[1] * c0 + di[3] * c1 + di[4] * c2;
+  xl[3 * l + 2] = di[2] * c0 + di[4] * c1 + di[5] * c2;
+}
+
+// SparseOptimizer::update (sparse_optimizer.cpp:433): poses <- exp(dxi) * pose (se3quat.h:100-106, 218-257),
+// points <- X + dX.  Reads `src`, writes `dst` (push/pop become a buffer swap on the host).
+__global__ __launch_bounds__(256) void k_update(const R* __restrict__ srcPoses, const R* __restrict__ srcPts, R* __restrict__ dstPoses,
+                                                R* __restrict__ dstPts, const int* __restrict__ poseOf, int nP,
+                                                const int* __restrict__ ptOf, int nL, const R* __restrict__ xp, const R* __restrict__ xl) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < nP) {
+    const int k = poseOf[i];
+    V3 t; Q4 q;
+    load_pose(srcPoses, k, t, q);
+    const R* u = xp + 6 * i;
+    const V3 omega{u[0], u[1], u[2]}, ups{u[3], u[4], u[5]};
+    const R theta = sqrt(omega.x * omega.x + omega.y * omega.y + omega.z * omega.z);
+    const R Om[3][3] = {{0, -omega.z, omega.y}, {omega.z, 0, -omega.x}, {-omega.y, omega.x, 0}};
+    R Om2[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) Om2[a][b] = Om[a][0] * Om[0][b] + Om[a][1] * Om[1][b] + Om[a][2] * Om[2][b];
+    R ca, cb, cc;
+    const bool small = theta < 0.00001;
+    if (small) { ca = 1; cb = 0.5; cc = 1. / 6.; }
+    else { ca = sin(theta) / theta; cb = (1 - cos(theta)) / (theta * theta); cc = (theta - sin(theta)) / pow(theta, 3.0); }
+    R Rm[3][3], V[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        const R I = a == b ? 1.0 : 0.0;
+        if (small) { Rm[a][b] = I + Om[a][b] + 0.5 * Om2[a][b]; V[a][b] = I + 0.5 * Om[a][b] + cc * Om2[a][b]; }
+        else { Rm[a][b] = I + ca * Om[a][b] + cb * Om2[a][b]; V[a][b] = I + cb * Om[a][b] + cc * Om2[a][b]; }
+      }
+    Q4 eq = rToQ(Rm);
+    qnormalize(eq);
+    const V3 et{V[0][0] * ups.x + V[0][1] * ups.y + V[0][2] * ups.z, V[1][0] * ups.x + V[1][1] * ups.y + V[1][2] * ups.z,
+                V[2][0] * ups.x + V[2][1] * ups.y + V[2][2] * ups.z};
+    const V3 nt = add(et, qrot(eq, t));
+    Q4 nq = qmul(eq, q);
+    qnormalize(nq);
+    R* o = dstPoses + 7 * k;
+    o[0] = nt.x; o[1] = nt.y; o[2] = nt.z; o[3] = nq.x; o[4] = nq.y; o[5] = nq.z; o[6] = nq.w;
+  }
+  if (i < nL) {
+    const int p = ptOf[i];
+    dstPts[3 * p] = srcPts[3 * p] + xl[3 * i];
+    dstPts[3 * p + 1] = srcPts[3 * p + 1] + xl[3 * i + 1];
+    dstPts[3 * p + 2] = srcPts[3 * p + 2] + xl[3 * i + 2];
+  }
+}
+
+// computeScale (levenberg.cpp:166-173): sum_j x_j (lambda x_j + b_j) over pose and landmark unknowns -> out[slot]
+__global__ __launch_bounds__(256) void k_scale(const R* __restrict__ xp, const R* __restrict__ bp, int np6, const R* __restrict__ xl,
+                                               const R* __restrict__ bl, int nl3, R lambda, R* __restrict__ out, int slot) {
+  __shared__ R lds[4];
+  R v = 0;
+  for (int i = threadIdx.x; i < np6; i += 256) v += xp[i] * (lambda * xp[i] + bp[i]);
+  for (int i = threadIdx.x; i < nl3; i += 256) v += xl[i] * (lambda * xl[i] + bl[i]);
+  const R s = block_sum(v, lds);
+  if (threadIdx.x == 0) out[slot] = s;
+}
+
+// depth of every edge under the current estimate (isDepthPositive, types_six_dof_expmap.h:215-219,276-280)
+__global__ __launch_bounds__(256) void k_depths(const int* __restrict__ ePose, const int* __restrict__ ePt, int E, const R* __restrict__ poses,
+                                                const R* __restrict__ pts, R* __restrict__ depth) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  V3 t; Q4 q;
+  load_pose(poses, ePose[e], t, q);
+  const R* X = pts + 3 * ePt[e];
+  depth[e] = add(qrot(q, V3{X[0], X[1], X[2]}), t).z;
+}
+
+}  // namespace ba
+}  // namespace ydorb

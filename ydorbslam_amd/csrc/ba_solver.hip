@@ -1,0 +1,452 @@
+// Host driver of the MI355X local-BA back-end + its C ABI (include/ydorb/c_api.h, "Local bundle adjustment").
+// Sequencing restated from the reference: two-stage schedule of Optimizer::localBundleAdjust
+// (src/optimizer.cpp:284-334), SparseOptimizer::initializeOptimization/optimize
+// (thirdParty/g2o/g2o/core/sparse_optimizer.cpp:208-280, 366-440) and the Levenberg-Marquardt trial loop
+// (core/optimization_algorithm_levenberg.cpp:57-173).  All arithmetic on the graph runs in ba_kernels.hip.h;
+// the host only sorts the edge list, keeps lambda / nu, and reads three scalars per trial.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <numeric>
+#include <vector>
+
+#include "../../include/ydorb/c_api.h"
+#include "ba_kernels.hip.h"
+#include "ydorb_host.h"
+
+using namespace ydorb;
+using namespace ydorb::ba;
+
+namespace {
+
+#define HIPCHK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      ydorb::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return YDORB_ERR_HIP;                                                                   \
+    }                                                                                         \
+  } while (0)
+
+struct DBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return YDORB_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 4, 256);
+    if (hipMalloc(&p, want) != hipSuccess) { set_error("hipMalloc(%zu) failed", want); return YDORB_ERR_HIP; }
+    cap = want;
+    return YDORB_OK;
+  }
+  template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+enum { PH_ERR = 0, PH_BUILD, PH_SCHUR, PH_SOLVE, PH_UPDATE, PH_COUNT };
+
+struct Ctx {  // per-device scratch, reused across calls (localBundleAdjust runs on one thread, localMapping.cpp:29)
+  int device = -1;
+  hipStream_t stream = nullptr;
+  DBuf poses[2], pts[2], ePoseAll, ePtAll, depth;
+  DBuf ePose, ePidx, ePt, eMeas, eInfo, eRobust, eLm, ptStart, poseStart, poseEdges, poseOf, ptOf;
+  DBuf err, partial, Hll, bl, Hpl, Hpp, bp, S, diagL, bs, Dinv, db, xp, xl, scal, status;
+  hipEvent_t ev[2 * PH_COUNT + 2]{};
+  bool evInit = false;
+};
+std::mutex g_mu;
+Ctx g_ctx[16];
+
+struct Run {
+  Ctx* c;
+  const YdBaProblem* P;
+  const YdBaOptions* O;
+  YdBaResult* res;
+  int cur = 0;  // which of poses[2]/pts[2] holds the current estimate
+  std::vector<uint8_t> level, robust;
+  std::vector<double> err;  // per original edge, as last computed
+  Cam cam;
+  double phaseMs[PH_COUNT] = {0, 0, 0, 0, 0};
+  bool pending[PH_COUNT] = {false, false, false, false, false};
+  bool stopped() const { return P->stop && *P->stop; }
+};
+
+int allreduce(Run& R_, void* d_buf, int64_t count, int op) {
+  const YdBaOptions* O = R_.O;
+  if (!O->allreduce || O->world <= 1) return YDORB_OK;
+  if (count > O->comm_doubles || !O->d_comm_buf) { set_error("BA comm buffer too small (%lld doubles needed)", (long long)count); return YDORB_ERR_CAPACITY; }
+  HIPCHK(hipMemcpyAsync(O->d_comm_buf, d_buf, sizeof(double) * count, hipMemcpyDeviceToDevice, R_.c->stream));
+  HIPCHK(hipStreamSynchronize(R_.c->stream));
+  if (O->allreduce(O->allreduce_user, O->d_comm_buf, count, op) != 0) { set_error("BA all-reduce callback failed"); return YDORB_ERR_HIP; }
+  HIPCHK(hipMemcpyAsync(d_buf, O->d_comm_buf, sizeof(double) * count, hipMemcpyDeviceToDevice, R_.c->stream));
+  return YDORB_OK;
+}
+
+struct PhaseTimer {
+  Run& r; int ph; hipEvent_t a, b; bool on;
+  PhaseTimer(Run& r_, int ph_) : r(r_), ph(ph_), a(r_.c->ev[2 * ph_]), b(r_.c->ev[2 * ph_ + 1]), on(true) {
+    collect(r_, ph_);  // an earlier recording of this phase's events must be read before they are re-recorded
+    (void)hipEventRecord(a, r.c->stream);
+  }
+  void stop() { if (on) { (void)hipEventRecord(b, r.c->stream); on = false; r.pending[ph] = true; } }
+  static void collect(Run& r_, int ph_) {
+    if (!r_.pending[ph_]) return;
+    float ms = 0;
+    if (hipEventSynchronize(r_.c->ev[2 * ph_ + 1]) == hipSuccess && hipEventElapsedTime(&ms, r_.c->ev[2 * ph_], r_.c->ev[2 * ph_ + 1]) == hipSuccess)
+      r_.phaseMs[ph_] += ms;
+    r_.pending[ph_] = false;
+  }
+};
+
+// one SparseOptimizer::optimize(iterations) on the level-0 edges
+int optimize(Run& R_, int iterations, int stage) {
+  Ctx& c = *R_.c;
+  const YdBaProblem& P = *R_.P;
+  const YdBaOptions& O = *R_.O;
+  hipStream_t s = c.stream;
+  const int K = P.n_poses, NP = P.n_points, E = P.n_edges;
+  std::vector<int> act;
+  for (int e = 0; e < E; e++) if (!R_.level[e]) act.push_back(e);
+  if (act.empty()) return YDORB_OK;
+  // index mapping (buildIndexMapping, sparse_optimizer.cpp:168-192): free poses first, then landmarks, active ones only
+  std::vector<int> poseIdx(K, -1), ptIdx(NP, -1), poseOf, ptOf;
+  {
+    std::vector<uint8_t> pu(K, 0), qu(NP, 0);
+    for (int e : act) { pu[P.edge_pose[e]] = 1; qu[P.edge_point[e]] = 1; }
+    for (int k = 0; k < K; k++) if (pu[k] && !P.pose_fixed[k]) { poseIdx[k] = (int)poseOf.size(); poseOf.push_back(k); }
+    for (int p = 0; p < NP; p++) if (qu[p]) { ptIdx[p] = (int)ptOf.size(); ptOf.push_back(p); }
+  }
+  const int nP = (int)poseOf.size(), nL = (int)ptOf.size(), Ea = (int)act.size();
+  if (O.world > 1) {
+    // every rank must factorise the same reduced system: the free-pose set comes from the caller's fixed mask only
+    poseOf.clear();
+    for (int k = 0; k < K; k++) { poseIdx[k] = -1; if (!P.pose_fixed[k]) { poseIdx[k] = (int)poseOf.size(); poseOf.push_back(k); } }
+  }
+  const int nPf = (int)poseOf.size();
+  (void)nP;
+  std::sort(act.begin(), act.end(), [&](int a, int b) {
+    const int la = ptIdx[P.edge_point[a]], lb = ptIdx[P.edge_point[b]];
+    if (la != lb) return la < lb;
+    const int pa = poseIdx[P.edge_pose[a]], pb = poseIdx[P.edge_pose[b]];
+    if (pa != pb) return pa < pb;
+    return a < b;
+  });
+  std::vector<int> hPose(Ea), hPidx(Ea), hPt(Ea), hLm(Ea), hPtStart(nL + 1, 0), hPoseStart(nPf + 1, 0), hPoseEdges;
+  std::vector<double> hMeas((size_t)3 * Ea), hInfo(Ea);
+  std::vector<uint8_t> hRobust(Ea);
+  for (int i = 0; i < Ea; i++) {
+    const int e = act[i];
+    hPose[i] = P.edge_pose[e]; hPidx[i] = poseIdx[P.edge_pose[e]]; hPt[i] = P.edge_point[e]; hLm[i] = ptIdx[P.edge_point[e]];
+    for (int d = 0; d < 3; d++) hMeas[3 * i + d] = P.edge_meas[3 * e + d];
+    hInfo[i] = P.edge_inv_sigma2[e];
+    hRobust[i] = R_.robust[e];
+    hPtStart[hLm[i] + 1]++;
+    if (hPidx[i] >= 0) hPoseStart[hPidx[i] + 1]++;
+  }
+  for (int l = 0; l < nL; l++) hPtStart[l + 1] += hPtStart[l];
+  for (int i = 0; i < nPf; i++) hPoseStart[i + 1] += hPoseStart[i];
+  hPoseEdges.resize(hPoseStart[nPf]);
+  {
+    std::vector<int> fill(hPoseStart.begin(), hPoseStart.end() - 1);
+    for (int i = 0; i < Ea; i++) if (hPidx[i] >= 0) hPoseEdges[fill[hPidx[i]]++] = i;
+  }
+  const int n = std::max(NB, (6 * nPf + NB - 1) / NB * NB), nb = n / NB;
+  const int nBlkE = (Ea + 255) / 256;
+  int rc;
+  if ((rc = c.ePose.ensure(sizeof(int) * Ea)) || (rc = c.ePidx.ensure(sizeof(int) * Ea)) || (rc = c.ePt.ensure(sizeof(int) * Ea)) ||
+      (rc = c.eLm.ensure(sizeof(int) * Ea)) || (rc = c.eMeas.ensure(sizeof(double) * 3 * Ea)) || (rc = c.eInfo.ensure(sizeof(double) * Ea)) ||
+      (rc = c.eRobust.ensure(Ea)) || (rc = c.ptStart.ensure(sizeof(int) * (nL + 1))) || (rc = c.poseStart.ensure(sizeof(int) * (nPf + 1))) ||
+      (rc = c.poseEdges.ensure(sizeof(int) * std::max<size_t>(hPoseEdges.size(), 1))) || (rc = c.poseOf.ensure(sizeof(int) * std::max(nPf, 1))) ||
+      (rc = c.ptOf.ensure(sizeof(int) * nL)) || (rc = c.err.ensure(sizeof(double) * 3 * Ea)) || (rc = c.partial.ensure(sizeof(double) * nBlkE)) ||
+      (rc = c.Hll.ensure(sizeof(double) * 6 * nL)) || (rc = c.bl.ensure(sizeof(double) * 3 * nL)) || (rc = c.Hpl.ensure(sizeof(double) * 18 * (size_t)Ea)) ||
+      (rc = c.Hpp.ensure(sizeof(double) * 42 * std::max(nPf, 1))) || (rc = c.S.ensure(sizeof(double) * ((size_t)n * n + n))) ||
+      (rc = c.diagL.ensure(sizeof(double) * (size_t)nb * NB * NB)) || (rc = c.Dinv.ensure(sizeof(double) * 6 * nL)) || (rc = c.db.ensure(sizeof(double) * 3 * nL)) ||
+      (rc = c.xp.ensure(sizeof(double) * n)) || (rc = c.xl.ensure(sizeof(double) * 3 * nL)) || (rc = c.scal.ensure(sizeof(double) * 8)) ||
+      (rc = c.status.ensure(sizeof(int) * 2)))
+    return rc;
+  // Hpp and bp are contiguous ([36 nPf | 6 nPf]) so one all-reduce covers both; bs follows S for the same reason
+  double* dHpp = c.Hpp.as<double>();
+  double* dbp = dHpp + (size_t)36 * nPf;
+  double* dS = c.S.as<double>();
+  double* dbs = dS + (size_t)n * n;
+#define UP(buf, vec, T) HIPCHK(hipMemcpyAsync(c.buf.p, vec.data(), sizeof(T) * vec.size(), hipMemcpyHostToDevice, s))
+  UP(ePose, hPose, int); UP(ePidx, hPidx, int); UP(ePt, hPt, int); UP(eLm, hLm, int); UP(eMeas, hMeas, double); UP(eInfo, hInfo, double);
+  UP(eRobust, hRobust, uint8_t); UP(ptStart, hPtStart, int); UP(poseStart, hPoseStart, int); UP(ptOf, ptOf, int);
+  if (!hPoseEdges.empty()) UP(poseEdges, hPoseEdges, int);
+  if (nPf) UP(poseOf, poseOf, int);
+#undef UP
+  EdgeSoA Ed{c.ePose.as<int>(), c.ePidx.as<int>(), c.ePt.as<int>(), c.eMeas.as<double>(), c.eInfo.as<double>(), c.eRobust.as<uint8_t>(), Ea};
+  const double dM = O.delta_mono, dSt = O.delta_stereo;
+  double hscal[8];
+  const bool multi = O.world > 1 && O.allreduce;
+
+  auto computeChi2 = [&](int buf, double* out) -> int {
+    PhaseTimer t(R_, PH_ERR);
+    hipLaunchKernelGGL(k_errors, dim3(nBlkE), dim3(256), 0, s, Ed, c.poses[buf].as<double>(), c.pts[buf].as<double>(), R_.cam, dM, dSt,
+                       c.err.as<double>(), c.partial.as<double>());
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, c.partial.as<double>(), nBlkE, c.scal.as<double>(), 0);
+    t.stop();
+    if (multi) { int r2 = allreduce(R_, c.scal.p, 1, 0); if (r2) return r2; }
+    HIPCHK(hipMemcpyAsync(hscal, c.scal.p, sizeof(double) * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *out = hscal[0];
+    return YDORB_OK;
+  };
+
+  double lambda = 0, ni = 2;
+  for (int it = 0; it < iterations && !R_.stopped(); it++) {
+    double currentChi;
+    if ((rc = computeChi2(R_.cur, &currentChi))) return rc;
+    {  // buildSystem
+      PhaseTimer t(R_, PH_BUILD);
+      hipLaunchKernelGGL(k_build_points, dim3((nL + 127) / 128), dim3(128), 0, s, Ed, c.ptStart.as<int>(), nL, c.poses[R_.cur].as<double>(),
+                         c.pts[R_.cur].as<double>(), R_.cam, dM, dSt, c.err.as<double>(), c.Hll.as<double>(), c.bl.as<double>(), c.Hpl.as<double>());
+      if (nPf)
+        hipLaunchKernelGGL(k_build_poses, dim3(nPf), dim3(256), 0, s, Ed, c.poseStart.as<int>(), c.poseEdges.as<int>(), c.poses[R_.cur].as<double>(),
+                           c.pts[R_.cur].as<double>(), R_.cam, dM, dSt, c.err.as<double>(), dHpp, dbp);
+      t.stop();
+      if (multi && nPf) { if ((rc = allreduce(R_, dHpp, (int64_t)42 * nPf, 0))) return rc; }
+    }
+    if (it == 0) {  // computeLambdaInit
+      hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, s, dHpp, nPf, c.Hll.as<double>(), nL, c.scal.as<double>(), 1);
+      if (multi) { if ((rc = allreduce(R_, c.scal.as<double>() + 1, 1, 1))) return rc; }
+      HIPCHK(hipMemcpyAsync(hscal, c.scal.p, sizeof(double) * 8, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      lambda = 1e-5 * hscal[1];
+      ni = 2;
+    }
+    double rho = 0;
+    int qmax = 0;
+    do {
+      const int nxt = R_.cur ^ 1;
+      HIPCHK(hipMemsetAsync(c.status.p, 0, sizeof(int) * 2, s));
+      {
+        PhaseTimer t(R_, PH_SCHUR);
+        const double contrib = (!multi || O.rank == 0) ? 1.0 : 0.0;
+        hipLaunchKernelGGL(k_schur_init, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s, dHpp, dbp, nPf, n, lambda, contrib, dS, dbs);
+        hipLaunchKernelGGL(k_dinv, dim3((nL + 255) / 256), dim3(256), 0, s, c.Hll.as<double>(), c.bl.as<double>(), nL, lambda, c.Dinv.as<double>(), c.db.as<double>());
+        hipLaunchKernelGGL(k_schur, dim3(nBlkE), dim3(256), 0, s, Ed, c.ptStart.as<int>(), c.eLm.as<int>(), c.Hpl.as<double>(), c.Dinv.as<double>(),
+                           c.db.as<double>(), n, dS, dbs);
+        t.stop();
+      }
+      if (multi) {  // sum of the per-rank landmark contributions (+ rank 0's Hpp, lambda, bp)
+        if ((rc = allreduce(R_, dS, (int64_t)n * n + n, 0))) return rc;
+      }
+      {
+        PhaseTimer t(R_, PH_SOLVE);
+        for (int kb = 0; kb < nb; kb++)
+          hipLaunchKernelGGL(k_chol_panel, dim3(nb - kb), dim3(256), 0, s, dS, c.diagL.as<double>(), n, kb, c.status.as<int>());
+        hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(256), sizeof(double) * n, s, dS, c.diagL.as<double>(), n, dbs, c.xp.as<double>());
+        hipLaunchKernelGGL(k_backsub, dim3((nL + 127) / 128), dim3(128), 0, s, Ed, c.ptStart.as<int>(), nL, c.Hpl.as<double>(), c.Dinv.as<double>(),
+                           c.bl.as<double>(), c.xp.as<double>(), c.xl.as<double>());
+        t.stop();
+      }
+      {
+        PhaseTimer t(R_, PH_UPDATE);
+        HIPCHK(hipMemcpyAsync(c.poses[nxt].p, c.poses[R_.cur].p, sizeof(double) * 7 * K, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(c.pts[nxt].p, c.pts[R_.cur].p, sizeof(double) * 3 * NP, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_update, dim3((std::max(nPf, nL) + 255) / 256), dim3(256), 0, s, c.poses[R_.cur].as<double>(), c.pts[R_.cur].as<double>(),
+                           c.poses[nxt].as<double>(), c.pts[nxt].as<double>(), c.poseOf.as<int>(), nPf, c.ptOf.as<int>(), nL, c.xp.as<double>(),
+                           c.xl.as<double>());
+        // computeScale: pose part once (rank 0), landmark part per rank
+        hipLaunchKernelGGL(k_scale, dim3(1), dim3(256), 0, s, c.xp.as<double>(), dbp, (!multi || O.rank == 0) ? 6 * nPf : 0, c.xl.as<double>(),
+                           c.bl.as<double>(), 3 * nL, lambda, c.scal.as<double>(), 2);
+        t.stop();
+        if (multi) { if ((rc = allreduce(R_, c.scal.as<double>() + 2, 1, 0))) return rc; }
+      }
+      double tempChi;
+      if ((rc = computeChi2(nxt, &tempChi))) return rc;  // also brings back scal[2] and leaves err = errors of the trial state
+      const double scaleSum = hscal[2];
+      int hstatus[2];
+      HIPCHK(hipMemcpy(hstatus, c.status.p, sizeof(hstatus), hipMemcpyDeviceToHost));
+      const bool ok2 = hstatus[0] == 0;
+      if (!ok2) tempChi = std::numeric_limits<double>::max();
+      rho = currentChi - tempChi;
+      double scale = scaleSum + 1e-3;
+      rho /= scale;
+      if (rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - pow((2 * rho - 1), 3);
+        alpha = std::min(alpha, 2. / 3.);
+        lambda *= std::max(1. / 3., alpha);
+        ni = 2;
+        currentChi = tempChi;
+        R_.cur = nxt;  // discardTop(): keep the updated estimate
+      } else {
+        lambda *= ni;
+        ni *= 2;  // pop(): the previous estimate is still in poses[cur]
+        if (!std::isfinite(lambda)) { qmax++; R_.res->n_trials++; break; }
+      }
+      qmax++;
+      R_.res->n_trials++;
+    } while (rho < 0 && qmax < O.max_trials && !R_.stopped());
+    YdBaResult* res = R_.res;
+    if (res->n_log < 32) {
+      res->log_chi2[res->n_log] = currentChi; res->log_lambda[res->n_log] = lambda; res->log_trials[res->n_log] = qmax; res->log_stage[res->n_log] = stage;
+      res->n_log++;
+    }
+    res->n_iterations++;
+    if (qmax == O.max_trials || rho == 0 || !std::isfinite(lambda)) break;  // SolverResult::Terminate
+  }
+  // errors as g2o leaves them in the edges: those of the last evaluated state (possibly a rejected trial)
+  std::vector<double> herr((size_t)3 * Ea);
+  HIPCHK(hipMemcpyAsync(herr.data(), c.err.p, sizeof(double) * 3 * Ea, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  for (int i = 0; i < Ea; i++)
+    for (int d = 0; d < 3; d++) R_.err[(size_t)3 * act[i] + d] = herr[(size_t)3 * i + d];
+  for (int ph = 0; ph < PH_COUNT; ph++) PhaseTimer::collect(R_, ph);
+  return YDORB_OK;
+}
+
+int edgeDepths(Run& R_, std::vector<double>& depth) {
+  Ctx& c = *R_.c;
+  const int E = R_.P->n_edges;
+  depth.resize(E);
+  if (!E) return YDORB_OK;
+  hipLaunchKernelGGL(k_depths, dim3((E + 255) / 256), dim3(256), 0, c.stream, c.ePoseAll.as<int>(), c.ePtAll.as<int>(), E, c.poses[R_.cur].as<double>(),
+                     c.pts[R_.cur].as<double>(), c.depth.as<double>());
+  HIPCHK(hipMemcpyAsync(depth.data(), c.depth.p, sizeof(double) * E, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipStreamSynchronize(c.stream));
+  return YDORB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ydorb_ba_default_options(YdBaOptions* o) {
+  if (!o) return;
+  memset(o, 0, sizeof(*o));
+  o->iters1 = 5; o->iters2 = 10;
+  o->chi2_mono = 5.991; o->chi2_stereo = 7.815;
+  o->delta_mono = (double)(float)sqrt(5.991);   // `const float monoDelta = sqrt(5.991)`, optimizer.cpp:223
+  o->delta_stereo = (double)(float)sqrt(7.815);
+  o->max_trials = 10;
+  o->device = 0;
+  o->rank = 0; o->world = 1;
+}
+
+int ydorb_ba_solve(const YdBaProblem* P, const YdBaOptions* optIn, YdBaResult* res) {
+  if (!P || !res) { set_error("null argument"); return YDORB_ERR_INVALID_ARG; }
+  YdBaOptions O;
+  if (optIn) O = *optIn; else ydorb_ba_default_options(&O);
+  uint8_t* outlier = res->edge_outlier;
+  memset(res, 0, sizeof(*res));
+  res->edge_outlier = outlier;
+  const int K = P->n_poses, NP = P->n_points, E = P->n_edges;
+  if (K < 0 || NP < 0 || E < 0 || (K && (!P->poses || !P->pose_fixed)) || (NP && !P->points) ||
+      (E && (!P->edge_pose || !P->edge_point || !P->edge_meas || !P->edge_inv_sigma2)) || O.device < 0 || O.device >= 16 || O.max_trials < 1) {
+    set_error("invalid BA problem");
+    return YDORB_ERR_INVALID_ARG;
+  }
+  for (int e = 0; e < E; e++)
+    if (P->edge_pose[e] < 0 || P->edge_pose[e] >= K || P->edge_point[e] < 0 || P->edge_point[e] >= NP) {
+      set_error("edge %d references a vertex out of range", e);
+      return YDORB_ERR_INVALID_ARG;
+    }
+  if (outlier) memset(outlier, 0, E);
+  if (P->stop && *P->stop) { res->stopped = 1; return YDORB_OK; }  // optimizer.cpp:284-286
+  if (E == 0 || K == 0 || NP == 0) return YDORB_OK;
+  int rc = require_device(O.device);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(g_mu);
+  Ctx& c = g_ctx[O.device];
+  if (!c.stream) {
+    c.device = O.device;
+    HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    for (auto& e : c.ev) HIPCHK(hipEventCreate(&e));
+  }
+  Run R_{&c, P, &O, res};
+  R_.level.assign(E, 0);
+  R_.robust.assign(E, 1);
+  R_.err.assign((size_t)3 * E, 0.0);
+  R_.cam = Cam{P->fx, P->fy, P->cx, P->cy, P->bf};
+  for (int i = 0; i < 2; i++)
+    if ((rc = c.poses[i].ensure(sizeof(double) * 7 * K)) || (rc = c.pts[i].ensure(sizeof(double) * 3 * NP))) return rc;
+  if ((rc = c.ePoseAll.ensure(sizeof(int) * E)) || (rc = c.ePtAll.ensure(sizeof(int) * E)) || (rc = c.depth.ensure(sizeof(double) * E))) return rc;
+  {  // SE3Quat's 7-vector constructor normalises the rotation (se3quat.h:80-86)
+    std::vector<double> hp(P->poses, P->poses + (size_t)7 * K);
+    for (int k = 0; k < K; k++) {
+      double* q = &hp[7 * k + 3];
+      if (q[3] < 0) for (int d = 0; d < 4; d++) q[d] = -q[d];
+      const double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+      for (int d = 0; d < 4; d++) q[d] /= nrm;
+    }
+    HIPCHK(hipMemcpy(c.poses[0].p, hp.data(), sizeof(double) * 7 * K, hipMemcpyHostToDevice));
+  }
+  HIPCHK(hipMemcpy(c.pts[0].p, P->points, sizeof(double) * 3 * NP, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c.ePoseAll.p, P->edge_pose, sizeof(int) * E, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c.ePtAll.p, P->edge_point, sizeof(int) * E, hipMemcpyHostToDevice));
+  hipEvent_t t0 = c.ev[2 * PH_COUNT], t1 = c.ev[2 * PH_COUNT + 1];
+  HIPCHK(hipEventRecord(t0, c.stream));
+
+  if ((rc = optimize(R_, O.iters1, 1))) return rc;
+  auto chi2Of = [&](int e) {
+    const double* r = &R_.err[(size_t)3 * e];
+    return P->edge_inv_sigma2[e] * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  };
+  std::vector<double> depth;
+  if (!R_.stopped()) {  // optimizer.cpp:290-314
+    if ((rc = edgeDepths(R_, depth))) return rc;
+    for (int e = 0; e < E; e++) {
+      const double th = P->edge_meas[3 * e + 2] >= 0 ? O.chi2_stereo : O.chi2_mono;
+      if (chi2Of(e) > th || !(depth[e] > 0.0)) R_.level[e] = 1;
+      R_.robust[e] = 0;
+    }
+    if ((rc = optimize(R_, O.iters2, 2))) return rc;
+  } else {
+    res->stopped = 1;
+  }
+  if ((rc = edgeDepths(R_, depth))) return rc;
+  if (outlier)
+    for (int e = 0; e < E; e++) {
+      const double th = P->edge_meas[3 * e + 2] >= 0 ? O.chi2_stereo : O.chi2_mono;
+      outlier[e] = (chi2Of(e) > th || !(depth[e] > 0.0)) ? 1 : 0;
+    }
+  HIPCHK(hipEventRecord(t1, c.stream));
+  HIPCHK(hipMemcpy(P->poses, c.poses[R_.cur].p, sizeof(double) * 7 * K, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(P->points, c.pts[R_.cur].p, sizeof(double) * 3 * NP, hipMemcpyDeviceToHost));
+  (void)hipEventElapsedTime(&res->ms_total, t0, t1);
+  res->ms_errors = (float)R_.phaseMs[PH_ERR]; res->ms_build = (float)R_.phaseMs[PH_BUILD]; res->ms_schur = (float)R_.phaseMs[PH_SCHUR];
+  res->ms_solve = (float)R_.phaseMs[PH_SOLVE]; res->ms_update = (float)R_.phaseMs[PH_UPDATE];
+  if (R_.stopped()) res->stopped = 1;
+  return YDORB_OK;
+}
+
+int ydorb_ba_dense_solve(int32_t device, const double* A, int32_t n0, const double* b, double* x, int32_t* ok) {
+  if (!A || !b || !x || !ok || n0 < 1 || device < 0 || device >= 16) { set_error("invalid argument"); return YDORB_ERR_INVALID_ARG; }
+  int rc = require_device(device);
+  if (rc) return rc;
+  const int n = (n0 + NB - 1) / NB * NB, nb = n / NB;
+  std::vector<double> hA((size_t)n * n, 0.0), hb(n, 0.0);
+  for (int i = 0; i < n; i++) {
+    for (int j = 0; j < n; j++) hA[(size_t)i * n + j] = (i < n0 && j < n0) ? A[(size_t)i * n0 + j] : (i == j ? 1.0 : 0.0);
+    if (i < n0) hb[i] = b[i];
+  }
+  double *dA = nullptr, *dD = nullptr, *db = nullptr, *dx = nullptr;
+  int* dst = nullptr;
+  HIPCHK(hipMalloc(&dA, sizeof(double) * n * n));
+  HIPCHK(hipMalloc(&dD, sizeof(double) * nb * NB * NB));
+  HIPCHK(hipMalloc(&db, sizeof(double) * n));
+  HIPCHK(hipMalloc(&dx, sizeof(double) * n));
+  HIPCHK(hipMalloc(&dst, sizeof(int) * 2));
+  HIPCHK(hipMemcpy(dA, hA.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(db, hb.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(dst, 0, sizeof(int) * 2));
+  for (int kb = 0; kb < nb; kb++) hipLaunchKernelGGL(k_chol_panel, dim3(nb - kb), dim3(256), 0, 0, dA, dD, n, kb, dst);
+  hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(256), sizeof(double) * n, 0, dA, dD, n, db, dx);
+  HIPCHK(hipGetLastError());
+  std::vector<double> hx(n);
+  int hst[2];
+  HIPCHK(hipMemcpy(hx.data(), dx, sizeof(double) * n, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hst, dst, sizeof(hst), hipMemcpyDeviceToHost));
+  *ok = hst[0] == 0;
+  for (int i = 0; i < n0; i++) x[i] = hx[i];
+  (void)hipFree(dA); (void)hipFree(dD); (void)hipFree(db); (void)hipFree(dx); (void)hipFree(dst);
+  return YDORB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+"""Python mirror of YDORBSLAM::Optimizer::localBundleAdjust (reference src/optimizer.hpp:34, optimizer.cpp:138-352) over the C ABI.
+
+The graph is passed flat (what optimizer.cpp:175-283 hands to g2o); the covisibility walk and the map write-back belong to the caller.
+"""
+import ctypes as C
+import numpy as np
+
+from ._lib import BA_ALLREDUCE_FN, YdBaOptions, YdBaProblem, YdBaResult, check, lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Optimizer:
+    @staticmethod
+    def default_options(device=0):
+        o = YdBaOptions()
+        lib().ydorb_ba_default_options(C.byref(o))
+        o.device = device
+        return o
+
+    @staticmethod
+    def local_bundle_adjust(prob, options=None, stop=None, allreduce=None, comm_tensor_ptr=None, comm_doubles=0, rank=0, world=1):
+        """prob: dict(poses[K,7], fixed[K], points[P,3], edge_pose, edge_point, meas[E,3], info[E], camera[5]).
+        Returns dict(poses, points, outlier, log (chi2, lambda, trials, stage), trials, iterations, ms)."""
+        L = lib()
+        o = options if options is not None else Optimizer.default_options()
+        poses = np.ascontiguousarray(prob["poses"], np.float64).copy()
+        points = np.ascontiguousarray(prob["points"], np.float64).copy()
+        fixed = np.ascontiguousarray(prob["fixed"], np.uint8)
+        ep = np.ascontiguousarray(prob["edge_pose"], np.int32)
+        eq = np.ascontiguousarray(prob["edge_point"], np.int32)
+        meas = np.ascontiguousarray(prob["meas"], np.float64)
+        info = np.ascontiguousarray(prob["info"], np.float64)
+        cam = [float(v) for v in prob["camera"]]
+        E = len(ep)
+        outlier = np.zeros(max(E, 1), np.uint8)
+        P = YdBaProblem(len(poses), len(points), E, _p(poses), _p(fixed), _p(points), _p(ep), _p(eq), _p(meas), _p(info), *cam,
+                        None if stop is None else _p(stop))
+        cb = None
+        if allreduce is not None:
+            cb = BA_ALLREDUCE_FN(allreduce)
+            o.allreduce = cb
+            o.d_comm_buf = comm_tensor_ptr
+            o.comm_doubles = comm_doubles
+            o.rank, o.world = rank, world
+        res = YdBaResult()
+        res.edge_outlier = outlier.ctypes.data_as(C.c_void_p).value
+        check(L.ydorb_ba_solve(C.byref(P), C.byref(o), C.byref(res)))
+        n = res.n_log
+        log = np.stack([np.array(res.log_chi2[:n]), np.array(res.log_lambda[:n]), np.array(res.log_trials[:n], np.float64),
+                        np.array(res.log_stage[:n], np.float64)], axis=1) if n else np.zeros((0, 4))
+        return dict(poses=poses, points=points, outlier=outlier[:E], log=log, trials=res.n_trials, iterations=res.n_iterations,
+                    stopped=bool(res.stopped),
+                    ms=dict(total=res.ms_total, errors=res.ms_errors, build=res.ms_build, schur=res.ms_schur, solve=res.ms_solve,
+                            update=res.ms_update))
+
+    @staticmethod
+    def dense_solve(A, b, device=0):
+        A = np.ascontiguousarray(A, np.float64)
+        b = np.ascontiguousarray(b, np.float64)
+        x = np.zeros(len(b), np.float64)
+        ok = C.c_int32(0)
+        check(lib().ydorb_ba_dense_solve(device, _p(A), len(b), _p(b), _p(x), C.byref(ok)))
+        return x, bool(ok.value)

@@ -38,3 +38,59 @@ def synth_frame(w=640, h=480, index=0, n_rects=None, n_blobs=200):
 
 def synth_batch(w, h, n, start=0):
     return np.stack([synth_frame(w, h, start + i) for i in range(n)])
+
+
+# ---------------------------------------------------------------------------------------------
+# Synthetic local-BA problem: K cameras on a line, P points, O observations each.
+# ---------------------------------------------------------------------------------------------
+def _so3_exp(w):
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-12:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * (K @ K)
+
+
+def _rot_to_quat(Rm):
+    w = np.sqrt(max(0.0, 1 + Rm[0, 0] + Rm[1, 1] + Rm[2, 2])) / 2
+    x = (Rm[2, 1] - Rm[1, 2]) / (4 * w)
+    y = (Rm[0, 2] - Rm[2, 0]) / (4 * w)
+    z = (Rm[1, 0] - Rm[0, 1]) / (4 * w)
+    return np.array([x, y, z, w])
+
+
+def synth_ba_problem(n_kf=100, n_pts=10000, n_obs=8, seed=1, stereo=True, n_fixed=1, outlier_frac=0.0, mono_frac=0.0):
+    """Returns dict(poses[K,7] (t,q) f64, fixed[K] u8, points[P,3] f64, edge_pose, edge_point i32, meas[E,3] f64,
+    info[E] f64, camera (fx,fy,cx,cy,bf), truth_poses, truth_points).  Poses are world->camera (T_c2w in the reference's naming)."""
+    rng = np.random.default_rng(seed)
+    fx = fy = 500.0
+    cx, cy, bf = 320.0, 240.0, 40.0
+    K, P, O = n_kf, n_pts, min(n_obs, n_kf)
+    cam_x = -0.05 * np.arange(K)  # camera centres along -x, identity rotation -> t = -C
+    truth_poses = np.zeros((K, 7)); truth_poses[:, 6] = 1.0; truth_poses[:, 0] = -cam_x
+    k0 = rng.integers(0, K, P)
+    pts = np.stack([cam_x[k0] + rng.uniform(-3, 3, P), rng.uniform(-2, 2, P), rng.uniform(3, 9, P)], axis=1)
+    ep, eq, meas = [], [], []
+    for p in range(P):
+        cams = rng.choice(K, O, replace=False)
+        cams.sort()
+        for k in cams:
+            Xc = pts[p] + truth_poses[k, :3]
+            u = fx * Xc[0] / Xc[2] + cx + rng.normal(0, 0.5)
+            v = fy * Xc[1] / Xc[2] + cy + rng.normal(0, 0.5)
+            ur = u - bf / Xc[2] if (stereo and rng.random() >= mono_frac) else -1.0
+            if rng.random() < outlier_frac:
+                u += rng.normal(0, 30); v += rng.normal(0, 30)
+            ep.append(k); eq.append(p); meas.append((u, v, ur))
+    E = len(ep)
+    poses = truth_poses.copy()
+    for k in range(n_fixed, K):
+        d = rng.normal(0, 0.005, 6)
+        Rm = _so3_exp(d[:3])
+        poses[k, :3] = Rm @ truth_poses[k, :3] + d[3:]
+        poses[k, 3:] = _rot_to_quat(Rm)
+    fixed = np.zeros(K, np.uint8); fixed[:n_fixed] = 1
+    points = pts + rng.normal(0, 0.03, (P, 3))
+    return dict(poses=poses, fixed=fixed, points=points, edge_pose=np.array(ep, np.int32), edge_point=np.array(eq, np.int32),
+                meas=np.array(meas, np.float64), info=np.ones(E, np.float64), camera=np.array([fx, fy, cx, cy, bf], np.float64),
+                truth_poses=truth_poses, truth_points=pts)
