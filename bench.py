@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ORB extract+match Mkeypoints/s (BASELINE.json config 2: 640x480 mono stream, 1000 features/frame)
+and local-BA LM iterations/s (config 5: 100 keyframes x 10 000 points) on N MI355X of one node.
+
+One "step" = one pass of the hot path over one batch of synthetic frames that already sit in HBM:
+  ydorb_extract_batch_device (pyramid -> FAST cells -> quad-tree -> blur -> orientation + rBRIEF)
+  + ydorb_match_consecutive_device (grid build -> candidate distances -> ordered resolve) over the F-1 frame pairs.
+N > 1: one process per GPU (torch.distributed / RCCL); frames shard across ranks (weak scaling); the frame pair that
+straddles two ranks is matched after an all-gather of the boundary frames' keypoints + descriptors.
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the launch stream; `cpu_baseline` times the
+CPU oracle (a port of the reference algorithm, single thread) on a bounded sample of the same frames.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, NFEAT = 640, 480, 1000
+HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
+FP64_VEC_PEAK = 78.6e12    # FLOP/s, MI355X FP64 vector datasheet figure (the in-container guide lists no FP64 number)
+
+
+def algorithmic_bytes_extract(w, h, n):
+    """image read + padded pyramid written (public output) + keypoints/descriptors written."""
+    tot = w * h + n * 60
+    for l in range(8):
+        inv = np.float32(pow(np.float32(1.2), -l))
+        wl, hl = int(np.rint(np.float32(w) * inv)), int(np.rint(np.float32(h) * inv))
+        tot += (wl + 38) * (hl + 38)
+    return tot
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=128, help="frames per step and per GPU")
+    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic frames (tiled to --frames)")
+    ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the CPU-oracle baseline sample")
+    ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import ydorbslam_amd as y
+    from ydorbslam_amd.synth import synth_frame, synth_ba_problem
+
+    F = args.frames
+    distinct = [synth_frame(W, H, rank * 1000 + i) for i in range(min(args.distinct, F))]
+    imgs = np.stack([distinct[i % len(distinct)] for i in range(F)])
+    ex = y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=F)
+    mt = y.OrbMatcher(0.9, True, device=local_rank)
+    cap = ex.max_keypoints
+    sf = ex.tables()["scale"]
+    d_img = torch.from_numpy(imgs).to(dev)
+    d_kps = torch.zeros((F, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((F, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(F, dtype=torch.int32, device=dev)
+    d_assigned = torch.zeros((F - 1, cap), dtype=torch.int32, device=dev)
+    d_counts = torch.zeros(F - 1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    # cross-rank boundary pair (only N > 1): all-gather of [keypoints | descriptors] of each rank's last frame
+    if world > 1:
+        rec = cap * (28 + 32) + 4
+        send = torch.zeros(rec, dtype=torch.uint8, device=dev)
+        gathered = torch.zeros(world * rec, dtype=torch.uint8, device=dev)
+        b_kps = torch.zeros((2, cap, 7), dtype=torch.float32, device=dev)
+        b_desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device=dev)
+        b_n = torch.zeros(2, dtype=torch.int32, device=dev)
+        b_assigned = torch.zeros((1, cap), dtype=torch.int32, device=dev)
+        b_counts = torch.zeros(1, dtype=torch.int32, device=dev)
+        mt2 = y.OrbMatcher(0.9, True, device=local_rank)
+
+    def step():
+        ex.extract_batch_device(d_img.data_ptr(), W, H, W, W * H, F, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(), stream)
+        mt.match_consecutive_device(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, F, W, H, 15.0, sf, d_assigned.data_ptr(),
+                                    d_counts.data_ptr(), None, stream)
+        if world > 1:
+            send[:cap * 28] = d_kps[F - 1].view(torch.uint8).reshape(-1)
+            send[cap * 28:cap * 60] = d_desc[F - 1].reshape(-1)
+            send[cap * 60:] = d_n[F - 1:F].view(torch.uint8)
+            dist.all_gather_into_tensor(gathered, send)
+            prev = (rank - 1) % world
+            g = gathered[prev * rec:(prev + 1) * rec]
+            b_kps[0] = g[:cap * 28].view(torch.float32).reshape(cap, 7)
+            b_desc[0] = g[cap * 28:cap * 60].reshape(cap, 32)
+            b_n[0:1] = g[cap * 60:].view(torch.int32)
+            b_kps[1], b_desc[1], b_n[1:2] = d_kps[0], d_desc[0], d_n[0:1]
+            mt2.match_consecutive_device(b_kps.data_ptr(), b_desc.data_ptr(), b_n.data_ptr(), cap, 2, W, H, 15.0, sf, b_assigned.data_ptr(),
+                                         b_counts.data_ptr(), None, stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    mt.synchronize()  # surfaces a record-pool overflow, if any
+    t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
+    kp_local = int(d_n.sum().item())
+    matched_local = int(d_counts.sum().item())
+    kp_all = torch.tensor([kp_local], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kp_all, op=dist.ReduceOp.SUM)
+    dt = float(t_all.item())
+    kp_total = float(kp_all.item())
+    value = kp_total * args.steps / dt / 1e6
+    ms_per_step = dt / args.steps * 1e3
+
+    # ---- roofline of the dominant kernel: per-stage device time, HIP events on the launch stream -------------------
+    ex2 = y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=F)
+    ex2.set_profiling(True)
+    mt.set_profiling(True)
+    for _ in range(5):
+        ex2.extract_batch(imgs)
+    for _ in range(5):
+        mt.match_consecutive_device(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, F, W, H, 15.0, sf, d_assigned.data_ptr(),
+                                    d_counts.data_ptr())
+        mt.synchronize()
+    mt.match_consecutive_device(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, F, W, H, 15.0, sf, d_assigned.data_ptr(), d_counts.data_ptr())
+    mt.synchronize()
+    stages = dict(ex2.stage_times())
+    stages.update(mt.stage_times())
+    mt.set_profiling(False)
+    dom = max(stages, key=stages.get)
+    A_frame = algorithmic_bytes_extract(W, H, NFEAT)
+    n_kp_frame = kp_local / F
+    pyr_pad = A_frame - W * H - NFEAT * 60
+    # algorithmic bytes of each kernel per frame (DESIGN.md "Kernels"): what it must read + write once
+    kbytes = {
+        "pyramid": W * H + pyr_pad,                       # read image, write padded pyramid
+        "fast_cells": pyr_pad,                            # read every pyramid pixel once (candidates are << 1 %)
+        "quadtree": 8 * 4200 * 4,                         # read ~4.2 k packed candidates per level (measured average), write keypoints
+        "blur": 2 * (A_frame - W * H - NFEAT * 60),       # read pyramid, write blurred levels
+        "orient_describe": int(n_kp_frame) * (60 + 2 * 1849),  # 43x43 patch of the level and of the blurred level + 60 B out
+        "grid_build": int(n_kp_frame) * (28 + 4),
+        "gather_distances": int(n_kp_frame) * (40 + 32 + 24 * 36),  # query + descriptor + ~24 candidates x (32 B descriptor + 4 B record)
+        "resolve": int(n_kp_frame) * 24 * 4,
+    }
+    t_dom = stages[dom] * 1e-3
+    achieved = kbytes.get(dom, A_frame) * F / t_dom if t_dom > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK, "traffic": None,
+                "pipeline_achieved_GBps": A_frame * F * args.steps / dt / 1e9, "pipeline_frac": A_frame * F * args.steps / dt / HBM_PEAK,
+                "stage_ms_per_batch": {k: round(v, 4) for k, v in stages.items()}}
+
+    out = {"metric": "ORB extract+match Mkeypoints/sec", "value": value, "unit": "Mkeypoints/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "TUM-fr1-size 640x480 mono stream, 1000 feat/frame, extract + consecutive-frame searchByProjection",
+                      "frames_per_step_per_gpu": F, "distinct_frames": len(distinct), "keypoints_per_frame": n_kp_frame,
+                      "matches_per_pair": matched_local / max(F - 1, 1), "parallelism": "frames sharded x%d" % world},
+           "roofline": roofline}
+
+    # ---- local BA (config 5) ------------------------------------------------------------------------------------------
+    if not args.no_ba:
+        prob = synth_ba_problem(100, 10000, 8, seed=1)
+        if world > 1:  # shard landmarks (and their edges) across ranks; every rank holds all poses
+            keep_pts = np.arange(len(prob["points"])) % world == rank
+            remap = np.cumsum(keep_pts) - 1
+            ke = keep_pts[prob["edge_point"]]
+            sub = dict(prob)
+            sub["points"] = prob["points"][keep_pts]
+            sub["edge_pose"] = prob["edge_pose"][ke]
+            sub["edge_point"] = remap[prob["edge_point"][ke]].astype(np.int32)
+            sub["meas"], sub["info"] = prob["meas"][ke], prob["info"][ke]
+            prob = sub
+            comm = torch.zeros(600 * 608 + 4096, dtype=torch.float64, device=dev)
+
+            def allreduce(user, d_buf, count, op):
+                try:
+                    dist.all_reduce(comm[:count], op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+                    torch.cuda.synchronize()
+                    return 0
+                except Exception:  # noqa: BLE001
+                    return 1
+            kw = dict(allreduce=allreduce, comm_tensor_ptr=comm.data_ptr(), comm_doubles=comm.numel(), rank=rank, world=world)
+        else:
+            kw = {}
+        opt = y.Optimizer.default_options(device=local_rank)
+        y.Optimizer.local_bundle_adjust(prob, opt, **kw)  # warm-up (allocations, code objects)
+        barrier()
+        t0 = time.perf_counter()
+        reps = 3
+        trials = 0
+        for _ in range(reps):
+            r = y.Optimizer.local_bundle_adjust(prob, opt, **kw)
+            trials += r["trials"]
+        barrier()
+        tb = time.perf_counter() - t0
+        tb_all = torch.tensor([tb], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tb_all, op=dist.ReduceOp.MAX)
+        tb = float(tb_all.item())
+        flops_schur = 89.9e6  # Schur part of one LM trial at C5 / 8 obs
+        ms = r["ms"]
+        out["ba"] = {"metric": "local-BA LM iterations/sec (100 KF x 10k points, 8 obs/point)", "value": trials / tb, "unit": "it/s",
+                     "lm_trials_per_solve": r["trials"], "ms_per_solve": tb / reps * 1e3, "final_chi2": float(r["log"][-1, 0]),
+                     "device_ms_per_solve": {k: round(float(v), 3) for k, v in ms.items()},
+                     "schur_fp64_frac": (flops_schur * r["trials"] / (ms["schur"] * 1e-3) / FP64_VEC_PEAK) if ms["schur"] > 0 else None,
+                     "scaling": "strong (landmarks sharded, all-reduce of the reduced camera system)" if world > 1 else "single GPU"}
+
+    # ---- CPU baseline: the oracle (port of the reference algorithm), one thread, bounded sample -------------------------
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle.orb_oracle import FrameOracle, OrbExtractorOracle, QUERY_DTYPE, ba_solve
+        oex = OrbExtractorOracle(NFEAT, 1.2, 8, 20, 7)
+        ncpu = min(args.cpu_frames, F)
+        tc = time.perf_counter()
+        prev = None
+        nk = 0
+        for i in range(ncpu):
+            k, d = oex.extract(imgs[i])
+            nk += len(k)
+            if prev is not None:
+                pk, pd = prev
+                q = np.zeros(len(pk), QUERY_DTYPE)
+                q["u"], q["v"] = pk["x"], pk["y"]
+                q["r"] = (np.float32(15.0) * sf[pk["octave"]]).astype(np.float32)
+                q["min_level"], q["max_level"] = pk["octave"] - 1, pk["octave"] + 1
+                q["angle"], q["level"], q["flags"] = pk["angle"], pk["octave"], 3
+                FrameOracle(k, d, (0.0, float(W), 0.0, float(H))).search_by_projection(1, q, pd, 0.9, True)
+            prev = (k, d)
+        tc = time.perf_counter() - tc
+        out["cpu_baseline"] = {"value": nk / tc / 1e6, "unit": "Mkeypoints/s", "cores": 1, "kind": "port",
+                               "sample": "%d of the same 640x480 frames, extract + consecutive match, oracle (C++ -O2), 1 thread" % ncpu}
+        if not args.no_ba:
+            pb = synth_ba_problem(100, 10000, 8, seed=1)
+            tcb = time.perf_counter()
+            rb = ba_solve(pb)
+            tcb = time.perf_counter() - tcb
+            out["ba"]["cpu_baseline"] = {"value": rb["trials"] / tcb, "unit": "it/s", "cores": 1, "kind": "port",
+                                         "sample": "one full localBundleAdjust schedule (%d LM trials) on the same problem" % rb["trials"]}
+            out["ba"]["vs_cpu"] = out["ba"]["value"] / out["ba"]["cpu_baseline"]["value"]
+        out["vs_cpu"] = value / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
