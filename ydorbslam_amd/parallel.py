@@ -1,0 +1,50 @@
+"""Multi-GPU host logic (one process per GPU, torch.distributed over RCCL): how the hot path shards.
+
+* extract + match: frames are independent units -> contiguous chunks per rank, no collective for extraction; the frame
+  pair that straddles two ranks needs one exchange: an all-gather of each rank's LAST frame record
+  (keypoints 28 B + descriptors 32 B per keypoint + count), after which rank r matches (last frame of rank r-1) -> (its frame 0).
+* local BA: landmarks (and their edges) shard across ranks, every rank holds all poses; per LM trial one all-reduce(sum)
+  of the reduced camera system (+ small reductions of chi2 / scale), see ydorbslam_amd/csrc/ba_solver.hip.
+Nothing here computes on the hot path; it only slices inputs and packs records.
+"""
+import numpy as np
+
+
+def frame_shard(n_frames, rank, world):
+    """[begin, end) of the frames rank owns (contiguous chunks keep consecutive-frame pairs local)."""
+    base, rem = divmod(n_frames, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def boundary_record_bytes(cap):
+    return cap * (28 + 32) + 4
+
+
+def pack_boundary(kps_bytes, desc, n, cap):
+    """kps_bytes: uint8[cap*28], desc: uint8[cap,32], n: int -> uint8 record."""
+    rec = np.zeros(boundary_record_bytes(cap), np.uint8)
+    rec[:cap * 28] = np.asarray(kps_bytes, np.uint8).reshape(-1)[:cap * 28]
+    rec[cap * 28:cap * 60] = np.asarray(desc, np.uint8).reshape(-1)[:cap * 32]
+    rec[cap * 60:] = np.array([n], np.int32).view(np.uint8)
+    return rec
+
+
+def unpack_boundary(rec, cap):
+    rec = np.asarray(rec, np.uint8)
+    return rec[:cap * 28].copy(), rec[cap * 28:cap * 60].reshape(cap, 32).copy(), int(rec[cap * 60:].view(np.int32)[0])
+
+
+def shard_ba_problem(prob, rank, world):
+    """Landmark l belongs to rank l % world; its edges follow it; poses are replicated."""
+    keep = np.arange(len(prob["points"])) % world == rank
+    remap = np.cumsum(keep) - 1
+    ke = keep[prob["edge_point"]]
+    sub = dict(prob)
+    sub["points"] = prob["points"][keep]
+    sub["edge_pose"] = prob["edge_pose"][ke]
+    sub["edge_point"] = remap[prob["edge_point"][ke]].astype(np.int32)
+    sub["meas"], sub["info"] = prob["meas"][ke], prob["info"][ke]
+    if "truth_points" in prob:
+        sub["truth_points"] = prob["truth_points"][keep]
+    return sub, keep, ke
