@@ -1,0 +1,138 @@
+// Drop-in adapter for YDORBSLAM::Optimizer::localBundleAdjust (reference src/optimizer.hpp:34, src/optimizer.cpp:138-352)
+// on top of the ydorb C ABI.  Template over the reference's KeyFrame / MapPoint / Map types: the body of
+//   void Optimizer::localBundleAdjust(std::shared_ptr<KeyFrame> kf, std::shared_ptr<Map> map, bool& stop)
+// becomes  ydorb::adapter::localBundleAdjust(kf, map, &stop == nullptr ? nullptr : &stop);
+// The host keeps the covisibility walk (:140-173), the float->double conversions of Converter (converter.cpp:12-19) and the
+// write-back under Map::m_mutex_updateMap (:336-351); residuals, Jacobians, Huber, Schur, Cholesky, LM run on the GPU.
+#ifndef YDORB_ADAPTER_OPTIMIZER_HPP
+#define YDORB_ADAPTER_OPTIMIZER_HPP
+
+#include <list>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include <Eigen/Core>
+#include <Eigen/Geometry>
+#include <opencv2/core.hpp>
+
+#include "c_api.h"
+
+namespace ydorb {
+namespace adapter {
+
+// Converter::transform_cvMat_SE3Quat (converter.cpp:12-19): float 4x4 -> (t, unit quaternion) in double
+inline void poseToSE3Quat(const cv::Mat& T, double* p7) {
+  Eigen::Matrix3d R;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) R(i, j) = T.at<float>(i, j);
+  Eigen::Quaterniond q(R);
+  if (q.w() < 0) q.coeffs() *= -1;
+  q.normalize();
+  p7[0] = T.at<float>(0, 3); p7[1] = T.at<float>(1, 3); p7[2] = T.at<float>(2, 3);
+  p7[3] = q.x(); p7[4] = q.y(); p7[5] = q.z(); p7[6] = q.w();
+}
+// Converter::transform_SE3_cvMat (converter.cpp:20-38): back to a float 4x4
+inline cv::Mat se3QuatToPose(const double* p7) {
+  const Eigen::Matrix3d R = Eigen::Quaterniond(p7[6], p7[3], p7[4], p7[5]).toRotationMatrix();
+  cv::Mat T = cv::Mat::eye(4, 4, CV_32F);
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) T.at<float>(i, j) = (float)R(i, j);
+    T.at<float>(i, 3) = (float)p7[i];
+  }
+  return T;
+}
+
+template <class KeyFramePtr, class MapPtr, class FrameT>
+void localBundleAdjustImpl(KeyFramePtr kf0, MapPtr map, const volatile bool* stop) {
+  typedef decltype(kf0->getMatchedMapPointsVec()) MapPointVec;
+  typedef typename MapPointVec::value_type MapPointPtr;
+  const long int tag = kf0->m_int_keyFrameID;
+  // local keyframes = current + its covisible ones; local points = what they see; fixed keyframes = other observers (:140-173)
+  std::list<KeyFramePtr> localKFs{kf0};
+  kf0->m_int_localBAForKeyFrameID = tag;
+  for (const KeyFramePtr& c : kf0->getOrderedConnectedKeyFrames()) {
+    c->m_int_localBAForKeyFrameID = tag;
+    if (!c->isBad()) localKFs.push_back(c);
+  }
+  std::list<MapPointPtr> localMPs;
+  for (const KeyFramePtr& k : localKFs)
+    for (const MapPointPtr& mp : k->getMatchedMapPointsVec())
+      if (mp && !mp->isBad() && mp->m_int_localBAForKeyFrameID != tag) { localMPs.push_back(mp); mp->m_int_localBAForKeyFrameID = tag; }
+  std::list<KeyFramePtr> fixedKFs;
+  for (const MapPointPtr& mp : localMPs)
+    for (const auto& ob : mp->getObservations())
+      if (ob.first->m_int_localBAForKeyFrameID != tag && ob.first->m_int_fixedBAForKeyFrameID != tag) {
+        ob.first->m_int_fixedBAForKeyFrameID = tag;
+        if (!ob.first->isBad()) fixedKFs.push_back(ob.first);
+      }
+  // flat graph (:185-283)
+  std::vector<KeyFramePtr> poseKF;
+  std::map<long int, int> poseIndex;
+  std::vector<double> poses;
+  std::vector<uint8_t> fixed;
+  long int maxKFid = 0;
+  auto addPose = [&](const KeyFramePtr& k, bool fix) {
+    poseIndex[k->m_int_keyFrameID] = (int)poseKF.size();
+    poseKF.push_back(k);
+    poses.resize(poses.size() + 7);
+    poseToSE3Quat(k->getCameraPoseByTransform_c2w(), &poses[poses.size() - 7]);
+    fixed.push_back(fix ? 1 : 0);
+    if (k->m_int_keyFrameID > maxKFid) maxKFid = k->m_int_keyFrameID;
+  };
+  for (const KeyFramePtr& k : localKFs) if (!k->isBad()) addPose(k, k->m_int_keyFrameID == 0);
+  const size_t nLocal = poseKF.size();
+  for (const KeyFramePtr& k : fixedKFs) addPose(k, true);
+  std::vector<MapPointPtr> pointMP(localMPs.begin(), localMPs.end());
+  std::vector<double> points(3 * pointMP.size());
+  std::vector<int32_t> ePose, ePoint;
+  std::vector<double> eMeas, eInfo;
+  std::vector<KeyFramePtr> edgeKF;
+  for (size_t p = 0; p < pointMP.size(); p++) {
+    const cv::Mat X = pointMP[p]->getPosInWorld();
+    for (int d = 0; d < 3; d++) points[3 * p + d] = X.at<float>(d);
+    for (const auto& ob : pointMP[p]->getObservations()) {
+      if (ob.first->isBad() || ob.first->m_int_keyFrameID > maxKFid) continue;
+      const auto it = poseIndex.find(ob.first->m_int_keyFrameID);
+      if (it == poseIndex.end()) continue;
+      const cv::KeyPoint& kp = ob.first->m_v_keyPoints[ob.second];
+      const float ur = ob.first->m_v_rightXcords[ob.second];
+      ePose.push_back(it->second); ePoint.push_back((int32_t)p);
+      eMeas.push_back(kp.pt.x); eMeas.push_back(kp.pt.y); eMeas.push_back(ur < 0 ? -1.0 : (double)ur);
+      eInfo.push_back(ob.first->m_v_invScaleFactorSquares[kp.octave]);
+      edgeKF.push_back(ob.first);
+    }
+  }
+  if (stop && *stop) return;  // :284-286
+  YdBaProblem P{};
+  P.n_poses = (int32_t)poseKF.size(); P.n_points = (int32_t)pointMP.size(); P.n_edges = (int32_t)ePose.size();
+  P.poses = poses.data(); P.pose_fixed = fixed.data(); P.points = points.data();
+  P.edge_pose = ePose.data(); P.edge_point = ePoint.data(); P.edge_meas = eMeas.data(); P.edge_inv_sigma2 = eInfo.data();
+  P.fx = FrameT::m_flt_fx; P.fy = FrameT::m_flt_fy; P.cx = FrameT::m_flt_cx; P.cy = FrameT::m_flt_cy; P.bf = FrameT::m_flt_baseLineTimesFx;
+  P.stop = reinterpret_cast<const volatile uint8_t*>(stop);
+  std::vector<uint8_t> outlier(ePose.size() + 1, 0);
+  YdBaResult res{};
+  res.edge_outlier = outlier.data();
+  if (ydorb_ba_solve(&P, nullptr, &res) != YDORB_OK) throw std::runtime_error(std::string("ydorb: ") + ydorb_last_error());
+  // write-back (:336-351)
+  std::unique_lock<std::mutex> lock(map->m_mutex_updateMap);
+  for (size_t e = 0; e < ePose.size(); e++)
+    if (outlier[e] && !pointMP[ePoint[e]]->isBad()) {
+      edgeKF[e]->eraseMatchedMapPoint(pointMP[ePoint[e]]);
+      pointMP[ePoint[e]]->eraseObservation(edgeKF[e]);
+    }
+  for (size_t k = 0; k < nLocal; k++) poseKF[k]->setCameraPoseByTransform_c2w(se3QuatToPose(&poses[7 * k]));
+  for (size_t p = 0; p < pointMP.size(); p++) {
+    cv::Mat X(3, 1, CV_32F);
+    for (int d = 0; d < 3; d++) X.at<float>(d) = (float)points[3 * p + d];
+    pointMP[p]->setPosInWorld(X);
+    pointMP[p]->updateNormalAndDepth();
+  }
+}
+
+}  // namespace adapter
+}  // namespace ydorb
+#endif

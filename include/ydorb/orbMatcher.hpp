@@ -1,0 +1,236 @@
+// Drop-in adapter for YDORBSLAM::OrbMatcher's search-by-projection / search-by-BoW entry points
+// (reference src/orbMatcher.hpp:32-46, src/orbMatcher.cpp:24-239,303-462) on top of the ydorb C ABI.
+//
+// The adapter is a set of templates over the reference's own Frame / KeyFrame / MapPoint types (included by the
+// translation unit that instantiates them), so Tracking / LocalMapping / LoopClosing keep calling
+// OrbMatcher::searchBy...() unchanged: each reference method body becomes a one-line forward, e.g.
+//   int OrbMatcher::searchByProjectionInLastAndCurrentFrame(Frame& c, Frame& l, const float th)
+//   { return ydorb::adapter::searchByProjectionInLastAndCurrentFrame(ydorb::adapter::matcher(), c, l, th, m_b_isToCheckOrientation); }
+// What stays on the host is exactly the float geometry the reference computes per map point with cv::Mat (projection,
+// radius, level window); the candidate search, Hamming distances, best/second-best, greedy assignment and the rotation
+// histogram run on the GPU.  searchForTriangulation / searchBySim3 / searchByProjectionInSim / fuse* are the "next" rows
+// of SURVEY.md 8(f) and keep the reference's CPU bodies.
+#ifndef YDORB_ADAPTER_ORBMATCHER_HPP
+#define YDORB_ADAPTER_ORBMATCHER_HPP
+
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include <opencv2/core.hpp>
+
+#include "c_api.h"
+
+namespace ydorb {
+namespace adapter {
+
+inline ydorb_matcher_t* matcher(int device = 0) {  // one matcher per calling thread (tracking / local mapping / loop closing)
+  thread_local ydorb_matcher_t* m = nullptr;
+  if (!m && ydorb_matcher_create(device, &m) != YDORB_OK) throw std::runtime_error(std::string("ydorb: ") + ydorb_last_error());
+  return m;
+}
+
+// static int OrbMatcher::computeDescriptorsDistance(const cv::Mat&, const cv::Mat&), src/orbMatcher.cpp:11-23
+inline int computeDescriptorsDistance(const cv::Mat& a, const cv::Mat& b) { return ydorb_descriptor_distance(a.ptr<uint8_t>(), b.ptr<uint8_t>()); }
+
+template <class FrameT>
+inline YdFrameView frameView(const FrameT& f) {
+  static_assert(sizeof(cv::KeyPoint) == sizeof(YdKeyPoint), "cv::KeyPoint layout");
+  YdFrameView v;
+  v.kps = reinterpret_cast<const YdKeyPoint*>(f.m_v_keyPoints.data());
+  v.desc = f.m_cvMat_descriptors.template ptr<uint8_t>();
+  v.right_x = f.m_v_rightXcords.empty() ? nullptr : f.m_v_rightXcords.data();
+  v.n = (int)f.m_v_keyPoints.size();
+  v.min_x = FrameT::m_flt_minX; v.max_x = FrameT::m_flt_maxX; v.min_y = FrameT::m_flt_minY; v.max_y = FrameT::m_flt_maxY;
+  return v;
+}
+
+// taken[idx] / assigned[idx] <-> frame.m_v_sptrMapPoints[idx]
+template <class FrameT>
+inline void takenMask(const FrameT& f, bool anyPoint, std::vector<uint8_t>& taken) {
+  taken.assign(f.m_v_sptrMapPoints.size(), 0);
+  for (size_t i = 0; i < taken.size(); i++)
+    if (f.m_v_sptrMapPoints[i] && (anyPoint || f.m_v_sptrMapPoints[i]->getObservationsNum() > 0)) taken[i] = 1;
+}
+
+// searchByProjectionInFrameAndMapPoint, src/orbMatcher.cpp:24-64
+template <class FrameT, class MapPointPtr>
+int searchByProjectionInFrameAndMapPoint(ydorb_matcher_t* m, FrameT& frame, const std::vector<MapPointPtr>& mps, float thd, float ratio) {
+  const int nq = (int)mps.size();
+  std::vector<YdQuery> q(nq);
+  cv::Mat qd(std::max(nq, 1), 32, CV_8U);
+  for (int i = 0; i < nq; i++) {
+    YdQuery& Q = q[i];
+    std::memset(&Q, 0, sizeof(Q));
+    const MapPointPtr& mp = mps[i];
+    if (!(mp->m_b_isTrackInView && !mp->isBad())) continue;
+    const int lvl = mp->m_int_trackScaleLevel;
+    const float radius = thd * (mp->m_flt_trackViewCos > 0.998 ? 2.5f : 4.0f);  // getRadiusByViewCos, :820-826
+    Q.u = mp->m_flt_trackProjX; Q.v = mp->m_flt_trackProjY;
+    Q.r = radius * frame.m_v_scaleFactors[lvl];
+    Q.min_level = lvl - 1; Q.max_level = lvl;
+    Q.ur = mp->m_flt_trackProjRightX; Q.rs = radius * frame.m_v_scaleFactors[lvl];
+    Q.level = lvl;
+    Q.flags = 1 | (mp->getObservationsNum() > 0 ? 2 : 0);
+    mp->getDescriptor().copyTo(qd.row(i));
+  }
+  std::vector<uint8_t> taken;
+  takenMask(frame, false, taken);
+  std::vector<int32_t> assigned(taken.size(), -1);
+  int32_t n = 0;
+  YdFrameView fv = frameView(frame);
+  if (ydorb_search_by_projection(m, YDORB_SEARCH_FRAME_MAPPOINT, &fv, q.data(), qd.data, nq, ratio, 0, 0, taken.data(), assigned.data(), &n) != YDORB_OK)
+    throw std::runtime_error(std::string("ydorb: ") + ydorb_last_error());
+  for (size_t i = 0; i < assigned.size(); i++)
+    if (assigned[i] >= 0) frame.m_v_sptrMapPoints[i] = mps[assigned[i]];
+  return n;
+}
+
+// searchByProjectionInLastAndCurrentFrame, src/orbMatcher.cpp:65-155
+template <class FrameT>
+int searchByProjectionInLastAndCurrentFrame(ydorb_matcher_t* m, FrameT& cur, FrameT& last, float thd, bool checkOri) {
+  const cv::Mat Rcw = cur.m_cvMat_T_c2w.rowRange(0, 3).colRange(0, 3), tcw = cur.m_cvMat_T_c2w.rowRange(0, 3).col(3);
+  const cv::Mat twc = -Rcw.t() * tcw;
+  const cv::Mat Rlw = last.m_cvMat_T_c2w.rowRange(0, 3).colRange(0, 3), tlw = last.m_cvMat_T_c2w.rowRange(0, 3).col(3);
+  const cv::Mat tlc = Rlw * twc + tlw;
+  const bool fwd = tlc.at<float>(2) > FrameT::m_flt_baseLine, bwd = -tlc.at<float>(2) > FrameT::m_flt_baseLine;
+  const int nq = (int)last.m_v_sptrMapPoints.size();
+  std::vector<YdQuery> q(nq);
+  cv::Mat qd(std::max(nq, 1), 32, CV_8U);
+  for (int i = 0; i < nq; i++) {
+    YdQuery& Q = q[i];
+    std::memset(&Q, 0, sizeof(Q));
+    auto& mp = last.m_v_sptrMapPoints[i];
+    if (!(mp && !last.m_v_isOutliers[i])) continue;
+    const cv::Mat Xc = Rcw * mp->getPosInWorld() + tcw;
+    const float x = Xc.at<float>(0), y = Xc.at<float>(1), z = Xc.at<float>(2);
+    const float u = FrameT::m_flt_fx * x / z + FrameT::m_flt_cx, v = FrameT::m_flt_fy * y / z + FrameT::m_flt_cy;
+    if (!(z >= 0.0 && cur.isInImage(u, v))) continue;
+    const int oct = last.m_v_keyPoints[i].octave;
+    Q.u = u; Q.v = v; Q.r = thd * cur.m_v_scaleFactors[oct];
+    if (fwd) { Q.min_level = oct; Q.max_level = -1; }
+    else if (bwd) { Q.min_level = 0; Q.max_level = oct; }
+    else { Q.min_level = oct - 1; Q.max_level = oct + 1; }
+    Q.ur = u - FrameT::m_flt_baseLineTimesFx / z; Q.rs = Q.r;
+    Q.angle = last.m_v_keyPoints[i].angle; Q.level = oct;
+    Q.flags = 1 | (mp->getObservationsNum() > 0 ? 2 : 0);
+    mp->getDescriptor().copyTo(qd.row(i));
+  }
+  std::vector<uint8_t> taken;
+  takenMask(cur, false, taken);
+  std::vector<int32_t> assigned(taken.size(), -2);  // -2: untouched, -1: cleared by the rotation-histogram cull
+  int32_t n = 0;
+  YdFrameView fv = frameView(cur);
+  if (ydorb_search_by_projection(m, YDORB_SEARCH_LAST_CURRENT, &fv, q.data(), qd.data, nq, 0.f, 0, checkOri ? 1 : 0, taken.data(), assigned.data(), &n) != YDORB_OK)
+    throw std::runtime_error(std::string("ydorb: ") + ydorb_last_error());
+  for (size_t i = 0; i < assigned.size(); i++) {
+    if (assigned[i] >= 0) cur.m_v_sptrMapPoints[i] = last.m_v_sptrMapPoints[assigned[i]];
+    else if (assigned[i] == -1) cur.m_v_sptrMapPoints[i].reset();
+  }
+  return n;
+}
+
+// searchByProjectionInKeyFrameAndCurrentFrame, src/orbMatcher.cpp:156-239 (camera centre -R*t as written at :160)
+template <class FrameT, class KeyFramePtr, class MapPointSet>
+int searchByProjectionInKeyFrameAndCurrentFrame(ydorb_matcher_t* m, FrameT& cur, KeyFramePtr kf, const MapPointSet& found, float thd, int orbDist,
+                                                bool checkOri) {
+  const cv::Mat Rcw = cur.m_cvMat_T_c2w.rowRange(0, 3).colRange(0, 3), tcw = cur.m_cvMat_T_c2w.rowRange(0, 3).col(3);
+  const cv::Mat Ow = -Rcw * tcw;
+  const auto mps = kf->getMatchedMapPointsVec();
+  const int nq = (int)mps.size();
+  std::vector<YdQuery> q(nq);
+  cv::Mat qd(std::max(nq, 1), 32, CV_8U);
+  for (int i = 0; i < nq; i++) {
+    YdQuery& Q = q[i];
+    std::memset(&Q, 0, sizeof(Q));
+    auto& mp = mps[i];
+    if (!(mp && !mp->isBad() && !found.count(mp))) continue;
+    const cv::Mat Xw = mp->getPosInWorld(), Xc = Rcw * Xw + tcw;
+    const float x = Xc.at<float>(0), y = Xc.at<float>(1), z = Xc.at<float>(2);
+    const float u = FrameT::m_flt_fx * x / z + FrameT::m_flt_cx, v = FrameT::m_flt_fy * y / z + FrameT::m_flt_cy;
+    const float dist3D = (float)cv::norm(Xw - Ow);
+    const int lvl = mp->predictScaleLevel(dist3D, cur);
+    if (!(z >= 0.0 && cur.isInImage(u, v) && dist3D >= mp->getMinDistanceInvariance() && dist3D <= mp->getMaxDistanceInvariance())) continue;
+    Q.u = u; Q.v = v; Q.r = thd * cur.m_v_scaleFactors[lvl];
+    Q.min_level = lvl - 1; Q.max_level = lvl + 1;
+    Q.angle = kf->m_v_keyPoints[i].angle; Q.level = lvl; Q.flags = 3;
+    mp->getDescriptor().copyTo(qd.row(i));
+  }
+  std::vector<uint8_t> taken;
+  takenMask(cur, true, taken);
+  std::vector<int32_t> assigned(taken.size(), -2);
+  int32_t n = 0;
+  YdFrameView fv = frameView(cur);
+  if (ydorb_search_by_projection(m, YDORB_SEARCH_KEYFRAME_CURRENT, &fv, q.data(), qd.data, nq, 0.f, orbDist, checkOri ? 1 : 0, taken.data(), assigned.data(), &n) != YDORB_OK)
+    throw std::runtime_error(std::string("ydorb: ") + ydorb_last_error());
+  for (size_t i = 0; i < assigned.size(); i++) {
+    if (assigned[i] >= 0) cur.m_v_sptrMapPoints[i] = mps[assigned[i]];
+    else if (assigned[i] == -1) cur.m_v_sptrMapPoints[i].reset();
+  }
+  return n;
+}
+
+// DBoW3::FeatureVector (std::map<node, std::vector<unsigned>>) -> CSR
+template <class FeatureVectorT>
+struct BowCsr {
+  std::vector<uint32_t> ids;
+  std::vector<int32_t> start, feat;
+  explicit BowCsr(const FeatureVectorT& fv) {
+    start.push_back(0);
+    for (const auto& kv : fv) {
+      ids.push_back(kv.first);
+      for (auto f : kv.second) feat.push_back((int32_t)f);
+      start.push_back((int32_t)feat.size());
+    }
+  }
+  YdFeatureVector c() const { return YdFeatureVector{ids.data(), start.data(), feat.data(), (int32_t)ids.size()}; }
+};
+
+// searchByBowInKeyFrameAndFrame, src/orbMatcher.cpp:303-379
+template <class KeyFramePtr, class FrameT, class MapPointPtr>
+int searchByBowInKeyFrameAndFrame(ydorb_matcher_t* m, KeyFramePtr kf, FrameT& frame, std::vector<MapPointPtr>& matched, float ratio, bool checkOri) {
+  const auto mps = kf->getMatchedMapPointsVec();
+  matched.assign(frame.m_int_keyPointsNum, MapPointPtr());
+  std::vector<uint8_t> valid(mps.size());
+  for (size_t i = 0; i < mps.size(); i++) valid[i] = mps[i] && !mps[i]->isBad();
+  BowCsr<decltype(kf->m_bow_keyPointsVec)> a(kf->m_bow_keyPointsVec);
+  BowCsr<decltype(frame.m_bow_keyPointsVec)> b(frame.m_bow_keyPointsVec);
+  YdBowSide A{reinterpret_cast<const YdKeyPoint*>(kf->m_v_keyPoints.data()), kf->m_cvMat_descriptors.template ptr<uint8_t>(), valid.data(), (int32_t)mps.size(), a.c()};
+  YdBowSide B{reinterpret_cast<const YdKeyPoint*>(frame.m_v_keyPoints.data()), frame.m_cvMat_descriptors.template ptr<uint8_t>(), nullptr,
+              (int32_t)frame.m_v_keyPoints.size(), b.c()};
+  std::vector<int32_t> out(B.n, -1);
+  int32_t n = 0;
+  if (ydorb_search_by_bow(m, YDORB_SEARCH_BOW_KEYFRAME_FRAME, &A, &B, ratio, checkOri ? 1 : 0, out.data(), &n) != YDORB_OK)
+    throw std::runtime_error(std::string("ydorb: ") + ydorb_last_error());
+  for (size_t i = 0; i < out.size(); i++)
+    if (out[i] >= 0) matched[i] = mps[out[i]];
+  return n;
+}
+
+// searchByBowInTwoKeyFrames, src/orbMatcher.cpp:380-462
+template <class KeyFramePtr, class MapPointPtr>
+int searchByBowInTwoKeyFrames(ydorb_matcher_t* m, KeyFramePtr kf1, KeyFramePtr kf2, std::vector<MapPointPtr>& matched, float ratio, bool checkOri) {
+  const auto mp1 = kf1->getMatchedMapPointsVec(), mp2 = kf2->getMatchedMapPointsVec();
+  matched.assign(mp1.size(), MapPointPtr());
+  std::vector<uint8_t> v1(mp1.size()), v2(mp2.size());
+  for (size_t i = 0; i < mp1.size(); i++) v1[i] = mp1[i] && !mp1[i]->isBad();
+  for (size_t i = 0; i < mp2.size(); i++) v2[i] = mp2[i] && !mp2[i]->isBad();
+  BowCsr<decltype(kf1->m_bow_keyPointsVec)> a(kf1->m_bow_keyPointsVec), b(kf2->m_bow_keyPointsVec);
+  YdBowSide A{reinterpret_cast<const YdKeyPoint*>(kf1->m_v_keyPoints.data()), kf1->m_cvMat_descriptors.template ptr<uint8_t>(), v1.data(), (int32_t)mp1.size(), a.c()};
+  YdBowSide B{reinterpret_cast<const YdKeyPoint*>(kf2->m_v_keyPoints.data()), kf2->m_cvMat_descriptors.template ptr<uint8_t>(), v2.data(), (int32_t)mp2.size(), b.c()};
+  std::vector<int32_t> out(A.n, -1);
+  int32_t n = 0;
+  if (ydorb_search_by_bow(m, YDORB_SEARCH_BOW_TWO_KEYFRAMES, &A, &B, ratio, checkOri ? 1 : 0, out.data(), &n) != YDORB_OK)
+    throw std::runtime_error(std::string("ydorb: ") + ydorb_last_error());
+  for (size_t i = 0; i < out.size(); i++)
+    if (out[i] >= 0) matched[i] = mp2[out[i]];
+  return n;
+}
+
+}  // namespace adapter
+}  // namespace ydorb
+#endif
