@@ -28,7 +28,7 @@ extern "C" int qt_cpu_distribute(const uint32_t* cands, int n, int rootX1, int r
   QtShared S{{g0.data(), g1.data()}, {c0.data(), c1.data()}, {b0.data(), b1.data()}, cc.data(), ci.data()};
   std::vector<uint32_t> ca(cands, cands + n), cb(n), keys(n);
   std::vector<uint16_t> na(n), nb(n);
-  QtGlobal G{{ca.data(), cb.data()}, {na.data(), nb.data()}, keys.data()};
+  QtGlobal G{{ca.data(), cb.data()}, {na.data(), nb.data()}, keys.data(), nullptr, 0};
   CpuCtx cx;
   return qt_distribute(cx, S, G, n, rootX1, rootY1, quota, nodeCap, out);
 }

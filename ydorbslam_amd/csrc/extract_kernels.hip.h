@@ -286,11 +286,11 @@ struct QtGpuCtx {
   __device__ void lds_add_u64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
 };
 
-// dynamic LDS layout: [geom0|geom1|cnt0|cnt1|base0|base1|cc|childIdx] for nodeCap nodes, then cellBase[maxCells+1]
+// dynamic LDS layout: [cc|geom0|geom1|childIdx|cnt0|cnt1|base0|base1] for nodeCap nodes, sort keys[ldsKeyCap], cellBase[maxCells+1]
 __global__ __launch_bounds__(kQtThreads) void k_quadtree(PlanDev P, const uint32_t* __restrict__ cellCount,
                                                          const uint32_t* __restrict__ cellCand, uint32_t* __restrict__ qtCand,
                                                          uint16_t* __restrict__ qtNode, uint32_t* __restrict__ qtKeys,
-                                                         size_t qtFrameStride, int nodeCap, uint32_t* __restrict__ lvlKp,
+                                                         size_t qtFrameStride, int nodeCap, int ldsKeyCap, uint32_t* __restrict__ lvlKp,
                                                          int* __restrict__ lvlCount, int* __restrict__ status) {
   extern __shared__ __align__(16) uint8_t smem[];
   __shared__ unsigned w32[kQtThreads / 64];
@@ -307,6 +307,7 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(PlanDev P, const uint32
   S.cnt[1] = reinterpret_cast<uint32_t*>(sp); sp += sizeof(uint32_t) * nodeCap;
   S.base[0] = reinterpret_cast<uint32_t*>(sp); sp += sizeof(uint32_t) * nodeCap;
   S.base[1] = reinterpret_cast<uint32_t*>(sp); sp += sizeof(uint32_t) * nodeCap;
+  uint32_t* ldsKeys = reinterpret_cast<uint32_t*>(sp); sp += sizeof(uint32_t) * ldsKeyCap;
   uint32_t* cellBase = reinterpret_cast<uint32_t*>(sp);
   QtGpuCtx cx{w32, w64};
 
@@ -330,6 +331,8 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(PlanDev P, const uint32
   G.node[0] = qtNode + 2 * so;
   G.node[1] = G.node[0] + cap;
   G.sortKeys = qtKeys + so;
+  G.ldsKeys = ldsKeys;
+  G.ldsKeyCap = ldsKeyCap;
   int nOut = 0;
   if (n > 65535u) {
     if (threadIdx.x == 0) atomicMax(status, 1);  // more candidates than the packed 16-bit counters allow
@@ -358,40 +361,49 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(PlanDev P, const uint32
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, size_t pyrFrameStride, uint8_t* __restrict__ blur,
                                               size_t blurFrameStride, PlanDev P) {
-  constexpr int TW = 64, TH = 16, SW = TW + 6, SH = TH + 6, SP = 72;
-  __shared__ uint8_t src[SH * SP];
-  __shared__ uint16_t hb[SH * TW];
+  constexpr int TW = 64, TH = 16, SH = TH + 6, SWW = 18;  // source tile: 22 rows x 18 dwords (72 B: cols x0-3 .. x0+68)
+  __shared__ uint32_t src[SH * SWW];
+  __shared__ __align__(8) uint16_t hb[SH * TW];
   const int level = blockIdx.y, f = blockIdx.z;
   const LevelDev L = P.lv[level];
   const int tilesX = (L.w + TW - 1) / TW, tilesY = (L.h + TH - 1) / TH;
   if ((int)blockIdx.x >= tilesX * tilesY) return;
   const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
   const int x0 = tx * TW, y0 = ty * TH;
-  const uint8_t* roi = pyr + (size_t)f * pyrFrameStride + L.padOff + (size_t)kPad * L.pitch + kPad;
-  for (int i = threadIdx.x; i < SH * SW; i += 256) {
-    const int r = i / SW, cc = i - r * SW;
-    const int gy = min(y0 + r - 3, L.h + kPad - 1), gx = min(x0 + cc - 3, L.w + kPad - 1);
-    src[r * SP + cc] = roi[(ptrdiff_t)gy * L.pitch + gx];
+  // padded-row coordinates: level x <-> x + 19, so the tile's first source column x0-3 sits at byte x0+16: dword aligned
+  // (pitch and padOff are multiples of 64), and the source loads are whole dwords.
+  const uint8_t* padded = pyr + (size_t)f * pyrFrameStride + L.padOff;
+  for (int i = threadIdx.x; i < SH * SWW; i += 256) {
+    const int r = i / SWW, wd = i - r * SWW;
+    const int prow = min(y0 + r + kPad - 3, L.h + 2 * kPad - 1), pcol = x0 + 16 + 4 * wd;
+    src[i] = pcol < L.pitch ? *reinterpret_cast<const uint32_t*>(padded + (size_t)prow * L.pitch + pcol) : 0u;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < SH * TW; i += 256) {
-    const int r = i / TW, cc = i - r * TW;
-    const uint8_t* s = &src[r * SP + cc];
-    hb[i] = (uint16_t)(18 * (s[0] + s[6]) + 34 * (s[1] + s[5]) + 48 * (s[2] + s[4]) + 56 * s[3]);
+  // horizontal pass: 4 outputs per thread from 3 dwords (bytes c4 .. c4+11 of the source row)
+  for (int i = threadIdx.x; i < SH * (TW / 4); i += 256) {
+    const int r = i >> 4, g = i & 15;
+    const uint32_t w0 = src[r * SWW + g], w1 = src[r * SWW + g + 1], w2 = src[r * SWW + g + 2];
+    int b[12];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { b[k] = (w0 >> (8 * k)) & 255; b[4 + k] = (w1 >> (8 * k)) & 255; b[8 + k] = (w2 >> (8 * k)) & 255; }
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] = 18 * (b[k] + b[k + 6]) + 34 * (b[k + 1] + b[k + 5]) + 48 * (b[k + 2] + b[k + 4]) + 56 * b[k + 3];
+    *reinterpret_cast<uint2*>(&hb[r * TW + g * 4]) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
   }
   __syncthreads();
   const int r = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
   const int gy = y0 + r;
-  if (gy < L.h) {
-    uint32_t out = 0;
+  if (gy < L.h && x0 + c4 < L.blurPitch) {
+    uint32_t acc[4] = {0, 0, 0, 0};
+    const uint32_t kw[7] = {18, 34, 48, 56, 48, 34, 18};
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-      const uint16_t* h = &hb[r * TW + c4 + b];
-      const uint32_t acc = 18u * (h[0] + h[6 * TW]) + 34u * (h[TW] + h[5 * TW]) + 48u * (h[2 * TW] + h[4 * TW]) + 56u * h[3 * TW];
-      out |= ((acc + 32768u) >> 16) << (8 * b);
+    for (int j = 0; j < 7; j++) {
+      const uint2 h = *reinterpret_cast<const uint2*>(&hb[(r + j) * TW + c4]);
+      acc[0] += kw[j] * (h.x & 0xFFFF); acc[1] += kw[j] * (h.x >> 16); acc[2] += kw[j] * (h.y & 0xFFFF); acc[3] += kw[j] * (h.y >> 16);
     }
-    uint8_t* dst = blur + (size_t)f * blurFrameStride + L.blurOff + (size_t)gy * L.blurPitch + x0 + c4;
-    if (x0 + c4 < L.blurPitch) *reinterpret_cast<uint32_t*>(dst) = out;
+    const uint32_t out = ((acc[0] + 32768u) >> 16) | (((acc[1] + 32768u) >> 16) << 8) | (((acc[2] + 32768u) >> 16) << 16) | (((acc[3] + 32768u) >> 16) << 24);
+    *reinterpret_cast<uint32_t*>(blur + (size_t)f * blurFrameStride + L.blurOff + (size_t)gy * L.blurPitch + x0 + c4) = out;
   }
 }
 

@@ -41,6 +41,8 @@ struct FrameDev {  // one target frame of a batched call
   float minX, minY, gridWInv, gridHInv;
   int* cellStart;       // [kGridCells + 1]
   int* cellIdx;         // [cap]
+  float4* sortedKp;     // [cap] (x, y, octave bits, index bits) in grid (CSR) order: a window column is one contiguous run
+  uint8_t* sortedDesc;  // [cap][32] descriptors in the same order
 };
 __device__ __forceinline__ int frame_n(const FrameDev& F) { return F.nPtr ? *F.nPtr : F.n; }
 
@@ -92,7 +94,13 @@ __global__ __launch_bounds__(256) void k_grid_build(const FrameDev* __restrict__
     if (cell < 0) continue;
     int rank = 0;
     for (int j = 0; j < i; j++) rank += cellOf[j] == cell;
-    F.cellIdx[hist[cell] + rank] = i;
+    const int pos = hist[cell] + rank;
+    F.cellIdx[pos] = i;
+    const KeyPointDev kp = F.kps[i];
+    F.sortedKp[pos] = make_float4(kp.x, kp.y, __int_as_float(kp.octave), __int_as_float(i));
+    const uint4* d = reinterpret_cast<const uint4*>(F.desc + (size_t)i * 32);
+    uint4* o = reinterpret_cast<uint4*>(F.sortedDesc + (size_t)pos * 32);
+    o[0] = d[0]; o[1] = d[1];
   }
 }
 
@@ -127,9 +135,16 @@ __device__ __forceinline__ int call_nq(const CallDev& C) { return C.nqPtr ? *C.n
 // static part of the candidate test (level window, per-axis distance test, stereo consistency) and the
 // descriptor distance.  Records keep the reference's scan order (ix, iy, insertion).
 // ---------------------------------------------------------------------------------------------------
+// Pool layout per call: [maxQ fixed slots of kSlot records][overflow region with one atomic head per call].  A query whose
+// window holds <= kSlot keypoints (the common case) writes into its own slot without any atomic; only larger windows
+// allocate from the overflow region.  (A single global head serialised at ~90 returning atomics/us — MI355X_MICROARCH
+// "dequeue" — and was the whole cost of the first version of this kernel.)
+// The grid cell of (ix, iy) is ix*48+iy, so the cells of one window COLUMN are contiguous in the CSR: the window is
+// nx <= 64 contiguous runs, visited in exactly the reference's (ix, iy, insertion) order.
+constexpr int kSlot = 64;
 __global__ __launch_bounds__(256) void k_gather_projection(const CallDev* __restrict__ calls, const FrameDev* __restrict__ frames,
-                                                           int maxQ, uint32_t* __restrict__ pool, unsigned* __restrict__ poolHead,
-                                                           unsigned poolCap, int* __restrict__ status) {
+                                                           int maxQ, uint32_t* __restrict__ pool, unsigned* __restrict__ poolHeads,
+                                                           unsigned poolPerCall, int* __restrict__ status) {
   __shared__ int pref[4][64];
   __shared__ int sStart[4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -145,69 +160,67 @@ __global__ __launch_bounds__(256) void k_gather_projection(const CallDev* __rest
     const int minCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.v, F.minY), Q.r), F.gridHInv)));
     const int maxCellY = min(kGridRows - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.v, F.minY), Q.r), F.gridHInv)));
     if (minCellX < kGridCols && maxCellX >= 0 && minCellY < kGridRows && maxCellY >= 0 && minCellX <= maxCellX && minCellY <= maxCellY) {
-      const int ny = maxCellY - minCellY + 1, nCells = (maxCellX - minCellX + 1) * ny;
-      // upper bound of records = keypoints in the window -> one pool allocation per query
-      int total = 0;
-      for (int c0 = 0; c0 < nCells; c0 += 64) {
-        const int c = c0 + lane;
-        int cnt = 0;
-        if (c < nCells) {
-          const int cell = (minCellX + c / ny) * kGridRows + minCellY + c % ny;
-          cnt = F.cellStart[cell + 1] - F.cellStart[cell];
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-        total += cnt;
+      const int nx = maxCellX - minCellX + 1;  // <= 64
+      int start = 0, cnt = 0;
+      if (lane < nx) {
+        const int c0 = (minCellX + lane) * kGridRows;
+        start = F.cellStart[c0 + minCellY];
+        cnt = F.cellStart[c0 + maxCellY + 1] - start;
       }
-      if (total > 0) {
-        unsigned base = 0;
-        if (lane == 0) base = atomicAdd(poolHead, (unsigned)total);
-        base = __shfl(base, 0, 64);
-        if (base + (unsigned)total > poolCap) {
-          if (lane == 0) atomicMax(status, 1);
-        } else {
-          int written = 0;
-          const uint8_t* qd = C.qdesc + (size_t)q * 32;
-          for (int c0 = 0; c0 < nCells; c0 += 64) {
-            const int c = c0 + lane;
-            int cnt = 0, start = 0;
-            if (c < nCells) {
-              const int cell = (minCellX + c / ny) * kGridRows + minCellY + c % ny;
-              start = F.cellStart[cell];
-              cnt = F.cellStart[cell + 1] - start;
-            }
-            int incl = cnt;
+      int incl = cnt;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
-            pref[wv][lane] = incl;
-            sStart[wv][lane] = start;
-            __builtin_amdgcn_wave_barrier();
-            const int chunkTotal = __shfl(incl, 63, 64);
-            for (int t0 = 0; t0 < chunkTotal; t0 += 64) {
-              const int t = t0 + lane;
-              bool pass = false;
-              int idx = 0, dist = 0;
-              if (t < chunkTotal) {
-                int lo = 0, hi = 63;  // first lane whose inclusive prefix exceeds t
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (pref[wv][mid] > t) hi = mid; else lo = mid + 1; }
-                const int cExcl = lo ? pref[wv][lo - 1] : 0;
-                idx = F.cellIdx[sStart[wv][lo] + (t - cExcl)];
-                const KeyPointDev kp = F.kps[idx];
-                pass = true;
-                if (Q.minLevel > 0 || Q.maxLevel >= 0)
-                  if (kp.octave < Q.minLevel || (Q.maxLevel >= 0 && kp.octave < Q.maxLevel)) pass = false;
-                if (!(fabsf(__fsub_rn(kp.x, Q.u)) > Q.r && fabsf(__fsub_rn(kp.y, Q.v)) < Q.r)) pass = false;
-                if (pass && C.mode != 2 && F.rightX) {
-                  const float rx = F.rightX[idx];
-                  if (!(rx <= 0 || fabsf(__fsub_rn(Q.ur, rx)) <= Q.rs)) pass = false;
-                }
-                if (pass) dist = hamming256(qd, F.desc + (size_t)idx * 32);
+      for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+      const int total = __shfl(incl, 63, 64);
+      if (total > 0) {
+        pref[wv][lane] = incl;
+        sStart[wv][lane] = start;
+        __builtin_amdgcn_wave_barrier();
+        unsigned base;
+        bool ok = true;
+        if (total <= kSlot) {
+          base = blockIdx.y * poolPerCall + (unsigned)q * kSlot;
+        } else {
+          unsigned off = 0;
+          if (lane == 0) off = atomicAdd(poolHeads + blockIdx.y, (unsigned)total);
+          off = __shfl(off, 0, 64);
+          const unsigned ovfBase = (unsigned)maxQ * kSlot;
+          ok = ovfBase + off + (unsigned)total <= poolPerCall;
+          base = blockIdx.y * poolPerCall + ovfBase + off;
+          if (!ok && lane == 0) atomicMax(status, 1);
+        }
+        if (ok) {
+          int written = 0;
+          const uint4* qd = reinterpret_cast<const uint4*>(C.qdesc + (size_t)q * 32);
+          const uint4 qa = qd[0], qb = qd[1];
+          for (int t0 = 0; t0 < total; t0 += 64) {
+            const int t = t0 + lane;
+            bool pass = false;
+            int idx = 0, dist = 0;
+            if (t < total) {
+              int lo = 0, hi = nx - 1;  // first column whose inclusive prefix exceeds t
+              while (lo < hi) { const int mid = (lo + hi) >> 1; if (pref[wv][mid] > t) hi = mid; else lo = mid + 1; }
+              const int pos = sStart[wv][lo] + (t - (lo ? pref[wv][lo - 1] : 0));
+              const float4 kp = F.sortedKp[pos];
+              const int octave = __float_as_int(kp.z);
+              idx = __float_as_int(kp.w);
+              pass = true;
+              if (Q.minLevel > 0 || Q.maxLevel >= 0)
+                if (octave < Q.minLevel || (Q.maxLevel >= 0 && octave < Q.maxLevel)) pass = false;
+              if (!(fabsf(__fsub_rn(kp.x, Q.u)) > Q.r && fabsf(__fsub_rn(kp.y, Q.v)) < Q.r)) pass = false;
+              if (pass && C.mode != 2 && F.rightX) {
+                const float rx = F.rightX[idx];
+                if (!(rx <= 0 || fabsf(__fsub_rn(Q.ur, rx)) <= Q.rs)) pass = false;
               }
-              const unsigned long long m = __ballot(pass);
-              if (pass) pool[base + written + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)dist << 16) | (uint32_t)idx;
-              written += __popcll(m);
+              if (pass) {
+                const uint4* td = reinterpret_cast<const uint4*>(F.sortedDesc + (size_t)pos * 32);
+                const uint4 ta = td[0], tb = td[1];
+                dist = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) + __popc(qb.x ^ tb.x) +
+                       __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+              }
             }
-            __builtin_amdgcn_wave_barrier();
+            const unsigned long long m = __ballot(pass);
+            if (pass) pool[base + written + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)dist << 16) | (uint32_t)idx;
+            written += __popcll(m);
           }
           info = make_int2((int)base, written);
         }
@@ -265,16 +278,27 @@ __global__ __launch_bounds__(256) void k_gather_bow(BowCallDev B, uint32_t* __re
 // Phase 2: ordered replay.  best = first minimum over the not-taken candidates in scan order; second = first
 // minimum of the rest — which is exactly what the if / else-if chain at orbMatcher.cpp:44-53 leaves behind.
 // ---------------------------------------------------------------------------------------------------
+// wave-wide unsigned min with DPP (quad_perm xor 1/2, row_half_mirror, row_mirror, row_bcast15/31 -> lane 63): ~8 VALU
+// ops instead of six ds_bpermute round trips; this reduction runs twice per query on the serial resolve path.
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o, 64));
-  return v;
+#define YD_DPP_MIN(ctrl, rmask) v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xF, false))
+  YD_DPP_MIN(0xB1, 0xF);   // quad_perm [1,0,3,2]
+  YD_DPP_MIN(0x4E, 0xF);   // quad_perm [2,3,0,1]
+  YD_DPP_MIN(0x141, 0xF);  // row_half_mirror
+  YD_DPP_MIN(0x140, 0xF);  // row_mirror
+  YD_DPP_MIN(0x142, 0xA);  // row_bcast15 into rows 1,3
+  YD_DPP_MIN(0x143, 0xC);  // row_bcast31 into rows 2,3
+#undef YD_DPP_MIN
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+
+constexpr int kResolveWindow = 2048;  // queries whose (base,count) are staged in LDS at a time
 
 __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ calls, const FrameDev* __restrict__ frames,
                                                 const uint32_t* __restrict__ pool, int takenWords) {
   extern __shared__ unsigned takenBits[];  // [takenWords]
   __shared__ int hist[kHistLen];
+  __shared__ int3 live[kResolveWindow];    // (query, pool base, record count) of the window's non-empty queries, in order
   const int lane = threadIdx.x;
   const CallDev C = calls[blockIdx.x];
   const int nq = call_nq(C);
@@ -290,34 +314,51 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
     takenBits[w] = bits;
   }
   if (lane < kHistLen) hist[lane] = 0;
+  for (int q = lane; q < nq; q += 64) C.matchQ[q] = -1;
   __syncthreads();
   int matchNum = 0;
-  for (int q = 0; q < nq; q++) {
-    const int2 info = C.qInfo[q];
-    int myMatch = -1;
-    if (info.y > 0) {
+  for (int w0 = 0; w0 < nq; w0 += kResolveWindow) {
+    // stage the window's non-empty queries (ordered ballot compaction): the serial loop then touches LDS only
+    int nLive = 0;
+    for (int q0 = w0; q0 < min(nq, w0 + kResolveWindow); q0 += 64) {
+      const int q = q0 + lane;
+      int2 info = make_int2(0, 0);
+      if (q < nq) info = C.qInfo[q];
+      const unsigned long long m = __ballot(info.y > 0);
+      if (info.y > 0) live[nLive + __popcll(m & ((1ull << lane) - 1ull))] = make_int3(q, info.x, info.y);
+      nLive += __popcll(m);
+    }
+    __syncthreads();
+    unsigned recNext = 0;
+    if (nLive > 0 && lane < live[0].z) recNext = pool[live[0].y + lane];
+    for (int e = 0; e < nLive; e++) {
+      const int3 L3 = live[e];
+      const int q = L3.x;
+      unsigned recFirst = recNext;
+      if (e + 1 < nLive) {  // prefetch the next query's first 64 records while this one is reduced
+        const int3 N3 = live[e + 1];
+        recNext = lane < N3.z ? pool[N3.y + lane] : 0u;
+      }
       unsigned best = 0xFFFFFFFFu, second = 0xFFFFFFFFu;  // key = dist(9) << 23 | scan position(23)
       unsigned bestRec = 0, secondRec = 0;
-      for (int t0 = 0; t0 < info.y; t0 += 64) {
+      for (int t0 = 0; t0 < L3.z; t0 += 64) {
         const int t = t0 + lane;
         unsigned key = 0xFFFFFFFFu, rec = 0;
-        if (t < info.y) {
-          rec = pool[info.x + t];
+        if (t < L3.z) {
+          rec = t0 == 0 ? recFirst : pool[L3.y + t];
           const unsigned idx = rec & 0xFFFFu;
           if (!((takenBits[idx >> 5] >> (idx & 31)) & 1u)) key = ((rec >> 16) << 23) | (unsigned)t;
         }
         const unsigned b1 = wave_min_u32(key);
+        if (b1 == 0xFFFFFFFFu) continue;
         const unsigned b2 = wave_min_u32(key == b1 ? 0xFFFFFFFFu : key);
-        const unsigned long long m1 = __ballot(key == b1 && b1 != 0xFFFFFFFFu), m2 = __ballot(key == b2 && b2 != 0xFFFFFFFFu);
-        const unsigned r1 = m1 ? (unsigned)__shfl((int)rec, __ffsll((long long)m1) - 1, 64) : 0u;
-        const unsigned r2 = m2 ? (unsigned)__shfl((int)rec, __ffsll((long long)m2) - 1, 64) : 0u;
-        // merge (best, second) with the chunk's (b1, b2); keys are unique so min/max order them totally
+        // keys are unique, so the low 6 bits of the scan position name the owning lane of this chunk
+        const unsigned r1 = (unsigned)__builtin_amdgcn_readlane((int)rec, (int)(b1 & 63u));
+        const unsigned r2 = b2 != 0xFFFFFFFFu ? (unsigned)__builtin_amdgcn_readlane((int)rec, (int)(b2 & 63u)) : 0u;
         if (b1 < best) {
           if (best < b2) { second = best; secondRec = bestRec; } else { second = b2; secondRec = r2; }
           best = b1; bestRec = r1;
-        } else {
-          if (b1 < second) { second = b1; secondRec = r1; }
-        }
+        } else if (b1 < second) { second = b1; secondRec = r1; }
       }
       if (best != 0xFFFFFFFFu) {
         const int bestDist = (int)(best >> 23), secondDist = second == 0xFFFFFFFFu ? 256 : (int)(second >> 23);
@@ -331,20 +372,22 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
         else accept = bestDist <= kThLow && (float)bestDist < __fmul_rn(C.ratio, (float)secondDist);
         if (accept) {
           matchNum++;
-          myMatch = bestIdx;
-          const int qflags = bow ? 3 : C.queries[q].flags;
           if (lane == 0) {
+            const int qflags = bow ? 3 : C.queries[q].flags;
             if (C.mode == 4) C.assigned[q] = bestIdx;   // out[firstIdx] = second-keyframe index; q is remapped by the host
             else C.assigned[bestIdx] = q;
             const bool nowTaken = C.mode >= 2 ? true : (qflags & 2) != 0;
             if (nowTaken) takenBits[bestIdx >> 5] |= 1u << (bestIdx & 31);
+            C.matchQ[q] = bestIdx;
           }
+          __syncthreads();
         }
       }
     }
-    if (lane == 0) C.matchQ[q] = myMatch;
     __syncthreads();
   }
+  __threadfence_block();
+  __syncthreads();
   // rotation histogram (orbMatcher.cpp:119-153): bin = round((a1 - a2 [+360]) / 30), keep the three largest bins
   if (C.mode != 0 && C.checkOri) {
     const float factor = (float)(1.0 / kHistLen);

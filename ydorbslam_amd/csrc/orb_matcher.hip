@@ -58,7 +58,7 @@ struct ydorb_matcher {
   int device = 0;
   hipStream_t stream = nullptr;
   Buf kps, desc, rightX, queries, qdesc, taken, assigned, matchQ, qInfo, cellStart, cellIdx, pool, frames, calls, misc, kps2,
-      desc2, feat, valid, qFeat, qRange, qAngle, sf;
+      desc2, feat, valid, qFeat, qRange, qAngle, sf, heads, sortedKp, sortedDesc;
   size_t poolRecords = 1u << 20;
   // cached descriptors of the last batched launch (re-uploaded only when they change)
   std::vector<FrameDev> hFrames;
@@ -90,13 +90,14 @@ int resetMisc(ydorb_matcher* m, hipStream_t s) {
   return YDORB_OK;
 }
 
-FrameDev makeFrame(const YdFrameView& v, const KeyPointDev* dk, const uint8_t* dd, const float* drx, int* cellStart, int* cellIdx) {
+FrameDev makeFrame(const YdFrameView& v, const KeyPointDev* dk, const uint8_t* dd, const float* drx, int* cellStart, int* cellIdx, float4* skp,
+                   uint8_t* sdesc) {
   FrameDev F{};
   F.kps = dk; F.desc = dd; F.rightX = drx; F.nPtr = nullptr; F.n = v.n;
   F.minX = v.min_x; F.minY = v.min_y;
   F.gridWInv = static_cast<float>(kGridCols) / (v.max_x - v.min_x);  // frame.cpp:99-100
   F.gridHInv = static_cast<float>(kGridRows) / (v.max_y - v.min_y);
-  F.cellStart = cellStart; F.cellIdx = cellIdx;
+  F.cellStart = cellStart; F.cellIdx = cellIdx; F.sortedKp = skp; F.sortedDesc = sdesc;
   return F;
 }
 
@@ -104,7 +105,8 @@ int uploadFrame(ydorb_matcher* m, const YdFrameView* fv, FrameDev* out) {
   const int n = std::max(fv->n, 1);
   int rc;
   if ((rc = m->kps.ensure(sizeof(YdKeyPoint) * n)) || (rc = m->desc.ensure((size_t)32 * n)) || (rc = m->cellStart.ensure(sizeof(int) * (kGridCells + 1))) ||
-      (rc = m->cellIdx.ensure(sizeof(int) * n)) || (rc = m->frames.ensure(sizeof(FrameDev))))
+      (rc = m->cellIdx.ensure(sizeof(int) * n)) || (rc = m->frames.ensure(sizeof(FrameDev))) || (rc = m->sortedKp.ensure(sizeof(float4) * n)) ||
+      (rc = m->sortedDesc.ensure((size_t)32 * n)))
     return rc;
   if (fv->right_x && (rc = m->rightX.ensure(sizeof(float) * n))) return rc;
   if (fv->n > 0) {
@@ -113,7 +115,7 @@ int uploadFrame(ydorb_matcher* m, const YdFrameView* fv, FrameDev* out) {
     if (fv->right_x) HIPCHK(hipMemcpyAsync(m->rightX.p, fv->right_x, sizeof(float) * fv->n, hipMemcpyHostToDevice, m->stream));
   }
   *out = makeFrame(*fv, m->kps.as<KeyPointDev>(), m->desc.as<uint8_t>(), fv->right_x ? m->rightX.as<float>() : nullptr,
-                   m->cellStart.as<int>(), m->cellIdx.as<int>());
+                   m->cellStart.as<int>(), m->cellIdx.as<int>(), m->sortedKp.as<float4>(), m->sortedDesc.as<uint8_t>());
   HIPCHK(hipMemcpyAsync(m->frames.p, out, sizeof(FrameDev), hipMemcpyHostToDevice, m->stream));
   hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), sizeof(int16_t) * n, m->stream, m->frames.as<FrameDev>(), n);
   return YDORB_OK;
@@ -153,7 +155,7 @@ void ydorb_matcher_destroy(ydorb_matcher_t* m) {
   (void)hipStreamSynchronize(m->stream);
   for (Buf* b : {&m->kps, &m->desc, &m->rightX, &m->queries, &m->qdesc, &m->taken, &m->assigned, &m->matchQ, &m->qInfo, &m->cellStart,
                  &m->cellIdx, &m->pool, &m->frames, &m->calls, &m->misc, &m->kps2, &m->desc2, &m->feat, &m->valid, &m->qFeat, &m->qRange,
-                 &m->qAngle, &m->sf})
+                 &m->qAngle, &m->sf, &m->heads, &m->sortedKp, &m->sortedDesc})
     b->release();
   for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(m->stream);
@@ -198,7 +200,7 @@ static int searchProjectionImpl(ydorb_matcher_t* m, int32_t mode, const YdFrameV
     if ((rc = uploadFrame(m, fv, &F))) return rc;
     if ((rc = m->queries.ensure(sizeof(YdQuery) * nq)) || (rc = m->qdesc.ensure((size_t)32 * nq)) || (rc = m->taken.ensure(n)) ||
         (rc = m->assigned.ensure(sizeof(int) * n)) || (rc = m->matchQ.ensure(sizeof(int) * nq)) || (rc = m->qInfo.ensure(sizeof(int2) * nq)) ||
-        (rc = m->pool.ensure(sizeof(uint32_t) * m->poolRecords)) || (rc = m->calls.ensure(sizeof(CallDev))) || (rc = resetMisc(m, m->stream)))
+        (rc = m->pool.ensure(sizeof(uint32_t) * ((size_t)nq * kSlot + m->poolRecords))) || (rc = m->calls.ensure(sizeof(CallDev))) || (rc = resetMisc(m, m->stream)))
       return rc;
     HIPCHK(hipMemcpyAsync(m->queries.p, queries, sizeof(YdQuery) * nq, hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipMemcpyAsync(m->qdesc.p, qdesc, (size_t)32 * nq, hipMemcpyHostToDevice, m->stream));
@@ -212,7 +214,7 @@ static int searchProjectionImpl(ydorb_matcher_t* m, int32_t mode, const YdFrameV
     C.count = m->misc.as<int>() + 2; C.mode = mode; C.ratio = ratio; C.orbDist = orbDist; C.checkOri = checkOri;
     HIPCHK(hipMemcpyAsync(m->calls.p, &C, sizeof(CallDev), hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(k_gather_projection, dim3((nq + 3) / 4, 1), dim3(256), 0, m->stream, m->calls.as<CallDev>(), m->frames.as<FrameDev>(), nq,
-                       m->pool.as<uint32_t>(), m->misc.as<unsigned>(), (unsigned)m->poolRecords, m->misc.as<int>() + 1);
+                       m->pool.as<uint32_t>(), m->misc.as<unsigned>(), (unsigned)((size_t)nq * kSlot + m->poolRecords), m->misc.as<int>() + 1);
     int hmisc[3];
     if (!recordsOut) {
       const int takenWords = (n + 31) / 32;
@@ -373,13 +375,15 @@ int ydorb_match_consecutive_device(ydorb_matcher_t* m, const YdKeyPoint* d_kps, 
   HIPCHK(hipSetDevice(m->device));
   hipStream_t s = stream ? (hipStream_t)stream : m->stream;
   const int nCalls = nFrames - 1;
-  const size_t poolPerCall = (size_t)cap * 48;
+  const size_t poolPerCall = (size_t)cap * kSlot + (size_t)cap * 16;  // fixed slots + overflow region
   int rc;
   if ((rc = m->queries.ensure(sizeof(QueryDev) * (size_t)cap * nCalls)) || (rc = m->taken.ensure((size_t)cap * nCalls)) ||
       (rc = m->matchQ.ensure(sizeof(int) * (size_t)cap * nCalls)) || (rc = m->qInfo.ensure(sizeof(int2) * (size_t)cap * nCalls)) ||
       (rc = m->cellStart.ensure(sizeof(int) * (size_t)(kGridCells + 1) * nFrames)) || (rc = m->cellIdx.ensure(sizeof(int) * (size_t)cap * nFrames)) ||
       (rc = m->pool.ensure(sizeof(uint32_t) * poolPerCall * nCalls)) || (rc = m->frames.ensure(sizeof(FrameDev) * nFrames)) ||
-      (rc = m->calls.ensure(sizeof(CallDev) * nCalls)) || (rc = m->sf.ensure(sizeof(float) * 8 + sizeof(float) * 6 * nCalls)) || (rc = m->misc.ensure(64)))
+      (rc = m->calls.ensure(sizeof(CallDev) * nCalls)) || (rc = m->sf.ensure(sizeof(float) * 8 + sizeof(float) * 6 * nCalls)) || (rc = m->misc.ensure(64)) ||
+      (rc = m->heads.ensure(sizeof(unsigned) * nCalls)) || (rc = m->sortedKp.ensure(sizeof(float4) * (size_t)cap * nFrames)) ||
+      (rc = m->sortedDesc.ensure((size_t)32 * cap * nFrames)))
     return rc;
   std::vector<FrameDev> hf(nFrames);
   std::vector<CallDev> hc(nCalls);
@@ -390,6 +394,7 @@ int ydorb_match_consecutive_device(ydorb_matcher_t* m, const YdKeyPoint* d_kps, 
     F.nPtr = d_n + f; F.n = 0; F.minX = minX; F.minY = minY;
     F.gridWInv = static_cast<float>(kGridCols) / (maxX - minX); F.gridHInv = static_cast<float>(kGridRows) / (maxY - minY);
     F.cellStart = m->cellStart.as<int>() + (size_t)f * (kGridCells + 1); F.cellIdx = m->cellIdx.as<int>() + (size_t)f * cap;
+    F.sortedKp = m->sortedKp.as<float4>() + (size_t)f * cap; F.sortedDesc = m->sortedDesc.as<uint8_t>() + (size_t)f * cap * 32;
     hf[f] = F;
   }
   for (int c = 0; c < nCalls; c++) {
@@ -420,7 +425,7 @@ int ydorb_match_consecutive_device(ydorb_matcher_t* m, const YdKeyPoint* d_kps, 
   const float* aff = d_affine ? d_affine : m->sf.as<float>() + 8;
   const bool prof = m->profiling;
   collect(m);
-  HIPCHK(hipMemsetAsync(m->misc.p, 0, 4, s));  // pool head; the overflow status is sticky until synchronize reads it
+  HIPCHK(hipMemsetAsync(m->heads.p, 0, sizeof(unsigned) * nCalls, s));  // per-call pool heads; the overflow status (misc[1]) is sticky until synchronize reads it
   HIPCHK(hipMemsetAsync(m->taken.p, 0, (size_t)cap * nCalls, s));
   HIPCHK(hipMemsetAsync(d_assigned, 0xFF, sizeof(int) * (size_t)cap * nCalls, s));
   if (prof) HIPCHK(hipEventRecord(m->ev[0], s));
@@ -429,7 +434,7 @@ int ydorb_match_consecutive_device(ydorb_matcher_t* m, const YdKeyPoint* d_kps, 
   hipLaunchKernelGGL(k_grid_build, dim3(nFrames), dim3(256), sizeof(int16_t) * cap, s, m->frames.as<FrameDev>(), cap);
   if (prof) HIPCHK(hipEventRecord(m->ev[1], s));
   hipLaunchKernelGGL(k_gather_projection, dim3((cap + 3) / 4, nCalls), dim3(256), 0, s, m->calls.as<CallDev>(), m->frames.as<FrameDev>(), cap,
-                     m->pool.as<uint32_t>(), m->misc.as<unsigned>(), (unsigned)(poolPerCall * nCalls), m->misc.as<int>() + 1);
+                     m->pool.as<uint32_t>(), m->heads.as<unsigned>(), (unsigned)poolPerCall, m->misc.as<int>() + 1);
   if (prof) HIPCHK(hipEventRecord(m->ev[2], s));
   const int takenWords = (cap + 31) / 32;
   hipLaunchKernelGGL(k_resolve, dim3(nCalls), dim3(64), sizeof(unsigned) * takenWords, s, m->calls.as<CallDev>(), m->frames.as<FrameDev>(),

@@ -144,6 +144,9 @@ YD_HD inline int qt_sort_front(uint32_t* a, int m) {
 }
 
 // ---- workgroup algorithm -------------------------------------------------------------------------
+#ifndef QT_ITEMS
+#define QT_ITEMS 8
+#endif
 struct QtShared {           // LDS (device) / heap (host); arrays of nodeCap entries
   QtGeom* geom[2];
   uint32_t* cnt[2];
@@ -154,7 +157,9 @@ struct QtShared {           // LDS (device) / heap (host); arrays of nodeCap ent
 struct QtGlobal {           // per (frame, level) scratch in HBM, n entries each
   uint32_t* cand[2];
   uint16_t* node[2];
-  uint32_t* sortKeys;
+  uint32_t* sortKeys;       // n keys for the per-node std::sort replay (HBM fallback)
+  uint32_t* ldsKeys;        // same, in LDS, used when n <= ldsKeyCap (a serial sort over HBM-latency loads was the slowest phase)
+  int ldsKeyCap;
 };
 
 // Ctx: tid(), nthreads(), sync(), scan_incl_u64(v,&total), scan_incl_u32(v,&total), lds_add_u64(p,v)
@@ -265,40 +270,58 @@ YD_HD int qt_distribute(Ctx& cx, const QtShared& S, const QtGlobal& G, int n, in
       }
     }
     cx.sync();
-    // sweep 2: stable 4-way partition (ordered scan of packed quadrant counters)
+    // sweep 2: stable 4-way partition (ordered scan of packed quadrant counters).  Each thread owns QT_ITEMS consecutive
+    // candidates, so one workgroup scan covers nthreads*QT_ITEMS positions (4096 at 512 threads): two barriers per pass
+    // instead of four per 512 candidates.
     {
       unsigned long long carry = 0;
-      for (int c0 = 0; c0 < n; c0 += nt) {
-        const int p = c0 + tid;
-        int k = 0, q = -1;
-        uint32_t c = 0;
-        unsigned long long v = 0;
-        if (p < n) {
-          k = G.node[cur][p];
-          c = G.cand[cur][p];
-          if (cnt[k] > 1) {
-            const QtGeom g = geom[k];
-            q = qt_quadrant(c, qt_center(g.x0, g.x1), qt_center(g.y0, g.y1));
-            v = 1ull << (16 * q);
+      for (int c0 = 0; c0 < n; c0 += nt * QT_ITEMS) {
+        int kk[QT_ITEMS], qq[QT_ITEMS];
+        uint32_t cc[QT_ITEMS];
+        unsigned long long loc[QT_ITEMS], tot = 0;
+#pragma unroll
+        for (int i = 0; i < QT_ITEMS; i++) {
+          const int p = c0 + tid * QT_ITEMS + i;
+          kk[i] = 0; qq[i] = -1; cc[i] = 0;
+          unsigned long long v = 0;
+          if (p < n) {
+            kk[i] = G.node[cur][p];
+            cc[i] = G.cand[cur][p];
+            if (cnt[kk[i]] > 1) {
+              const QtGeom g = geom[kk[i]];
+              qq[i] = qt_quadrant(cc[i], qt_center(g.x0, g.x1), qt_center(g.y0, g.y1));
+              v = 1ull << (16 * qq[i]);
+            }
           }
+          loc[i] = tot;
+          tot += v;
         }
         unsigned long long total;
-        const unsigned long long incl = cx.scan_incl_u64(v, &total);
-        const unsigned long long excl = carry + incl - v;
-        if (p < n && (uint32_t)p == base[k]) S.cc[k] = excl;  // prefix at segment start
+        const unsigned long long incl = cx.scan_incl_u64(tot, &total);
+        const unsigned long long texcl = carry + incl - tot;
+#pragma unroll
+        for (int i = 0; i < QT_ITEMS; i++) {
+          const int p = c0 + tid * QT_ITEMS + i;
+          loc[i] += texcl;
+          if (p < n && (uint32_t)p == base[kk[i]]) S.cc[kk[i]] = loc[i];  // prefix at segment start
+        }
         cx.sync();
-        if (p < n) {
-          int idx, rank;
-          if (q >= 0) {
-            idx = S.childIdx[k * 4 + q];
-            rank = (int)(((excl - S.cc[k]) >> (16 * q)) & 0xFFFF);
-          } else {
-            idx = S.childIdx[k * 4];
-            rank = 0;
+#pragma unroll
+        for (int i = 0; i < QT_ITEMS; i++) {
+          const int p = c0 + tid * QT_ITEMS + i;
+          if (p < n) {
+            int idx, rank;
+            if (qq[i] >= 0) {
+              idx = S.childIdx[kk[i] * 4 + qq[i]];
+              rank = (int)(((loc[i] - S.cc[kk[i]]) >> (16 * qq[i])) & 0xFFFF);
+            } else {
+              idx = S.childIdx[kk[i] * 4];
+              rank = 0;
+            }
+            const uint32_t np = S.base[nxt][idx] + (uint32_t)rank;
+            G.cand[nxt][np] = cc[i];
+            G.node[nxt][np] = (uint16_t)idx;
           }
-          const uint32_t np = S.base[nxt][idx] + (uint32_t)rank;
-          G.cand[nxt][np] = c;
-          G.node[nxt][np] = (uint16_t)idx;
         }
         carry += total;
         cx.sync();
@@ -310,19 +333,24 @@ YD_HD int qt_distribute(Ctx& cx, const QtShared& S, const QtGlobal& G, int n, in
   }
   // best keypoint per node, list order, truncated to the quota (:534-543)
   const int nOut = K < quota ? K : quota;
+  uint32_t* keysAll = n <= G.ldsKeyCap ? G.ldsKeys : G.sortKeys;
+  {  // keys of every candidate, segment-relative index in the low half: filled by all threads, coalesced
+    const uint16_t* nodeOf = G.node[cur];
+    const uint32_t* cd = G.cand[cur];
+    for (int p = tid; p < n; p += nt) keysAll[p] = ((uint32_t)qt_r(cd[p]) << 16) | ((uint32_t)p - S.base[cur][nodeOf[p]]);
+  }
+  cx.sync();
   for (int k = tid; k < nOut; k += nt) {
     const uint32_t b = S.base[cur][k], m = S.cnt[cur][k];
-    const uint32_t* seg = G.cand[cur] + b;
+    uint32_t* keys = keysAll + b;
     int best = 0;
     if (m > 16) {
-      uint32_t* keys = G.sortKeys + b;
-      for (uint32_t i = 0; i < m; i++) keys[i] = ((uint32_t)qt_r(seg[i]) << 16) | i;
       best = qt_sort_front(keys, (int)m);
     } else {
       for (uint32_t i = 1; i < m; i++)
-        if (qt_r(seg[i]) > qt_r(seg[best])) best = (int)i;
+        if (qt_gt(keys[i], keys[best])) best = (int)i;
     }
-    out[k] = seg[best];
+    out[k] = G.cand[cur][b + best];
   }
   cx.sync();
   return nOut;
