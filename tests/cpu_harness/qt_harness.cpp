@@ -14,7 +14,7 @@ struct CpuCtx {
   void sync() {}
   unsigned scan_incl_u32(unsigned v, unsigned* total) { *total = v; return v; }
   unsigned long long scan_incl_u64(unsigned long long v, unsigned long long* total) { *total = v; return v; }
-  void lds_add_u64(unsigned long long* p, unsigned long long v) { *p += v; }
+  void count_child(unsigned long long* cc, int k, int q) { if (k >= 0) cc[k] += 1ull << (16 * q); }
 };
 }  // namespace
 
@@ -28,7 +28,7 @@ extern "C" int qt_cpu_distribute(const uint32_t* cands, int n, int rootX1, int r
   QtShared S{{g0.data(), g1.data()}, {c0.data(), c1.data()}, {b0.data(), b1.data()}, cc.data(), ci.data()};
   std::vector<uint32_t> ca(cands, cands + n), cb(n), keys(n);
   std::vector<uint16_t> na(n), nb(n);
-  QtGlobal G{{ca.data(), cb.data()}, {na.data(), nb.data()}, keys.data(), nullptr, 0};
+  QtGlobal G{{ca.data(), cb.data()}, {na.data(), nb.data()}};
   CpuCtx cx;
   return qt_distribute(cx, S, G, n, rootX1, rootY1, quota, nodeCap, out);
 }

@@ -12,7 +12,8 @@ class YdorbError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libydorb.so")
+    # YDORB_LIB: an alternative build of the same library (kernel experiments); the default is the in-tree product build
+    return os.environ.get("YDORB_LIB") or os.path.join(_HERE, "libydorb.so")
 
 
 def build_library(jobs=4):

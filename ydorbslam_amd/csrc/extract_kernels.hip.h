@@ -20,7 +20,10 @@ constexpr int kPad = 19;          // m_int_maxPadSize, orbExtractor.hpp:71
 constexpr int kBorder = 16;       // m_int_maxPadSize - 3, orbExtractor.cpp:549
 constexpr int kMaxLevels = 8;
 constexpr int kTileMax = 72;      // FAST cell sub-image is at most (59+1+6) px wide
-constexpr int kQtThreads = 512;
+#ifndef QT_THREADS
+#define QT_THREADS 512
+#endif
+constexpr int kQtThreads = QT_THREADS;     // threads per (frame, level) unit
 
 struct LevelDev {
   int w, h, pitch;          // interior size, padded-row pitch (bytes)
@@ -107,27 +110,26 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, s
 }
 
 // ------------------------------------------------------------------------------------------------
-// FAST-9/16 segment test + corner score for one pixel (cv::FAST, call site orbExtractor.cpp:581).
-// ring[k], k=0..15 in circle order.  Returns 0 if not a corner, else the score (>= thr):
-//   score = max over the 16 arcs of 9 contiguous ring pixels of  min(v - p)  resp.  min(p - v),  minus 1
-// which equals OpenCV's cornerScore<16> recurrence for every pixel that passes the segment test.
+// FAST-9/16 (cv::FAST, call site orbExtractor.cpp:581) split into the three tests a pixel has to pass, so that each
+// later (more expensive) test runs only on a dense list of survivors:
+//   compass test : a 9-arc of the 16-ring always contains >= 2 of the 4 compass pixels, so < 2 brighter and < 2 darker
+//                  compass pixels means "not a corner" (8 compares);
+//   segment test : 16-bit darker / brighter ring masks, 9 contiguous bits via shift-and (strict compares, like OpenCV);
+//   corner score : max over the 16 arcs of min(v - p) resp. min(p - v), minus 1  ==  OpenCV's cornerScore<16> recurrence
+//                  for every pixel that passes the segment test.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int fast_corner_score(int v, const int (&ring)[16], int thr) {
-  unsigned dark = 0, bright = 0;
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    dark |= (unsigned)(ring[k] < v - thr) << k;
-    bright |= (unsigned)(ring[k] > v + thr) << k;
-  }
-  auto run9 = [](unsigned m) {
-    m |= m << 16;
-    unsigned a = m & (m >> 1);
-    unsigned b = a & (a >> 2);
-    unsigned c = b & (b >> 4);
-    return (c & (m >> 8)) != 0;
-  };
-  const bool isDark = run9(dark), isBright = run9(bright);
-  if (!isDark && !isBright) return 0;
+__device__ __forceinline__ bool fast_run9(unsigned m) {
+  m |= m << 16;
+  const unsigned a = m & (m >> 1), b = a & (a >> 2), c = b & (b >> 4);
+  return (c & (m >> 8)) != 0;
+}
+__device__ __forceinline__ void fast_ring(const uint8_t* p, int (&ring)[16]) {
+  ring[0] = p[3 * kTileMax];       ring[1] = p[3 * kTileMax + 1];   ring[2] = p[2 * kTileMax + 2];   ring[3] = p[kTileMax + 3];
+  ring[4] = p[3];                  ring[5] = p[-kTileMax + 3];      ring[6] = p[-2 * kTileMax + 2];  ring[7] = p[-3 * kTileMax + 1];
+  ring[8] = p[-3 * kTileMax];      ring[9] = p[-3 * kTileMax - 1];  ring[10] = p[-2 * kTileMax - 2]; ring[11] = p[-kTileMax - 3];
+  ring[12] = p[-3];                ring[13] = p[kTileMax - 3];      ring[14] = p[2 * kTileMax - 2];  ring[15] = p[3 * kTileMax - 1];
+}
+__device__ __forceinline__ int fast_score(int v, const int (&ring)[16], int thr, bool isDark, bool isBright) {
   int d[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) d[k] = v - ring[k];
@@ -157,6 +159,19 @@ __device__ __forceinline__ int fast_corner_score(int v, const int (&ring)[16], i
   return best - 1;
 }
 
+// ordered (stable) compaction of one 256-item round: returns this thread's output slot (or -1) and advances *total
+__device__ __forceinline__ int fast_compact(bool keep, int* waveCnt, int& total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const unsigned long long m = __ballot(keep);
+  __syncthreads();                       // previous round's readers of waveCnt are done
+  if (lane == 0) waveCnt[wv] = __popcll(m);
+  __syncthreads();
+  int off = total;
+  for (int j = 0; j < wv; j++) off += waveCnt[j];
+  total += waveCnt[0] + waveCnt[1] + waveCnt[2] + waveCnt[3];
+  return keep ? off + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+
 // ------------------------------------------------------------------------------------------------
 // One workgroup per (cell, frame): cv::FAST(cell sub-image, thr, nms=true) — orbExtractor.cpp:562-590.
 // FAST never looks outside the sub-image, so each cell has a private 3-px dead border and NMS sees
@@ -164,14 +179,15 @@ __device__ __forceinline__ int fast_corner_score(int v, const int (&ring)[16], i
 // cv::FAST returns them) into the cell's fixed slot; the quad-tree kernel concatenates cells in
 // (row, col) order, which reproduces keyPointsToDistr.  The retry at :583 uses the same threshold
 // (m_int_minFastThd is initialised from _initFastThd, :318), so it is a no-op and is not launched.
+// Every list is produced by stable compaction in pixel order, so the final list needs no sort.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyrFrameStride, PlanDev P,
                                                     const CellDev* __restrict__ cells, int thr,
                                                     uint32_t* __restrict__ cellCount, uint32_t* __restrict__ cellCand) {
-  __shared__ uint8_t tile[kTileMax * kTileMax];
+  __shared__ __align__(4) uint8_t tile[kTileMax * kTileMax];
   __shared__ uint8_t score[(kTileMax - 4) * (kTileMax - 4)];
+  __shared__ uint16_t list[(kTileMax - 6) * (kTileMax - 6)];   // pixel index (12 bits) | dark << 14 | bright << 15
   __shared__ int waveCnt[4];
-  __shared__ int total;
   const int cellId = blockIdx.x, f = blockIdx.y;
   const CellDev c = cells[cellId];
   const LevelDev L = P.lv[c.level];
@@ -189,55 +205,85 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
   }
   const int sw = bw + 2, sh = bh + 2;  // score map with a zero ring
   for (int i = threadIdx.x; i < sw * sh; i += 256) score[i] = 0;
-  if (threadIdx.x == 0) total = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < bw * bh; i += 256) {
-    const int by = i / bw, bx = i - by * bw;
-    const uint8_t* p = &tile[(by + 3) * kTileMax + bx + 3];
-    const int v = p[0];
-    int ring[16];
-    ring[0] = p[3 * kTileMax];       ring[1] = p[3 * kTileMax + 1];   ring[2] = p[2 * kTileMax + 2];   ring[3] = p[kTileMax + 3];
-    ring[4] = p[3];                  ring[5] = p[-kTileMax + 3];      ring[6] = p[-2 * kTileMax + 2];  ring[7] = p[-3 * kTileMax + 1];
-    ring[8] = p[-3 * kTileMax];      ring[9] = p[-3 * kTileMax - 1];  ring[10] = p[-2 * kTileMax - 2]; ring[11] = p[-kTileMax - 3];
-    ring[12] = p[-3];                ring[13] = p[kTileMax - 3];      ring[14] = p[2 * kTileMax - 2];  ring[15] = p[3 * kTileMax - 1];
-    const int s = fast_corner_score(v, ring, thr);
-    if (s) score[(by + 1) * sw + bx + 1] = (uint8_t)s;
-  }
-  __syncthreads();
-  // NMS (strictly greater than the 8 neighbours) + ordered compaction, 256 band pixels per round
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  uint32_t* dst = cellCand + slot * P.cellCap;
-  for (int base = 0; base < bw * bh; base += 256) {
+  const int nBand = bw * bh;
+  // stage A: compass test over the band
+  int n1 = 0;
+  for (int base = 0; base < nBand; base += 256) {
     const int i = base + threadIdx.x;
     bool keep = false;
+    if (i < nBand) {
+      const int by = i / bw, bx = i - by * bw;
+      const uint8_t* p = &tile[(by + 3) * kTileMax + bx + 3];
+      const int v = p[0], hi = v + thr, lo = v - thr;
+      const int r0 = p[3 * kTileMax], r4 = p[3], r8 = p[-3 * kTileMax], r12 = p[-3];
+      const int nb = (r0 > hi) + (r4 > hi) + (r8 > hi) + (r12 > hi), nd = (r0 < lo) + (r4 < lo) + (r8 < lo) + (r12 < lo);
+      keep = nb >= 2 || nd >= 2;
+    }
+    const int pos = fast_compact(keep, waveCnt, n1);
+    if (pos >= 0) list[pos] = (uint16_t)i;   // pos <= i: in-place safe
+  }
+  __syncthreads();
+  // stage B: segment test on the survivors (in place: the output index never passes the input index)
+  int n2 = 0;
+  for (int base = 0; base < n1; base += 256) {
+    const int j = base + threadIdx.x;
+    bool keep = false;
+    unsigned ent = 0;
+    if (j < n1) {
+      const int i = list[j];
+      const int by = i / bw, bx = i - by * bw;
+      const uint8_t* p = &tile[(by + 3) * kTileMax + bx + 3];
+      const int v = p[0];
+      int ring[16];
+      fast_ring(p, ring);
+      unsigned dark = 0, bright = 0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        dark |= (unsigned)(ring[k] < v - thr) << k;
+        bright |= (unsigned)(ring[k] > v + thr) << k;
+      }
+      const bool isDark = fast_run9(dark), isBright = fast_run9(bright);
+      keep = isDark || isBright;
+      ent = (unsigned)i | (isDark ? 0x4000u : 0u) | (isBright ? 0x8000u : 0u);
+    }
+    const int pos = fast_compact(keep, waveCnt, n2);   // its barriers also order this round's list reads before the writes
+    if (pos >= 0) list[pos] = (uint16_t)ent;
+  }
+  __syncthreads();
+  // stage C: corner score, corners only
+  for (int j = threadIdx.x; j < n2; j += 256) {
+    const unsigned ent = list[j];
+    const int i = ent & 0xFFF;
+    const int by = i / bw, bx = i - by * bw;
+    const uint8_t* p = &tile[(by + 3) * kTileMax + bx + 3];
+    int ring[16];
+    fast_ring(p, ring);
+    score[(by + 1) * sw + bx + 1] = (uint8_t)fast_score(p[0], ring, thr, (ent & 0x4000u) != 0, (ent & 0x8000u) != 0);
+  }
+  __syncthreads();
+  // stage D: NMS (strictly greater than the 8 neighbours; zeros outside the band) + ordered output
+  uint32_t* dst = cellCand + slot * P.cellCap;
+  int n3 = 0;
+  for (int base = 0; base < n2; base += 256) {
+    const int j = base + threadIdx.x;
+    bool keep = false;
     int bx = 0, by = 0, s = 0;
-    if (i < bw * bh) {
+    if (j < n2) {
+      const int i = list[j] & 0xFFF;
       by = i / bw;
       bx = i - by * bw;
       const uint8_t* q = &score[(by + 1) * sw + bx + 1];
       s = q[0];
-      keep = s && s > q[-1] && s > q[1] && s > q[-sw - 1] && s > q[-sw] && s > q[-sw + 1] && s > q[sw - 1] && s > q[sw] && s > q[sw + 1];
+      keep = s > q[-1] && s > q[1] && s > q[-sw - 1] && s > q[-sw] && s > q[-sw + 1] && s > q[sw - 1] && s > q[sw] && s > q[sw + 1];
     }
-    const unsigned long long m = __ballot(keep);
-    if (lane == 0) waveCnt[wv] = __popcll(m);
-    __syncthreads();
-    int off = total;
-    for (int j = 0; j < wv; j++) off += waveCnt[j];
-    if (keep) {
-      const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
-      if (pos < P.cellCap) dst[pos] = qt_pack(c.x0 + 3 + bx - kBorder, c.y0 + 3 + by - kBorder, s);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) total += waveCnt[0] + waveCnt[1] + waveCnt[2] + waveCnt[3];
-    __syncthreads();
+    const int pos = fast_compact(keep, waveCnt, n3);
+    if (pos >= 0 && pos < P.cellCap) dst[pos] = qt_pack(c.x0 + 3 + bx - kBorder, c.y0 + 3 + by - kBorder, s);
   }
-  if (threadIdx.x == 0) cellCount[slot] = (uint32_t)min(total, P.cellCap);
+  if (threadIdx.x == 0) cellCount[slot] = (uint32_t)min(n3, P.cellCap);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Quad-tree thinning, one workgroup per (level, frame).  See quadtree_core.h.
-// ------------------------------------------------------------------------------------------------
-struct QtGpuCtx {
+struct QtBlockCtx {   // workgroup of kQtThreads threads: barriers + LDS hand-off of the per-wave scan totals
   unsigned* w32;
   unsigned long long* w64;
   __device__ int tid() const { return threadIdx.x; }
@@ -283,75 +329,144 @@ struct QtGpuCtx {
     *total = tot;
     return x + off;
   }
-  __device__ void lds_add_u64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
+  // all lanes of the wave call this together; lanes with k < 0 only take part in the ballots
+  __device__ void count_child(QT_LDS unsigned long long* cc, int k, int q) {
+    unsigned long long remaining = __ballot(k >= 0);
+    const int lane = threadIdx.x & 63;
+    while (remaining) {
+      const int leader = __ffsll((long long)remaining) - 1;
+      const int k0 = __shfl(k, leader, 64);
+      const bool mine = k == k0;
+      const unsigned long long m = __ballot(mine);
+      const unsigned long long c0 = __popcll(__ballot(mine && q == 0)), c1 = __popcll(__ballot(mine && q == 1));
+      const unsigned long long c2 = __popcll(__ballot(mine && q == 2)), c3 = __popcll(__ballot(mine && q == 3));
+      if (lane == leader) __hip_atomic_fetch_add(cc + k0, c0 | (c1 << 16) | (c2 << 32) | (c3 << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      remaining &= ~m;
+    }
+  }
+
 };
 
-// dynamic LDS layout: [cc|geom0|geom1|childIdx|cnt0|cnt1|base0|base1] for nodeCap nodes, sort keys[ldsKeyCap], cellBase[maxCells+1]
+// Wave-synchronous context: ONE 64-lane wave runs a whole (frame, level).  The first version used a 512-thread workgroup and
+// spent its time in ~25 __syncthreads per split pass (measured: 0.44 of 0.75 ms in the passes, 1 workgroup per CU); a wave
+// needs no workgroup barrier at all, LDS/L1 keep program order inside a wave, and ~1000 (frame, level) units run at once.
+struct QtWaveCtx {
+  __device__ int tid() const { return threadIdx.x; }
+  __device__ int nthreads() const { return 64; }
+  __device__ void sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ unsigned scan_incl_u32(unsigned v, unsigned* total) {
+    const int lane = threadIdx.x;
+    unsigned x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    *total = __shfl(x, 63, 64);
+    return x;
+  }
+  __device__ unsigned long long scan_incl_u64(unsigned long long v, unsigned long long* total) {
+    const int lane = threadIdx.x;
+    unsigned long long x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned lo = __shfl_up((unsigned)x, d, 64), hi = __shfl_up((unsigned)(x >> 32), d, 64);
+      if (lane >= d) x += ((unsigned long long)hi << 32) | lo;
+    }
+    *total = ((unsigned long long)__shfl((unsigned)(x >> 32), 63, 64) << 32) | __shfl((unsigned)x, 63, 64);
+    return x;
+  }
+  // all lanes of the wave call this together; lanes with k < 0 only take part in the ballots
+  __device__ void count_child(QT_LDS unsigned long long* cc, int k, int q) {
+    unsigned long long remaining = __ballot(k >= 0);
+    const int lane = threadIdx.x & 63;
+    while (remaining) {
+      const int leader = __ffsll((long long)remaining) - 1;
+      const int k0 = __shfl(k, leader, 64);
+      const bool mine = k == k0;
+      const unsigned long long m = __ballot(mine);
+      const unsigned long long c0 = __popcll(__ballot(mine && q == 0)), c1 = __popcll(__ballot(mine && q == 1));
+      const unsigned long long c2 = __popcll(__ballot(mine && q == 2)), c3 = __popcll(__ballot(mine && q == 3));
+      if (lane == leader) __hip_atomic_fetch_add(cc + k0, c0 | (c1 << 16) | (c2 << 32) | (c3 << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      remaining &= ~m;
+    }
+  }
+
+};
+
+// dynamic LDS layout: [cc|geom0|geom1|childIdx|cnt0|cnt1|base0|base1] for nodeCap nodes, keys/cand[ldsCandCap] u32 x2,
+// node ids [ldsCandCap] u16 x2, cellBase[maxCells+1]
 __global__ __launch_bounds__(kQtThreads) void k_quadtree(PlanDev P, const uint32_t* __restrict__ cellCount,
-                                                         const uint32_t* __restrict__ cellCand, uint32_t* __restrict__ qtCand,
-                                                         uint16_t* __restrict__ qtNode, uint32_t* __restrict__ qtKeys,
-                                                         size_t qtFrameStride, int nodeCap, int ldsKeyCap, uint32_t* __restrict__ lvlKp,
-                                                         int* __restrict__ lvlCount, int* __restrict__ status) {
+                                                 const uint32_t* __restrict__ cellCand, uint32_t* __restrict__ qtCand,
+                                                 uint16_t* __restrict__ qtNode, size_t qtFrameStride, int nodeCap, int ldsCandCap,
+                                                 uint32_t* __restrict__ lvlKp, int* __restrict__ lvlCount, int* __restrict__ status) {
   extern __shared__ __align__(16) uint8_t smem[];
-  __shared__ unsigned w32[kQtThreads / 64];
-  __shared__ unsigned long long w64[kQtThreads / 64];
-  const int level = blockIdx.x, f = blockIdx.y;
+  __shared__ unsigned w32[16];
+  __shared__ unsigned long long w64[16];
+  const int level = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
   const LevelDev L = P.lv[level];
   uint8_t* sp = smem;
   QtShared S;
-  S.cc = reinterpret_cast<unsigned long long*>(sp); sp += sizeof(unsigned long long) * nodeCap;
-  S.geom[0] = reinterpret_cast<QtGeom*>(sp); sp += sizeof(QtGeom) * nodeCap;
-  S.geom[1] = reinterpret_cast<QtGeom*>(sp); sp += sizeof(QtGeom) * nodeCap;
-  S.childIdx = reinterpret_cast<uint16_t*>(sp); sp += sizeof(uint16_t) * 4 * nodeCap;
-  S.cnt[0] = reinterpret_cast<uint32_t*>(sp); sp += sizeof(uint32_t) * nodeCap;
-  S.cnt[1] = reinterpret_cast<uint32_t*>(sp); sp += sizeof(uint32_t) * nodeCap;
-  S.base[0] = reinterpret_cast<uint32_t*>(sp); sp += sizeof(uint32_t) * nodeCap;
-  S.base[1] = reinterpret_cast<uint32_t*>(sp); sp += sizeof(uint32_t) * nodeCap;
-  uint32_t* ldsKeys = reinterpret_cast<uint32_t*>(sp); sp += sizeof(uint32_t) * ldsKeyCap;
-  uint32_t* cellBase = reinterpret_cast<uint32_t*>(sp);
-  QtGpuCtx cx{w32, w64};
+  S.cc = (QT_LDS unsigned long long*)(sp); sp += sizeof(unsigned long long) * nodeCap;
+  S.geom[0] = (QT_LDS QtGeom*)(sp); sp += sizeof(QtGeom) * nodeCap;
+  S.geom[1] = (QT_LDS QtGeom*)(sp); sp += sizeof(QtGeom) * nodeCap;
+  S.childIdx = (QT_LDS uint16_t*)(sp); sp += sizeof(uint16_t) * 4 * nodeCap;
+  S.cnt[0] = (QT_LDS uint32_t*)(sp); sp += sizeof(uint32_t) * nodeCap;
+  S.cnt[1] = (QT_LDS uint32_t*)(sp); sp += sizeof(uint32_t) * nodeCap;
+  S.base[0] = (QT_LDS uint32_t*)(sp); sp += sizeof(uint32_t) * nodeCap;
+  S.base[1] = (QT_LDS uint32_t*)(sp); sp += sizeof(uint32_t) * nodeCap;
+  QT_LDS uint32_t* ldsCand = (QT_LDS uint32_t*)(sp); sp += sizeof(uint32_t) * 2 * ldsCandCap;
+  QT_LDS uint16_t* ldsNode = (QT_LDS uint16_t*)(sp); sp += sizeof(uint16_t) * 2 * ldsCandCap;
+  QT_LDS uint32_t* cellBase = (QT_LDS uint32_t*)(sp);
+  QtBlockCtx cx{w32, w64};
 
   // concatenate the level's cells in (row, col) order == keyPointsToDistr (orbExtractor.cpp:584-590)
   const uint32_t* cnts = cellCount + (size_t)f * P.nCellsTotal + L.cellBegin;
   unsigned n = 0;
   for (int c0 = 0; c0 < L.nCells; c0 += kQtThreads) {
-    const int c = c0 + threadIdx.x;
+    const int c = c0 + lane;
     const unsigned v = c < L.nCells ? cnts[c] : 0u;
     unsigned tot;
     const unsigned incl = cx.scan_incl_u32(v, &tot);
     if (c < L.nCells) cellBase[c] = n + incl - v;
     n += tot;
   }
-  __syncthreads();
+  cx.sync();
   const size_t so = (size_t)f * qtFrameStride + L.candOff;
   const size_t cap = (size_t)L.nCells * P.cellCap;
-  QtGlobal G;
-  G.cand[0] = qtCand + 2 * so;
-  G.cand[1] = G.cand[0] + cap;
-  G.node[0] = qtNode + 2 * so;
-  G.node[1] = G.node[0] + cap;
-  G.sortKeys = qtKeys + so;
-  G.ldsKeys = ldsKeys;
-  G.ldsKeyCap = ldsKeyCap;
+  // Two copies of the algorithm, one over LDS-resident candidates and one over HBM scratch, selected here (not through a
+  // runtime pointer select): the compiler then proves the address space and emits ds_* instead of flat_* for the LDS copy.
+  const bool inLds = (int)n <= ldsCandCap;
+  QtCandT<true> GL{{ldsCand, ldsCand + ldsCandCap}, {ldsNode, ldsNode + ldsCandCap}};
+  QtGlobal GG{{qtCand + 2 * so, qtCand + 2 * so + cap}, {qtNode + 2 * so, qtNode + 2 * so + cap}};
   int nOut = 0;
   if (n > 65535u) {
-    if (threadIdx.x == 0) atomicMax(status, 1);  // more candidates than the packed 16-bit counters allow
+    if (lane == 0) atomicMax(status, 1);  // more candidates than the packed 16-bit counters allow
   } else {
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int c = wv; c < L.nCells; c += kQtThreads / 64) {
+    // one thread per cell: its (few) entries are independent loads
+    for (int c = lane; c < L.nCells; c += kQtThreads) {
       const unsigned m = cnts[c], b = cellBase[c];
       const uint32_t* src = cellCand + ((size_t)f * P.nCellsTotal + L.cellBegin + c) * P.cellCap;
-      for (unsigned i = lane; i < m; i += 64) G.cand[0][b + i] = src[i];
+      if (inLds) { for (unsigned i = 0; i < m; i++) ldsCand[b + i] = src[i]; }
+      else { for (unsigned i = 0; i < m; i++) GG.cand[0][b + i] = src[i]; }
     }
-    __syncthreads();
-    nOut = qt_distribute(cx, S, G, (int)n, L.w - 2 * kBorder, L.h - 2 * kBorder, L.quota, nodeCap,
-                         lvlKp + (size_t)f * P.sumQuota + L.kpOff);
+    cx.sync();
+#if defined(QT_DBG_STOP) && QT_DBG_STOP == 1
+    if (lane == 0) lvlCount[f * kMaxLevels + level] = 0;
+    return;
+#endif
+    uint32_t* outKp = lvlKp + (size_t)f * P.sumQuota + L.kpOff;
+    if (inLds) nOut = qt_distribute(cx, S, GL, (int)n, L.w - 2 * kBorder, L.h - 2 * kBorder, L.quota, nodeCap, outKp);
+    else nOut = qt_distribute(cx, S, GG, (int)n, L.w - 2 * kBorder, L.h - 2 * kBorder, L.quota, nodeCap, outKp);
     if (nOut < 0) {
-      if (threadIdx.x == 0) atomicMax(status, 2);
+      if (lane == 0) atomicMax(status, 2);
       nOut = 0;
     }
   }
-  if (threadIdx.x == 0) lvlCount[f * kMaxLevels + level] = nOut;
+  if (lane == 0) lvlCount[f * kMaxLevels + level] = nOut;
 }
 
 // ------------------------------------------------------------------------------------------------

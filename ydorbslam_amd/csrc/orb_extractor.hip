@@ -30,7 +30,7 @@ struct HostPlan {
   PlanDev dev{};
   std::vector<CellDev> cells;
   size_t pyrFrameStride = 0, blurFrameStride = 0, qtFrameStride = 0;
-  int nodeCap = 0, maxCellsPerLevel = 0, ldsKeyCap = 0;
+  int nodeCap = 0, maxCellsPerLevel = 0, ldsCandCap = 0;
   size_t qtLds = 0;
   std::vector<int> tabInt;      // xofs|yofs per level
   std::vector<short> tabShort;  // alpha|beta per level
@@ -201,9 +201,12 @@ int buildPlan(ydorb_extractor* e, int w, int h, HostPlan& P) {
   for (int l = 0; l < D.nLevels; l++) maxQuota = std::max(maxQuota, D.lv[l].quota);
   P.nodeCap = 4 * maxQuota;
   P.qtLds = (size_t)P.nodeCap * (8 + 8 + 8 + 8 + 4 + 4 + 4 + 4) + (size_t)(P.maxCellsPerLevel + 1) * 4;
-  // sort keys of the best-per-node selection live in LDS up to this many candidates per level (HBM scratch beyond)
-  P.ldsKeyCap = (int)std::min<size_t>(8192, (150 * 1024 > P.qtLds ? (150 * 1024 - P.qtLds) / 4 : 0));
-  P.qtLds += (size_t)P.ldsKeyCap * 4;
+  // a level with up to ldsCandCap FAST candidates keeps its whole candidate state (2 x u32 + 2 x u16 per entry) in LDS
+#ifndef QT_LDSCAP
+#define QT_LDSCAP 2560
+#endif
+  P.ldsCandCap = (int)std::min<size_t>(QT_LDSCAP, (120 * 1024 > P.qtLds ? (120 * 1024 - P.qtLds) / 12 : 0)) / 64 * 64;
+  P.qtLds += (size_t)P.ldsCandCap * 12;
   if (P.qtLds > 150 * 1024) {
     set_error("n_features=%d needs %zu B of LDS for the quad-tree (max 150 KiB)", e->cfg.n_features, P.qtLds);
     return YDORB_ERR_UNSUPPORTED;
@@ -230,7 +233,7 @@ int ensurePlan(ydorb_extractor* e, int w, int h, int nFrames) {
   HIPCHK(hipMalloc(&e->d_cellCand, sizeof(uint32_t) * (size_t)D.nCellsTotal * D.cellCap * B));
   HIPCHK(hipMalloc(&e->d_qtCand, sizeof(uint32_t) * 2 * P.qtFrameStride * B));
   HIPCHK(hipMalloc(&e->d_qtNode, sizeof(uint16_t) * 2 * P.qtFrameStride * B));
-  HIPCHK(hipMalloc(&e->d_qtKeys, sizeof(uint32_t) * P.qtFrameStride * B));
+
   HIPCHK(hipMalloc(&e->d_lvlKp, sizeof(uint32_t) * (size_t)D.sumQuota * B));
   HIPCHK(hipMalloc(&e->d_lvlAngle, sizeof(float) * (size_t)D.sumQuota * B));
   HIPCHK(hipMalloc(&e->d_lvlCount, sizeof(int) * kMaxLevels * B));
@@ -282,7 +285,7 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
                        std::min(std::max(e->cfg.ini_fast_thr, 0), 255), e->d_cellCount, e->d_cellCand);
   if (prof) HIPCHK(hipEventRecord(e->ev[2], s));
   hipLaunchKernelGGL(k_quadtree, dim3(D.nLevels, nFrames), dim3(kQtThreads), P.qtLds, s, D, e->d_cellCount, e->d_cellCand,
-                     e->d_qtCand, e->d_qtNode, e->d_qtKeys, P.qtFrameStride, P.nodeCap, P.ldsKeyCap, e->d_lvlKp, e->d_lvlCount, e->d_status);
+                     e->d_qtCand, e->d_qtNode, P.qtFrameStride, P.nodeCap, P.ldsCandCap, e->d_lvlKp, e->d_lvlCount, e->d_status);
   if (prof) HIPCHK(hipEventRecord(e->ev[3], s));
   {
     int maxTiles = 0;

@@ -55,9 +55,9 @@ YD_HD inline int qt_quadrant(uint32_t c, int cx, int cy) {  // :37-47
 // ---- libstdc++ std::sort(first,last,[](a,b){return a.response>b.response;}) -> index of front() ----
 // keys[i] = (response << 16) | i ; comparison looks at the response only.
 YD_HD inline bool qt_gt(uint32_t a, uint32_t b) { return (a >> 16) > (b >> 16); }
-YD_HD inline void qt_swap(uint32_t* a, int i, int j) { uint32_t t = a[i]; a[i] = a[j]; a[j] = t; }
+template <class P> YD_HD inline void qt_swap(P a, int i, int j) { uint32_t t = a[i]; a[i] = a[j]; a[j] = t; }
 
-YD_HD inline void qt_push_heap(uint32_t* a, int hole, int top, uint32_t v) {
+template <class P> YD_HD inline void qt_push_heap(P a, int hole, int top, uint32_t v) {
   int parent = (hole - 1) / 2;
   while (hole > top && qt_gt(a[parent], v)) {
     a[hole] = a[parent];
@@ -66,7 +66,7 @@ YD_HD inline void qt_push_heap(uint32_t* a, int hole, int top, uint32_t v) {
   }
   a[hole] = v;
 }
-YD_HD inline void qt_adjust_heap(uint32_t* a, int hole, int len, uint32_t v) {
+template <class P> YD_HD inline void qt_adjust_heap(P a, int hole, int len, uint32_t v) {
   const int top = hole;
   int child = hole;
   while (child < (len - 1) / 2) {
@@ -82,7 +82,7 @@ YD_HD inline void qt_adjust_heap(uint32_t* a, int hole, int len, uint32_t v) {
   }
   qt_push_heap(a, hole, top, v);
 }
-YD_HD inline void qt_heap_sort(uint32_t* a, int len) {  // __partial_sort(first,last,last)
+template <class P> YD_HD inline void qt_heap_sort(P a, int len) {  // __partial_sort(first,last,last)
   if (len >= 2) {
     int parent = (len - 2) / 2;
     for (;;) {
@@ -101,7 +101,7 @@ YD_HD inline void qt_heap_sort(uint32_t* a, int len) {  // __partial_sort(first,
   }
 }
 // a[0..m): scratch holding the keys in member order; returns the member index that std::sort leaves at front().
-YD_HD inline int qt_sort_front(uint32_t* a, int m) {
+template <class P> YD_HD inline int qt_sort_front(P a, int m) {
   int hi = m;
   if (m > 16) {
     int depth = 0;
@@ -147,24 +147,32 @@ YD_HD inline int qt_sort_front(uint32_t* a, int m) {
 #ifndef QT_ITEMS
 #define QT_ITEMS 8
 #endif
+// On the device the node table always lives in LDS; typing the pointers with the LDS address space makes every access a
+// ds_* instruction (generic pointers compiled to flat_* loads, which cost global-memory latency even for LDS addresses).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define QT_LDS __attribute__((address_space(3)))
+#else
+#define QT_LDS
+#endif
 struct QtShared {           // LDS (device) / heap (host); arrays of nodeCap entries
-  QtGeom* geom[2];
-  uint32_t* cnt[2];
-  uint32_t* base[2];
-  unsigned long long* cc;   // packed 4x16 child counts; re-used as the segment-start prefix in sweep 2
-  uint16_t* childIdx;       // [nodeCap*4] new list index of child q (slot 0: own new index for a leaf)
+  QT_LDS QtGeom* geom[2];
+  QT_LDS uint32_t* cnt[2];
+  QT_LDS uint32_t* base[2];
+  QT_LDS unsigned long long* cc;   // packed 4x16 child counts; re-used as the segment-start prefix in sweep 2
+  QT_LDS uint16_t* childIdx;       // [nodeCap*4] new list index of child q (slot 0: own new index for a leaf)
 };
-struct QtGlobal {           // per (frame, level) scratch in HBM, n entries each
-  uint32_t* cand[2];
-  uint16_t* node[2];
-  uint32_t* sortKeys;       // n keys for the per-node std::sort replay (HBM fallback)
-  uint32_t* ldsKeys;        // same, in LDS, used when n <= ldsKeyCap (a serial sort over HBM-latency loads was the slowest phase)
-  int ldsKeyCap;
+template <bool InLds> struct QtCandPtr { typedef uint32_t* U32; typedef uint16_t* U16; };
+template <> struct QtCandPtr<true> { typedef QT_LDS uint32_t* U32; typedef QT_LDS uint16_t* U16; };
+template <bool InLds>
+struct QtCandT {            // per (frame, level) candidate state, n entries each: LDS when the level fits, else HBM scratch
+  typename QtCandPtr<InLds>::U32 cand[2];  // ping-pong; after the last pass the idle half holds the keys of the std::sort replay
+  typename QtCandPtr<InLds>::U16 node[2];
 };
+typedef QtCandT<false> QtGlobal;
 
-// Ctx: tid(), nthreads(), sync(), scan_incl_u64(v,&total), scan_incl_u32(v,&total), lds_add_u64(p,v)
-template <class Ctx>
-YD_HD int qt_distribute(Ctx& cx, const QtShared& S, const QtGlobal& G, int n, int rootX1, int rootY1, int quota,
+// Ctx: tid(), nthreads(), sync(), scan_incl_u64(v,&total), scan_incl_u32(v,&total), count_child(cc,k,q) (k < 0: lane idle)
+template <class Ctx, class Cand>
+YD_HD int qt_distribute(Ctx& cx, const QtShared& S, const Cand& G, int n, int rootX1, int rootY1, int quota,
                         int nodeCap, uint32_t* out) {
   const int tid = cx.tid(), nt = cx.nthreads();
   if (n <= 0 || quota <= 0) return 0;  // resize(desired) of an empty or zero-quota list
@@ -180,59 +188,75 @@ YD_HD int qt_distribute(Ctx& cx, const QtShared& S, const QtGlobal& G, int n, in
   while (K > last && K < quota) {
     last = K;
     const int nxt = cur ^ 1;
-    const QtGeom* geom = S.geom[cur];
-    const uint32_t* cnt = S.cnt[cur];
-    const uint32_t* base = S.base[cur];
+    const auto geom = S.geom[cur];
+    const auto cnt = S.cnt[cur];
+    const auto base = S.base[cur];
     for (int k = tid; k < K; k += nt) S.cc[k] = 0;
     cx.sync();
-    // sweep 1: child counts
-    for (int p = tid; p < n; p += nt) {
-      const int k = G.node[cur][p];
-      if (cnt[k] > 1) {
-        const QtGeom g = geom[k];
-        const int q = qt_quadrant(G.cand[cur][p], qt_center(g.x0, g.x1), qt_center(g.y0, g.y1));
-        cx.lds_add_u64(&S.cc[k], 1ull << (16 * q));
+    // sweep 1: child counts.  Candidates of one node are contiguous, so the lanes of a wave mostly hit the same counter:
+    // the context aggregates equal-node lanes with ballots and issues one LDS atomic per (wave, node) instead of 64
+    // same-address atomics (which the LDS serialises).
+    for (int p0 = 0; p0 < n; p0 += nt) {
+      const int p = p0 + tid;
+      int k = -1, q = 0;
+      if (p < n) {
+        const int kk = G.node[cur][p];
+        if (cnt[kk] > 1) {
+          const QtGeom g = geom[kk];
+          q = qt_quadrant(G.cand[cur][p], qt_center(g.x0, g.x1), qt_center(g.y0, g.y1));
+          k = kk;
+        }
       }
+      cx.count_child(S.cc, k, q);
     }
     cx.sync();
-    // node phase A: number of new front nodes M (suffix sums) and rank of leaves
-    // processed in chunks in REVERSE list order so an inclusive prefix scan yields the suffix sum.
-    int M = 0;      // total children created
+    // node phases A/A': each thread owns a contiguous run of `per` nodes, so every phase needs ONE workgroup scan.
+    // A: new front nodes.  Children of LATER list nodes come first -> walk the list in reverse (suffix sum as a prefix).
+    const int per = (K + nt - 1) / nt;
+    int M = 0;
     {
-      int carry = 0;
-      for (int c0 = 0; c0 < K; c0 += nt) {
-        const int kr = c0 + tid;          // reversed index
-        const int k = K - 1 - kr;
-        int m = 0;
-        unsigned long long ccv = 0;
-        if (kr < K && cnt[k] > 1) {
-          ccv = S.cc[k];
-          for (int q = 0; q < 4; q++) m += ((ccv >> (16 * q)) & 0xFFFF) != 0;
-        }
-        unsigned total;
-        const unsigned incl = cx.scan_incl_u32((unsigned)m, &total);
-        if (kr < K && cnt[k] > 1) {
-          int idx = carry + (int)incl - m;  // children of nodes after k come first
-          for (int q = 3; q >= 0; q--) {    // n4 is pushed last -> sits first
-            if ((ccv >> (16 * q)) & 0xFFFF) S.childIdx[k * 4 + q] = (uint16_t)idx++;
+      int mine = 0;
+      for (int j = 0; j < per; j++) {
+        const int kr = tid * per + j;
+        if (kr < K) {
+          const int k = K - 1 - kr;
+          if (cnt[k] > 1) {
+            const unsigned long long ccv = S.cc[k];
+            for (int q = 0; q < 4; q++) mine += ((ccv >> (16 * q)) & 0xFFFF) != 0;
           }
         }
-        carry += (int)total;
       }
-      M = carry;
+      unsigned total;
+      const unsigned incl = cx.scan_incl_u32((unsigned)mine, &total);
+      int idx = (int)incl - mine;
+      for (int j = 0; j < per; j++) {
+        const int kr = tid * per + j;
+        if (kr < K) {
+          const int k = K - 1 - kr;
+          if (cnt[k] > 1) {
+            const unsigned long long ccv = S.cc[k];
+            for (int q = 3; q >= 0; q--)  // n4 is pushed last -> sits first
+              if ((ccv >> (16 * q)) & 0xFFFF) S.childIdx[k * 4 + q] = (uint16_t)idx++;
+          }
+        }
+      }
+      M = (int)total;
     }
     int Knew = M;
-    {
-      int carry = 0;
-      for (int c0 = 0; c0 < K; c0 += nt) {
-        const int k = c0 + tid;
-        const unsigned leaf = (k < K && cnt[k] <= 1) ? 1u : 0u;
-        unsigned total;
-        const unsigned incl = cx.scan_incl_u32(leaf, &total);
-        if (leaf) S.childIdx[k * 4] = (uint16_t)(M + carry + (int)incl - 1);
-        carry += (int)total;
+    {  // A': leaves keep their relative order behind all new nodes
+      int mine = 0;
+      for (int j = 0; j < per; j++) {
+        const int k = tid * per + j;
+        if (k < K && cnt[k] <= 1) mine++;
       }
-      Knew += carry;
+      unsigned total;
+      const unsigned incl = cx.scan_incl_u32((unsigned)mine, &total);
+      int idx = M + (int)incl - mine;
+      for (int j = 0; j < per; j++) {
+        const int k = tid * per + j;
+        if (k < K && cnt[k] <= 1) S.childIdx[k * 4] = (uint16_t)idx++;
+      }
+      Knew += (int)total;
     }
     if (Knew > nodeCap) return -1;  // cannot happen for nodeCap >= 4*quota
     cx.sync();
@@ -259,14 +283,18 @@ YD_HD int qt_distribute(Ctx& cx, const QtShared& S, const QtGlobal& G, int n, in
     cx.sync();
     // node phase C: segment bases of the new list (exclusive scan of counts in new list order)
     {
-      unsigned carry = 0;
-      for (int c0 = 0; c0 < Knew; c0 += nt) {
-        const int k = c0 + tid;
-        const unsigned v = k < Knew ? S.cnt[nxt][k] : 0u;
-        unsigned total;
-        const unsigned incl = cx.scan_incl_u32(v, &total);
-        if (k < Knew) S.base[nxt][k] = carry + incl - v;
-        carry += total;
+      const int perN = (Knew + nt - 1) / nt;
+      unsigned mine = 0;
+      for (int j = 0; j < perN; j++) {
+        const int k = tid * perN + j;
+        if (k < Knew) mine += S.cnt[nxt][k];
+      }
+      unsigned total;
+      const unsigned incl = cx.scan_incl_u32(mine, &total);
+      unsigned run = incl - mine;
+      for (int j = 0; j < perN; j++) {
+        const int k = tid * perN + j;
+        if (k < Knew) { S.base[nxt][k] = run; run += S.cnt[nxt][k]; }
       }
     }
     cx.sync();
@@ -333,16 +361,19 @@ YD_HD int qt_distribute(Ctx& cx, const QtShared& S, const QtGlobal& G, int n, in
   }
   // best keypoint per node, list order, truncated to the quota (:534-543)
   const int nOut = K < quota ? K : quota;
-  uint32_t* keysAll = n <= G.ldsKeyCap ? G.ldsKeys : G.sortKeys;
+#if defined(QT_DBG_STOP) && QT_DBG_STOP == 2
+  return 0;
+#endif
+  const auto keysAll = G.cand[cur ^ 1];
   {  // keys of every candidate, segment-relative index in the low half: filled by all threads, coalesced
-    const uint16_t* nodeOf = G.node[cur];
-    const uint32_t* cd = G.cand[cur];
+    const auto nodeOf = G.node[cur];
+    const auto cd = G.cand[cur];
     for (int p = tid; p < n; p += nt) keysAll[p] = ((uint32_t)qt_r(cd[p]) << 16) | ((uint32_t)p - S.base[cur][nodeOf[p]]);
   }
   cx.sync();
   for (int k = tid; k < nOut; k += nt) {
     const uint32_t b = S.base[cur][k], m = S.cnt[cur][k];
-    uint32_t* keys = keysAll + b;
+    const auto keys = keysAll + b;
     int best = 0;
     if (m > 16) {
       best = qt_sort_front(keys, (int)m);
