@@ -56,57 +56,102 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // Pyramid level 0: copyMakeBorder(image, 19 px, BORDER_REFLECT_101)  (orbExtractor.cpp:618).
 // One thread writes 4 consecutive bytes of the padded buffer.
 // ------------------------------------------------------------------------------------------------
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+typedef unsigned long long __attribute__((aligned(1))) u64_unaligned;
+
+// Workgroup = 64 x 4 threads; a thread writes one dword (4 px) in each of kPyrRows consecutive rows, so a workgroup covers
+// 256 B x 16 rows and the per-column tables are loaded once per thread (one-row workgroups were dispatch-bound).
+constexpr int kPyrRows = 4;
 __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ img, int stride, size_t frameStride,
                                                     uint8_t* __restrict__ pyr, size_t pyrFrameStride, LevelDev L) {
-  const int wx = blockIdx.x * 256 + threadIdx.x;
-  const int y = blockIdx.y;
+  const int wx = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int yb = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kPyrRows;
   if (wx * 4 >= L.pitch) return;
   const uint8_t* src = img + (size_t)blockIdx.z * frameStride;
-  const int sy = reflect101(y - kPad, L.h);
-  uint32_t v = 0;
+  uint8_t* dst = pyr + (size_t)blockIdx.z * pyrFrameStride + L.padOff + wx * 4;
+  const int x0 = wx * 4 - kPad;
+  const bool interior = x0 >= 0 && x0 + 3 < L.w;
+  int rx[4];
 #pragma unroll
-  for (int b = 0; b < 4; b++) {
-    const int x = wx * 4 + b - kPad;
-    if (x < L.w + kPad) v |= (uint32_t)src[(size_t)sy * stride + reflect101(x, L.w)] << (8 * b);
+  for (int b = 0; b < 4; b++) rx[b] = x0 + b < L.w + kPad ? reflect101(x0 + b, L.w) : -1;
+#pragma unroll
+  for (int r = 0; r < kPyrRows; r++) {
+    const int y = yb + r;
+    if (y >= L.h + 2 * kPad) break;
+    const uint8_t* row = src + (size_t)reflect101(y - kPad, L.h) * stride;
+    uint32_t v = 0;
+    if (interior) {
+      v = *reinterpret_cast<const u32_unaligned*>(row + x0);
+    } else {
+#pragma unroll
+      for (int b = 0; b < 4; b++)
+        if (rx[b] >= 0) v |= (uint32_t)row[rx[b]] << (8 * b);
+    }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)y * L.pitch) = v;
   }
-  *reinterpret_cast<uint32_t*>(pyr + (size_t)blockIdx.z * pyrFrameStride + L.padOff + (size_t)y * L.pitch + wx * 4) = v;
 }
 
 // ------------------------------------------------------------------------------------------------
 // Pyramid level l>=1: cv::resize(level l-1, INTER_LINEAR) + reflect-101 border (orbExtractor.cpp:614-615).
 // Border pixels are recomputed from the reflected interior coordinate instead of re-read, so the level
 // is written exactly once.  Coefficient tables (11-bit fixed point) are built on the host.
+// Interior fast path: the 4 outputs of a thread read source columns sx[0] .. sx[3]+1, at most 8 consecutive bytes for
+// scale factors <= 2, fetched as one unaligned 8-byte load per source row.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, size_t pyrFrameStride, LevelDev Lp, LevelDev L,
                                                     const int* __restrict__ xofs, const short* __restrict__ alpha,
                                                     const int* __restrict__ yofs, const short* __restrict__ beta) {
-  const int wx = blockIdx.x * 256 + threadIdx.x;
-  const int y = blockIdx.y;
+  const int wx = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int yb = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kPyrRows;
   if (wx * 4 >= L.pitch) return;
   uint8_t* frame = pyr + (size_t)blockIdx.z * pyrFrameStride;
   const uint8_t* S = frame + Lp.padOff + (size_t)kPad * Lp.pitch + kPad;  // ROI origin of the source level
-  const int dy = reflect101(y - kPad, L.h);
-  const int sy = yofs[dy];
-  const int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
-  const int sy0 = min(max(sy, 0), Lp.h - 1), sy1 = min(max(sy + 1, 0), Lp.h - 1);
-  const uint8_t* r0p = S + (size_t)sy0 * Lp.pitch;
-  const uint8_t* r1p = S + (size_t)sy1 * Lp.pitch;
-  uint32_t v = 0;
+  uint8_t* dst = frame + L.padOff + wx * 4;
+  const int x0 = wx * 4 - kPad;
+  int sx[4], sx1[4], a0[4], a1[4];
 #pragma unroll
   for (int b = 0; b < 4; b++) {
-    const int x = wx * 4 + b - kPad;
-    if (x < L.w + kPad) {
-      const int dx = reflect101(x, L.w);
-      const int sx = xofs[dx];
-      const int a0 = alpha[2 * dx], a1 = alpha[2 * dx + 1];
-      const int sx1 = min(sx + 1, Lp.w - 1);  // a1 == 0 whenever sx+1 is outside
-      const int h0 = r0p[sx] * a0 + r0p[sx1] * a1;
-      const int h1 = r1p[sx] * a0 + r1p[sx1] * a1;
-      const int o = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-      v |= (uint32_t)(o & 0xFF) << (8 * b);
+    sx[b] = -1; sx1[b] = 0; a0[b] = 0; a1[b] = 0;
+    if (x0 + b < L.w + kPad) {
+      const int dx = reflect101(x0 + b, L.w);
+      sx[b] = xofs[dx]; a0[b] = alpha[2 * dx]; a1[b] = alpha[2 * dx + 1];
+      sx1[b] = min(sx[b] + 1, Lp.w - 1);   // a1 == 0 whenever sx+1 is outside
     }
   }
-  *reinterpret_cast<uint32_t*>(frame + L.padOff + (size_t)y * L.pitch + wx * 4) = v;
+  const bool fast = x0 >= 0 && x0 + 3 < L.w && sx[3] - sx[0] <= 6 && sx[0] + 7 < Lp.w + kPad;
+#pragma unroll
+  for (int r = 0; r < kPyrRows; r++) {
+    const int y = yb + r;
+    if (y >= L.h + 2 * kPad) break;
+    const int dy = reflect101(y - kPad, L.h);
+    const int sy = yofs[dy];
+    const int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+    const uint8_t* r0p = S + (size_t)min(max(sy, 0), Lp.h - 1) * Lp.pitch;
+    const uint8_t* r1p = S + (size_t)min(max(sy + 1, 0), Lp.h - 1) * Lp.pitch;
+    uint32_t v = 0;
+    if (fast) {
+      const unsigned long long w0 = *reinterpret_cast<const u64_unaligned*>(r0p + sx[0]);
+      const unsigned long long w1 = *reinterpret_cast<const u64_unaligned*>(r1p + sx[0]);
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int sh = 8 * (sx[b] - sx[0]);
+        const int h0 = (int)((w0 >> sh) & 255) * a0[b] + (int)((w0 >> (sh + 8)) & 255) * a1[b];
+        const int h1 = (int)((w1 >> sh) & 255) * a0[b] + (int)((w1 >> (sh + 8)) & 255) * a1[b];
+        const int o = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        v |= (uint32_t)(o & 0xFF) << (8 * b);
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < 4; b++)
+        if (sx[b] >= 0) {
+          const int h0 = r0p[sx[b]] * a0[b] + r0p[sx1[b]] * a1[b];
+          const int h1 = r1p[sx[b]] * a0[b] + r1p[sx1[b]] * a1[b];
+          const int o = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+          v |= (uint32_t)(o & 0xFF) << (8 * b);
+        }
+    }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)y * L.pitch) = v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -269,11 +269,11 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   if (prof) HIPCHK(hipEventRecord(e->ev[0], s));
   {
     const LevelDev& L0 = D.lv[0];
-    dim3 g((L0.pitch / 4 + 255) / 256, L0.h + 2 * kPad, nFrames);
+    dim3 g((L0.pitch / 4 + 63) / 64, (L0.h + 2 * kPad + 4 * kPyrRows - 1) / (4 * kPyrRows), nFrames);
     hipLaunchKernelGGL(k_pyr_level0, g, dim3(256), 0, s, d_img, stride, frameStride, e->d_pyr, P.pyrFrameStride, L0);
     for (int l = 1; l < D.nLevels; l++) {
       const LevelDev& L = D.lv[l];
-      dim3 gl((L.pitch / 4 + 255) / 256, L.h + 2 * kPad, nFrames);
+      dim3 gl((L.pitch / 4 + 63) / 64, (L.h + 2 * kPad + 4 * kPyrRows - 1) / (4 * kPyrRows), nFrames);
       hipLaunchKernelGGL(k_pyr_resize, gl, dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, D.lv[l - 1], L,
                          e->d_tabInt + P.tab[l].xofs, e->d_tabShort + P.tab[l].alpha, e->d_tabInt + P.tab[l].yofs,
                          e->d_tabShort + P.tab[l].beta);
