@@ -306,22 +306,6 @@ __global__ __launch_bounds__(256) void k_max_diag(const R* __restrict__ Hpp, int
   if (threadIdx.x == 0) out[slot] = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
 }
 
-// S <- blockdiag(Hpp) + lambda*I (dense n x n, n = padded 6*nP; identity on the padding), bs <- bp
-// contrib = 1 on a single GPU; with landmark sharding only rank 0 passes 1 so the all-reduced sum holds Hpp, lambda and bp once.
-__global__ __launch_bounds__(256) void k_schur_init(const R* __restrict__ Hpp, const R* __restrict__ bp, int nP, int n, R lambda, R contrib,
-                                                    R* __restrict__ S, R* __restrict__ bs) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)n * n) return;
-  const int r = (int)(idx / n), c = (int)(idx % n);
-  R v = 0;
-  if (r < 6 * nP && c < 6 * nP) {
-    if (r / 6 == c / 6) v = Hpp[(size_t)36 * (r / 6) + (r % 6) * 6 + (c % 6)];
-    if (r == c) v += lambda;
-  } else if (r == c) v = 1;
-  S[idx] = v * contrib;
-  if (c == 0) bs[r] = r < 6 * nP ? bp[r] * contrib : 0;
-}
-
 // D^-1 = (Hll + lambda I)^-1 (Eigen cofactor inverse, block_solver.hpp:350) and db = D^-1 b_l, per landmark
 __global__ __launch_bounds__(256) void k_dinv(const R* __restrict__ Hll, const R* __restrict__ bl, int nL, R lambda, R* __restrict__ Dinv,
                                               R* __restrict__ db) {
@@ -340,178 +324,385 @@ __global__ __launch_bounds__(256) void k_dinv(const R* __restrict__ Hll, const R
   db[3 * l + 2] = o[2] * b0 + o[4] * b1 + o[5] * b2;
 }
 
-// Schur complement (block_solver.hpp:342-393): thread = one observation (landmark l, free pose i1); it subtracts
-// (B_i1 D^-1) B_i2^T for every observation i2 >= i1 of the same landmark into the LOWER triangle of S
-// (block row i2, block column i1, transposed) and (B_i1 D^-1 b_l) from bs.  FP64 atomics: addends commute only up
-// to rounding, which is inside the BA tolerance (the reference's own sum order is heap-address dependent).
-__global__ __launch_bounds__(256) void k_schur(EdgeSoA Ed, const int* __restrict__ ptStart, const int* __restrict__ edgeLm,
-                                               const R* __restrict__ Hpl, const R* __restrict__ Dinv, const R* __restrict__ db, int n,
-                                               R* __restrict__ S, R* __restrict__ bs) {
+// ---- Schur complement (block_solver.hpp:342-393) without atomics ---------------------------------------------------
+// S(i2,i1) = [i1==i2](Hpp_i1 + lambda I) - sum over landmarks seen by both poses of  B_i2 D^-1 B_i1^T   (lower triangle, i2 >= i1).
+// The contributions are bucketed ONCE per optimize() by pose pair (the graph structure does not change between LM trials):
+// k_pair_count / k_pair_fill / k_pair_sort build, for every pose pair, the list of (edge of i1, edge of i2) of the landmarks
+// they share, ordered by landmark.  Per trial one wave owns one 6x6 block and walks its list: 36 lanes = 36 entries, no
+// reduction, no atomics, fixed summation order (the first version issued 13 M FP64 atomics per trial: 0.87 ms).
+__device__ __forceinline__ int pair_bucket(int i1, int i2) { return i2 * (i2 + 1) / 2 + i1; }  // i2 >= i1
+
+__global__ __launch_bounds__(256) void k_pair_count(EdgeSoA Ed, const int* __restrict__ ptStart, int nL, int* __restrict__ cnt) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= nL) return;
+  for (int a = ptStart[l]; a < ptStart[l + 1]; a++) {
+    const int i1 = Ed.pidx[a];
+    if (i1 < 0) continue;
+    for (int b = a; b < ptStart[l + 1]; b++) {
+      const int i2 = Ed.pidx[b];  // edges of a landmark are sorted by pose index: i2 >= i1
+      if (i2 >= 0) atomicAdd(&cnt[pair_bucket(i1, i2)], 1);
+    }
+  }
+}
+// exclusive scan of n ints by one workgroup: out[0..n], out[n] = total
+__global__ __launch_bounds__(256) void k_excl_scan(const int* __restrict__ in, int n, int* __restrict__ out) {
+  __shared__ int wsum[4];
+  __shared__ int carryS;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carryS = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < n; c0 += 256) {
+    const int i = c0 + threadIdx.x;
+    const int v = i < n ? in[i] : 0;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+    if (lane == 63) wsum[wv] = x;
+    __syncthreads();
+    int off = carryS;
+    for (int j = 0; j < wv; j++) off += wsum[j];
+    if (i < n) out[i] = off + x - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carryS += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[n] = carryS;
+}
+__global__ __launch_bounds__(256) void k_pair_fill(EdgeSoA Ed, const int* __restrict__ ptStart, int nL, int* __restrict__ cursor,
+                                                   int2* __restrict__ items) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= nL) return;
+  for (int a = ptStart[l]; a < ptStart[l + 1]; a++) {
+    const int i1 = Ed.pidx[a];
+    if (i1 < 0) continue;
+    for (int b = a; b < ptStart[l + 1]; b++) {
+      const int i2 = Ed.pidx[b];
+      if (i2 >= 0) items[atomicAdd(&cursor[pair_bucket(i1, i2)], 1)] = make_int2(a, b);
+    }
+  }
+}
+// order every bucket by its first edge index (== by landmark): rank sort from LDS, one wave per bucket, out of place.
+// Buckets with more than kSortCap entries are copied unsorted (their summation order is then not reproducible run to run).
+constexpr int kSortCap = 512;
+__global__ __launch_bounds__(256) void k_pair_sort(const int* __restrict__ start, int nBuckets, const int2* __restrict__ in,
+                                                   int2* __restrict__ out) {
+  __shared__ int keys[4][kSortCap];
+  const int wv = threadIdx.x >> 6, bkt = blockIdx.x * 4 + wv, lane = threadIdx.x & 63;
+  if (bkt >= nBuckets) return;
+  const int s0 = start[bkt], m = start[bkt + 1] - s0;
+  if (m > kSortCap) {
+    for (int t = lane; t < m; t += 64) out[s0 + t] = in[s0 + t];
+    return;
+  }
+  for (int t = lane; t < m; t += 64) keys[wv][t] = in[s0 + t].x;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int t = lane; t < m; t += 64) {
+    const int2 it = in[s0 + t];
+    int rank = 0;
+    for (int u = 0; u < m; u++) rank += keys[wv][u] < it.x;
+    out[s0 + rank] = it;
+  }
+}
+// BD_e = Hpl_e D^-1 (6x3) for every observation of a free pose
+__global__ __launch_bounds__(256) void k_bd(EdgeSoA Ed, const int* __restrict__ edgeLm, const R* __restrict__ Hpl, const R* __restrict__ Dinv,
+                                            R* __restrict__ BD) {
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= Ed.n) return;
-  const int i1 = Ed.pidx[e];
-  if (i1 < 0) return;
-  const int l = edgeLm[e];
-  const R* di = Dinv + (size_t)6 * l;
-  const R* Bi = Hpl + (size_t)18 * e;
-  R BD[6][3];
+  if (e >= Ed.n || Ed.pidx[e] < 0) return;
+  const R* di = Dinv + (size_t)6 * edgeLm[e];
+  const R* B = Hpl + (size_t)18 * e;
+  R* o = BD + (size_t)18 * e;
 #pragma unroll
   for (int r = 0; r < 6; r++) {
-    BD[r][0] = Bi[r * 3] * di[0] + Bi[r * 3 + 1] * di[1] + Bi[r * 3 + 2] * di[2];
-    BD[r][1] = Bi[r * 3] * di[1] + Bi[r * 3 + 1] * di[3] + Bi[r * 3 + 2] * di[4];
-    BD[r][2] = Bi[r * 3] * di[2] + Bi[r * 3 + 1] * di[4] + Bi[r * 3 + 2] * di[5];
-    const R cf = Bi[r * 3] * db[3 * l] + Bi[r * 3 + 1] * db[3 * l + 1] + Bi[r * 3 + 2] * db[3 * l + 2];
-    unsafeAtomicAdd(&bs[6 * i1 + r], -cf);
+    o[r * 3] = B[r * 3] * di[0] + B[r * 3 + 1] * di[1] + B[r * 3 + 2] * di[2];
+    o[r * 3 + 1] = B[r * 3] * di[1] + B[r * 3 + 1] * di[3] + B[r * 3 + 2] * di[4];
+    o[r * 3 + 2] = B[r * 3] * di[2] + B[r * 3 + 1] * di[4] + B[r * 3 + 2] * di[5];
   }
-  for (int e2 = e; e2 < ptStart[l + 1]; e2++) {
-    const int i2 = Ed.pidx[e2];
-    if (i2 < 0) continue;
-    const R* Bj = Hpl + (size_t)18 * e2;
+}
+// bs_i = contrib * bp_i - sum over the observations e of pose i of Hpl_e (D^-1 b_l)   (one workgroup per free pose)
+__global__ __launch_bounds__(256) void k_bs(EdgeSoA Ed, const int* __restrict__ poseStart, const int* __restrict__ poseEdges,
+                                            const int* __restrict__ edgeLm, const R* __restrict__ Hpl, const R* __restrict__ db,
+                                            const R* __restrict__ bp, R contrib, R* __restrict__ bs) {
+  __shared__ R part[4][6];
+  const int i = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  R acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int j = poseStart[i] + threadIdx.x; j < poseStart[i + 1]; j += 256) {
+    const int e = poseEdges[j];
+    const R* B = Hpl + (size_t)18 * e;
+    const R* d = db + (size_t)3 * edgeLm[e];
 #pragma unroll
-    for (int q = 0; q < 6; q++) {
-      const R b0 = Bj[q * 3], b1 = Bj[q * 3 + 1], b2 = Bj[q * 3 + 2];
+    for (int r = 0; r < 6; r++) acc[r] += B[r * 3] * d[0] + B[r * 3 + 1] * d[1] + B[r * 3 + 2] * d[2];
+  }
 #pragma unroll
-      for (int r = 0; r < 6; r++) {
-        const R v = BD[r][0] * b0 + BD[r][1] * b1 + BD[r][2] * b2;
-        unsafeAtomicAdd(&S[(size_t)(6 * i2 + q) * n + 6 * i1 + r], -v);
+  for (int r = 0; r < 6; r++) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc[r] += __shfl_xor(acc[r], o, 64);
+    if (lane == 0) part[wv][r] = acc[r];
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) bs[6 * i + threadIdx.x] = contrib * bp[6 * i + threadIdx.x] - (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+// One wave per lower 6x6 block (i2 >= i1); the last workgroup also writes the identity padding of S and bs.
+// The block is the contraction  [Hpl_b rows q | 3m columns] x [BD_a rows r | 3m columns]^T  over the m landmarks the two poses
+// share: it runs on the FP64 matrix core, v_mfma_f64_16x16x4_f64 (A[i = lane&15][k = lane>>4], B[k][j = lane&15],
+// D col = lane&15, row = (lane>>4) + 4*reg; rows/cols >= 6 are fed zeros), four k-columns per instruction, items of a
+// 64-item chunk handed to the lanes by ds_bpermute so no load depends on another load.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_schur_pairs(const int* __restrict__ start, const int2* __restrict__ items, int nP, int nBuckets,
+                                                     const R* __restrict__ BD, const R* __restrict__ Hpl, const R* __restrict__ Hpp, R lambda,
+                                                     R contrib, int n, R* __restrict__ S, R* __restrict__ bs) {
+  const int bkt = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (bkt >= nBuckets) {
+    if (blockIdx.x == gridDim.x - 1) {  // padding rows/cols 6 nP .. n-1: identity (scaled like the rest for the all-reduce)
+      for (int idx = threadIdx.x; idx < (n - 6 * nP) * n; idx += 256) {
+        const int r = 6 * nP + idx / n, c = idx % n;
+        if (c <= r) S[(size_t)r * n + c] = r == c ? contrib : 0.0;
+      }
+      for (int r = 6 * nP + threadIdx.x; r < n; r += 256) bs[r] = 0;
+    }
+    return;
+  }
+  int i2 = (int)((sqrt(8.0 * bkt + 1.0) - 1.0) * 0.5);
+  while ((i2 + 1) * (i2 + 2) / 2 <= bkt) i2++;
+  while (i2 * (i2 + 1) / 2 > bkt) i2--;
+  const int i1 = bkt - i2 * (i2 + 1) / 2;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const bool live = i16 < 6;
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  const int s0 = start[bkt], s1 = start[bkt + 1];
+  for (int chunk = s0; chunk < s1; chunk += 64) {
+    const int cnt = min(64, s1 - chunk);
+    const int2 it = lane < cnt ? items[chunk + lane] : make_int2(0, 0);
+    const int nk = 3 * cnt;
+#pragma unroll 4
+    for (int kk0 = 0; kk0 < nk; kk0 += 4) {
+      const int kk = kk0 + kq;
+      const int t = kk / 3, c = kk - 3 * t;
+      const int ea = __shfl(it.x, t & 63, 64), eb = __shfl(it.y, t & 63, 64);
+      R a = 0.0, b = 0.0;
+      if (live && kk < nk) {
+        a = Hpl[(size_t)18 * eb + i16 * 3 + c];
+        b = BD[(size_t)18 * ea + i16 * 3 + c];
+      }
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+      const int q = kq + 4 * reg, r = i16;
+      if (q < 6) {
+        R v = -acc[reg];
+        if (i1 == i2) v += contrib * (Hpp[(size_t)36 * i1 + q * 6 + r] + (q == r ? lambda : 0.0));
+        S[(size_t)(6 * i2 + q) * n + 6 * i1 + r] = v;
       }
     }
   }
 }
 
-// ---- dense blocked left-looking Cholesky of S (n multiple of 32, lower triangle, row-major) -----------------
-// Launch kb: workgroup r handles tile (block row kb + r, block column kb).  Every workgroup recomputes the
-// 32x32 diagonal tile, factorises it in LDS, and (r > 0) solves its own tile against it, so a block column needs
-// one launch and no inter-workgroup hand-off.  status[0] is set when a pivot is not positive
-// (LinearSolverEigen reports failure -> the LM step is rejected, linear_solver_eigen.h:118-126).
+// ---- dense blocked right-looking Cholesky of S (n multiple of 32, lower triangle, row-major) ----------------------
+// Launch kb (0 .. nb-1) has one workgroup per tile (i >= j >= kb) of the trailing lower triangle:
+//   * every tile first applies the rank-32 update of the previous panel:  A(i,j) -= L(i,kb-1) L(j,kb-1)^T ;
+//   * tiles of column kb then factor the panel: each recomputes the updated 32x32 diagonal tile (one extra rank-32 update),
+//     factors it with a single wave in LDS (no workgroup barriers inside the 32 pivot steps) and solves its own tile against it;
+//   * workgroup (kb,kb) stores the diagonal factor and its inverse in diagL / diagInv (S's own diagonal tile is left untouched
+//     because the other workgroups of the column still read it).
+// All (nb-kb)(nb-kb+1)/2 tiles of a launch run in parallel (the first, left-looking version kept <= 19 workgroups busy and took
+// 19 x 68 us).  status[0] is set when a pivot is not positive (LinearSolverEigen reports failure -> the LM step is rejected,
+// linear_solver_eigen.h:118-126).
 constexpr int NB = 32;
-__global__ __launch_bounds__(256) void k_chol_panel(R* __restrict__ S, R* __restrict__ diagL, int n, int kb, int* __restrict__ status) {
-  __shared__ R Dg[NB][NB + 1];   // diagonal tile / its factor
-  __shared__ R Tl[NB][NB + 1];   // this workgroup's tile
-  __shared__ R La[NB][NB + 1];   // staged L[rowblk, j]
-  __shared__ R Lb[NB][NB + 1];   // staged L[kb, j]
-  const int tid = threadIdx.x, tr = tid >> 3, tc4 = (tid & 7) * 4;  // thread -> row tr, columns tc4..tc4+3
-  const int rb = kb + blockIdx.x;
-  const bool own = blockIdx.x > 0;
-  R accD[4], accT[4];
+constexpr int NBP = NB + 1;
+
+// LL^T of the lower part of D (LDS, [NB][NBP]) by ONE wave; returns false on a non-positive pivot.
+// Lane i (< 32) keeps row i in 32 registers (all loops fully unrolled, so every index is a compile-time constant); per pivot
+// step the scaled column goes through a 32-entry LDS vector that every lane reads back with independent (pipelined)
+// broadcast loads.  The first version updated the trailing block element-by-element in LDS: ~30 us per tile.
+__device__ __forceinline__ bool potrf_wave(R (*D)[NBP], R* col, int lane) {
+  const int i = lane & 31;
+  R a[NB];
+#pragma unroll
+  for (int c = 0; c < NB; c++) a[c] = D[i][c];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < NB; j++) {
+    const R d = __shfl(a[j], j, 64);   // pivot: element (j, j) lives in lane j
+    if (!(d > 0)) ok = false;
+    const R sd = sqrt(d);
+    const R lij = i == j ? sd : a[j] / sd;   // rows i < j hold stale values in a[j]; they are never used again
+    a[j] = lij;
+    if (lane < NB) col[i] = lij;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = j + 1; c < NB; c++) a[c] -= lij * col[c];   // only c <= i matters; the rest is never read
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane < NB) {
+#pragma unroll
+    for (int c = 0; c < NB; c++) D[i][c] = c <= i ? a[c] : 0.0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return ok;
+}
+
+__device__ __forceinline__ int tri_index(int t, int* row) {  // t -> (row, col) of a packed lower triangle, row-major
+  int r = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+  while ((r + 1) * (r + 2) / 2 <= t) r++;
+  while (r * (r + 1) / 2 > t) r--;
+  *row = r;
+  return t - r * (r + 1) / 2;
+}
+
+__global__ __launch_bounds__(256) void k_chol_step(R* __restrict__ S, R* __restrict__ diagL, R* __restrict__ diagInv, int n, int kb,
+                                                   int* __restrict__ status) {
+  __shared__ R Ta[NB][NBP];   // this tile
+  __shared__ R Dg[NB][NBP];   // diagonal tile of the panel (panel workgroups only)
+  __shared__ R La[NB][NBP];   // L(i, kb-1)
+  __shared__ R Lb[NB][NBP];   // L(j, kb-1)
+  __shared__ R Lk[NB][NBP];   // L(kb, kb-1)
+  __shared__ R colv[NB];
+  __shared__ int sOk;
+  const int tid = threadIdx.x, tr = tid >> 3, tc4 = (tid & 7) * 4;
+  int ri;
+  const int cj = tri_index(blockIdx.x, &ri);
+  const int i = kb + ri, j = kb + cj;          // tile (i, j), i >= j >= kb
+  const bool panel = j == kb;
+  R acc[4], accD[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int c = 0; c < 4; c++) {
-    accD[c] = S[(size_t)(kb * NB + tr) * n + kb * NB + tc4 + c];
-    accT[c] = own ? S[(size_t)(rb * NB + tr) * n + kb * NB + tc4 + c] : 0;
+    acc[c] = S[(size_t)(i * NB + tr) * n + j * NB + tc4 + c];
+    if (panel) accD[c] = S[(size_t)(kb * NB + tr) * n + kb * NB + tc4 + c];
   }
-  for (int j = 0; j < kb; j++) {
-    __syncthreads();
+  if (kb > 0) {
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-      Lb[tr][tc4 + c] = S[(size_t)(kb * NB + tr) * n + j * NB + tc4 + c];
-      if (own) La[tr][tc4 + c] = S[(size_t)(rb * NB + tr) * n + j * NB + tc4 + c];
+      La[tr][tc4 + c] = S[(size_t)(i * NB + tr) * n + (kb - 1) * NB + tc4 + c];
+      Lb[tr][tc4 + c] = S[(size_t)(j * NB + tr) * n + (kb - 1) * NB + tc4 + c];
+      if (panel) Lk[tr][tc4 + c] = S[(size_t)(kb * NB + tr) * n + (kb - 1) * NB + tc4 + c];
     }
     __syncthreads();
 #pragma unroll 8
     for (int k = 0; k < NB; k++) {
-      const R lbk = Lb[tr][k], lak = own ? La[tr][k] : 0;
+      const R a = La[tr][k];
 #pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const R lc = Lb[tc4 + c][k];
-        accD[c] -= lbk * lc;
-        accT[c] -= lak * lc;
+      for (int c = 0; c < 4; c++) acc[c] -= a * Lb[tc4 + c][k];
+    }
+    if (panel) {
+#pragma unroll 8
+      for (int k = 0; k < NB; k++) {
+        const R a = Lk[tr][k];
+#pragma unroll
+        for (int c = 0; c < 4; c++) accD[c] -= a * Lk[tc4 + c][k];
       }
     }
   }
-  __syncthreads();
+  if (!panel) {
 #pragma unroll
-  for (int c = 0; c < 4; c++) { Dg[tr][tc4 + c] = accD[c]; Tl[tr][tc4 + c] = accT[c]; }
-  __syncthreads();
-  // unblocked LL^T of the diagonal tile (lower part of Dg)
-  for (int j = 0; j < NB; j++) {
-    const R d = Dg[j][j];
-    __syncthreads();
-    if (!(d > 0)) {
-      if (tid == 0) atomicMax(status, 1);
-      return;
-    }
-    const R sd = sqrt(d);
-    if (tid < NB) {
-      if (tid == j) Dg[j][j] = sd;
-      else if (tid > j) Dg[tid][j] = Dg[tid][j] / sd;
-    }
-    __syncthreads();
-    // trailing update: rows i > j, cols j < c <= i
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-      const int i = idx >> 5, c = idx & 31;
-      if (i > j && c > j && c <= i) Dg[i][c] -= Dg[i][j] * Dg[c][j];
-    }
-    __syncthreads();
-  }
-  if (!own) {  // the factor of the diagonal tile lives in diagL: S's own diagonal tile is still being read by the other workgroups
-#pragma unroll
-    for (int c = 0; c < 4; c++) diagL[(size_t)kb * NB * NB + tr * NB + tc4 + c] = tc4 + c <= tr ? Dg[tr][tc4 + c] : 0;
+    for (int c = 0; c < 4; c++) S[(size_t)(i * NB + tr) * n + j * NB + tc4 + c] = acc[c];
     return;
   }
-  // X * Lkk^T = T  ->  row-wise forward substitution, one thread per row of the tile
-  if (tid < NB) {
-    for (int c = 0; c < NB; c++) {
-      R s = Tl[tid][c];
-      for (int k = 0; k < c; k++) s -= Tl[tid][k] * Dg[c][k];
-      Tl[tid][c] = s / Dg[c][c];
-    }
+#pragma unroll
+  for (int c = 0; c < 4; c++) { Ta[tr][tc4 + c] = acc[c]; Dg[tr][tc4 + c] = accD[c]; }
+  __syncthreads();
+  if (tid < 64) {
+    const bool ok = potrf_wave(Dg, colv, tid);
+    if (tid == 0) sOk = ok ? 1 : 0;
   }
   __syncthreads();
+  if (!sOk) {
+    if (tid == 0) atomicMax(status, 1);
+    return;
+  }
+  // inverse of the diagonal factor (column c by lane c: forward substitution on e_c), kept in LDS: the panel solve
+  // X L_kk^T = T then is a 32x32x32 product X = T * Linv^T on all 256 threads instead of 32 serial substitutions
+  if (tid < NB) {
+    const int c = tid;
+    R z[NB];
 #pragma unroll
-  for (int c = 0; c < 4; c++) S[(size_t)(rb * NB + tr) * n + kb * NB + tc4 + c] = Tl[tr][tc4 + c];
+    for (int r = 0; r < NB; r++) {
+      R s = r == c ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < NB; k++) if (k < r) s -= Dg[r][k] * z[k];
+      z[r] = r < c ? 0.0 : s / Dg[r][r];
+    }
+#pragma unroll
+    for (int r = 0; r < NB; r++) La[r][c] = z[r];   // La is free after the update: La = Linv
+  }
+  __syncthreads();
+  if (i == kb) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      diagL[(size_t)kb * NB * NB + tr * NB + tc4 + c] = tc4 + c <= tr ? Dg[tr][tc4 + c] : 0;
+      diagInv[(size_t)kb * NB * NB + tr * NB + tc4 + c] = La[tr][tc4 + c];
+    }
+    return;
+  }
+  R xo[4] = {0, 0, 0, 0};
+#pragma unroll 8
+  for (int k = 0; k < NB; k++) {
+    const R t = Ta[tr][k];
+#pragma unroll
+    for (int c = 0; c < 4; c++) xo[c] += t * La[tc4 + c][k];
+  }
+#pragma unroll
+  for (int c = 0; c < 4; c++) S[(size_t)(i * NB + tr) * n + kb * NB + tc4 + c] = xo[c];
 }
 
-// x = S^-1 b with S = L L^T (single workgroup, blocked by 32): forward then backward substitution.
-__global__ __launch_bounds__(256) void k_chol_solve(const R* __restrict__ L, const R* __restrict__ diagL, int n, const R* __restrict__ b, R* __restrict__ x) {
+// x = S^-1 b with S = L L^T (single workgroup of 1024 threads, blocked by 32, diagonal blocks applied through their inverses):
+// forward  y_k = Linv_kk b_k ; b_i -= L(i,k) y_k (i > k)      backward  x_k = Linv_kk^T y_k ; y_j -= L(k,j)^T x_k (j < k)
+__global__ __launch_bounds__(1024) void k_chol_solve(const R* __restrict__ L, const R* __restrict__ diagInv, int n, const R* __restrict__ b,
+                                                     R* __restrict__ x) {
   extern __shared__ R y[];  // [n]
-  __shared__ R blk[NB][NB + 1];
+  __shared__ R yk[NB];
   const int tid = threadIdx.x, nb = n / NB;
-  for (int i = tid; i < n; i += 256) y[i] = b[i];
+  for (int i = tid; i < n; i += 1024) y[i] = b[i];
   __syncthreads();
   for (int kb = 0; kb < nb; kb++) {
-    for (int idx = tid; idx < NB * NB; idx += 256) blk[idx >> 5][idx & 31] = diagL[(size_t)kb * NB * NB + idx];
-    __syncthreads();
-    if (tid < 64) {  // one wave: sequential substitution inside the diagonal block
-      for (int j = 0; j < NB; j++) {
-        const R yj = y[kb * NB + j] / blk[j][j];
-        __builtin_amdgcn_wave_barrier();
-        if (tid == j) y[kb * NB + j] = yj;
-        else if (tid > j && tid < NB) y[kb * NB + tid] -= blk[tid][j] * yj;
-        __builtin_amdgcn_wave_barrier();
-      }
+    if (tid < NB) {
+      const R* inv = diagInv + (size_t)kb * NB * NB + tid * NB;
+      R s = 0;
+#pragma unroll 8
+      for (int k = 0; k <= tid; k++) s += inv[k] * y[kb * NB + k];
+      yk[tid] = s;
     }
     __syncthreads();
-    for (int i = (kb + 1) * NB + tid; i < n; i += 256) {
-      R s = y[i];
-      const R* row = L + (size_t)i * n + kb * NB;
-#pragma unroll 8
-      for (int k = 0; k < NB; k++) s -= row[k] * y[kb * NB + k];
-      y[i] = s;
+    if (tid < NB) y[kb * NB + tid] = yk[tid];
+    // rows below: 32 threads per row chunk -> thread (row r = tid / 4 ... ) use 4 threads per row, 8 columns each
+    for (int r0 = (kb + 1) * NB; r0 < n; r0 += 256) {
+      const int r = r0 + (tid >> 2), q = tid & 3;
+      R s = 0;
+      if (r < n) {
+        const R* row = L + (size_t)r * n + kb * NB + q * 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) s += row[k] * yk[q * 8 + k];
+      }
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      if (r < n && q == 0) y[r] -= s;
     }
     __syncthreads();
   }
   for (int kb = nb - 1; kb >= 0; kb--) {
-    for (int idx = tid; idx < NB * NB; idx += 256) blk[idx >> 5][idx & 31] = diagL[(size_t)kb * NB * NB + idx];
-    __syncthreads();
-    if (tid < 64) {
-      for (int j = NB - 1; j >= 0; j--) {
-        const R yj = y[kb * NB + j] / blk[j][j];
-        __builtin_amdgcn_wave_barrier();
-        if (tid == j) y[kb * NB + j] = yj;
-        else if (tid < j) y[kb * NB + tid] -= blk[j][tid] * yj;
-        __builtin_amdgcn_wave_barrier();
-      }
+    if (tid < NB) {
+      const R* inv = diagInv + (size_t)kb * NB * NB;   // x_k[c] = sum_{r >= c} Linv[r][c] y_k[r]
+      R s = 0;
+      for (int r = tid; r < NB; r++) s += inv[r * NB + tid] * y[kb * NB + r];
+      yk[tid] = s;
     }
     __syncthreads();
-    for (int i = tid; i < kb * NB; i += 256) {
-      R s = y[i];
+    if (tid < NB) y[kb * NB + tid] = yk[tid];
+    // y_j -= sum_r L(kb*NB + r, j) x_k[r] for j < kb*NB: row access, coalesced over j
+    for (int jcol = tid; jcol < kb * NB; jcol += 1024) {
+      R s = 0;
 #pragma unroll 8
-      for (int k = 0; k < NB; k++) s -= L[(size_t)(kb * NB + k) * n + i] * y[kb * NB + k];
-      y[i] = s;
+      for (int r = 0; r < NB; r++) s += L[(size_t)(kb * NB + r) * n + jcol] * yk[r];
+      y[jcol] -= s;
     }
     __syncthreads();
   }
-  for (int i = tid; i < n; i += 256) x[i] = y[i];
+  for (int i = tid; i < n; i += 1024) x[i] = y[i];
 }
 
 // landmark step (block_solver.hpp:420-444): xl = D^-1 (b_l - sum_e Hpl_e^T xp[pose(e)])
@@ -587,15 +778,16 @@ __global__ __launch_bounds__(256) void k_update(const R* __restrict__ srcPoses, 
   }
 }
 
-// computeScale (levenberg.cpp:166-173): sum_j x_j (lambda x_j + b_j) over pose and landmark unknowns -> out[slot]
+// computeScale (levenberg.cpp:166-173): sum_j x_j (lambda x_j + b_j) over pose and landmark unknowns -> per-workgroup partials
 __global__ __launch_bounds__(256) void k_scale(const R* __restrict__ xp, const R* __restrict__ bp, int np6, const R* __restrict__ xl,
-                                               const R* __restrict__ bl, int nl3, R lambda, R* __restrict__ out, int slot) {
+                                               const R* __restrict__ bl, int nl3, R lambda, R* __restrict__ partial) {
   __shared__ R lds[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
   R v = 0;
-  for (int i = threadIdx.x; i < np6; i += 256) v += xp[i] * (lambda * xp[i] + bp[i]);
-  for (int i = threadIdx.x; i < nl3; i += 256) v += xl[i] * (lambda * xl[i] + bl[i]);
+  if (i < np6) v = xp[i] * (lambda * xp[i] + bp[i]);
+  else if (i - np6 < nl3) { const int j = i - np6; v = xl[j] * (lambda * xl[j] + bl[j]); }
   const R s = block_sum(v, lds);
-  if (threadIdx.x == 0) out[slot] = s;
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
 // depth of every edge under the current estimate (isDepthPositive, types_six_dof_expmap.h:215-219,276-280)

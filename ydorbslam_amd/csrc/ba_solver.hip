@@ -54,7 +54,7 @@ struct Ctx {  // per-device scratch, reused across calls (localBundleAdjust runs
   hipStream_t stream = nullptr;
   DBuf poses[2], pts[2], ePoseAll, ePtAll, depth;
   DBuf ePose, ePidx, ePt, eMeas, eInfo, eRobust, eLm, ptStart, poseStart, poseEdges, poseOf, ptOf;
-  DBuf err, partial, Hll, bl, Hpl, Hpp, bp, S, diagL, bs, Dinv, db, xp, xl, scal, status;
+  DBuf err, partial, Hll, bl, Hpl, BD, Hpp, bp, S, diagL, diagInv, bs, Dinv, db, xp, xl, scal, status, pairCnt, pairStart, pairCursor, pairA, pairB;
   hipEvent_t ev[2 * PH_COUNT + 2]{};
   bool evInit = false;
 };
@@ -161,10 +161,11 @@ int optimize(Run& R_, int iterations, int stage) {
       (rc = c.eLm.ensure(sizeof(int) * Ea)) || (rc = c.eMeas.ensure(sizeof(double) * 3 * Ea)) || (rc = c.eInfo.ensure(sizeof(double) * Ea)) ||
       (rc = c.eRobust.ensure(Ea)) || (rc = c.ptStart.ensure(sizeof(int) * (nL + 1))) || (rc = c.poseStart.ensure(sizeof(int) * (nPf + 1))) ||
       (rc = c.poseEdges.ensure(sizeof(int) * std::max<size_t>(hPoseEdges.size(), 1))) || (rc = c.poseOf.ensure(sizeof(int) * std::max(nPf, 1))) ||
-      (rc = c.ptOf.ensure(sizeof(int) * nL)) || (rc = c.err.ensure(sizeof(double) * 3 * Ea)) || (rc = c.partial.ensure(sizeof(double) * nBlkE)) ||
+      (rc = c.ptOf.ensure(sizeof(int) * nL)) || (rc = c.err.ensure(sizeof(double) * 3 * Ea)) || (rc = c.partial.ensure(sizeof(double) * (nBlkE + (6 * nPf + 3 * nL + 255) / 256 + 1))) ||
       (rc = c.Hll.ensure(sizeof(double) * 6 * nL)) || (rc = c.bl.ensure(sizeof(double) * 3 * nL)) || (rc = c.Hpl.ensure(sizeof(double) * 18 * (size_t)Ea)) ||
+      (rc = c.BD.ensure(sizeof(double) * 18 * (size_t)Ea)) ||
       (rc = c.Hpp.ensure(sizeof(double) * 42 * std::max(nPf, 1))) || (rc = c.S.ensure(sizeof(double) * ((size_t)n * n + n))) ||
-      (rc = c.diagL.ensure(sizeof(double) * (size_t)nb * NB * NB)) || (rc = c.Dinv.ensure(sizeof(double) * 6 * nL)) || (rc = c.db.ensure(sizeof(double) * 3 * nL)) ||
+      (rc = c.diagL.ensure(sizeof(double) * (size_t)nb * NB * NB)) || (rc = c.diagInv.ensure(sizeof(double) * (size_t)nb * NB * NB)) || (rc = c.Dinv.ensure(sizeof(double) * 6 * nL)) || (rc = c.db.ensure(sizeof(double) * 3 * nL)) ||
       (rc = c.xp.ensure(sizeof(double) * n)) || (rc = c.xl.ensure(sizeof(double) * 3 * nL)) || (rc = c.scal.ensure(sizeof(double) * 8)) ||
       (rc = c.status.ensure(sizeof(int) * 2)))
     return rc;
@@ -181,6 +182,27 @@ int optimize(Run& R_, int iterations, int stage) {
 #undef UP
   EdgeSoA Ed{c.ePose.as<int>(), c.ePidx.as<int>(), c.ePt.as<int>(), c.eMeas.as<double>(), c.eInfo.as<double>(), c.eRobust.as<uint8_t>(), Ea};
   const double dM = O.delta_mono, dSt = O.delta_stereo;
+  // pose-pair buckets of the Schur complement (structure is fixed for this optimize() call)
+  const int nBuckets = nPf * (nPf + 1) / 2;
+  size_t nItems = 0;
+  for (int l = 0; l < nL; l++) {
+    size_t m = 0;
+    for (int i = hPtStart[l]; i < hPtStart[l + 1]; i++) m += hPidx[i] >= 0;
+    nItems += m * (m + 1) / 2;
+  }
+  if ((rc = c.pairCnt.ensure(sizeof(int) * (nBuckets + 1))) || (rc = c.pairStart.ensure(sizeof(int) * (nBuckets + 1))) ||
+      (rc = c.pairCursor.ensure(sizeof(int) * (nBuckets + 1))) || (rc = c.pairA.ensure(sizeof(int2) * std::max<size_t>(nItems, 1))) ||
+      (rc = c.pairB.ensure(sizeof(int2) * std::max<size_t>(nItems, 1))))
+    return rc;
+  if (nBuckets > 0) {
+    HIPCHK(hipMemsetAsync(c.pairCnt.p, 0, sizeof(int) * (nBuckets + 1), s));
+    hipLaunchKernelGGL(k_pair_count, dim3((nL + 255) / 256), dim3(256), 0, s, Ed, c.ptStart.as<int>(), nL, c.pairCnt.as<int>());
+    hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(256), 0, s, c.pairCnt.as<int>(), nBuckets, c.pairStart.as<int>());
+    HIPCHK(hipMemcpyAsync(c.pairCursor.p, c.pairStart.p, sizeof(int) * (nBuckets + 1), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_pair_fill, dim3((nL + 255) / 256), dim3(256), 0, s, Ed, c.ptStart.as<int>(), nL, c.pairCursor.as<int>(), c.pairA.as<int2>());
+    hipLaunchKernelGGL(k_pair_sort, dim3((nBuckets + 3) / 4), dim3(256), 0, s, c.pairStart.as<int>(), nBuckets, c.pairA.as<int2>(), c.pairB.as<int2>());
+  }
+  HIPCHK(hipMemsetAsync(dS, 0, sizeof(double) * ((size_t)n * n + n), s));
   double hscal[8];
   const bool multi = O.world > 1 && O.allreduce;
 
@@ -227,10 +249,13 @@ int optimize(Run& R_, int iterations, int stage) {
       {
         PhaseTimer t(R_, PH_SCHUR);
         const double contrib = (!multi || O.rank == 0) ? 1.0 : 0.0;
-        hipLaunchKernelGGL(k_schur_init, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s, dHpp, dbp, nPf, n, lambda, contrib, dS, dbs);
         hipLaunchKernelGGL(k_dinv, dim3((nL + 255) / 256), dim3(256), 0, s, c.Hll.as<double>(), c.bl.as<double>(), nL, lambda, c.Dinv.as<double>(), c.db.as<double>());
-        hipLaunchKernelGGL(k_schur, dim3(nBlkE), dim3(256), 0, s, Ed, c.ptStart.as<int>(), c.eLm.as<int>(), c.Hpl.as<double>(), c.Dinv.as<double>(),
-                           c.db.as<double>(), n, dS, dbs);
+        hipLaunchKernelGGL(k_bd, dim3(nBlkE), dim3(256), 0, s, Ed, c.eLm.as<int>(), c.Hpl.as<double>(), c.Dinv.as<double>(), c.BD.as<double>());
+        if (nPf)
+          hipLaunchKernelGGL(k_bs, dim3(nPf), dim3(256), 0, s, Ed, c.poseStart.as<int>(), c.poseEdges.as<int>(), c.eLm.as<int>(), c.Hpl.as<double>(),
+                             c.db.as<double>(), dbp, contrib, dbs);
+        hipLaunchKernelGGL(k_schur_pairs, dim3((nBuckets + 3) / 4 + 1), dim3(256), 0, s, c.pairStart.as<int>(), c.pairB.as<int2>(), nPf, nBuckets,
+                           c.BD.as<double>(), c.Hpl.as<double>(), dHpp, lambda, contrib, n, dS, dbs);
         t.stop();
       }
       if (multi) {  // sum of the per-rank landmark contributions (+ rank 0's Hpp, lambda, bp)
@@ -239,8 +264,9 @@ int optimize(Run& R_, int iterations, int stage) {
       {
         PhaseTimer t(R_, PH_SOLVE);
         for (int kb = 0; kb < nb; kb++)
-          hipLaunchKernelGGL(k_chol_panel, dim3(nb - kb), dim3(256), 0, s, dS, c.diagL.as<double>(), n, kb, c.status.as<int>());
-        hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(256), sizeof(double) * n, s, dS, c.diagL.as<double>(), n, dbs, c.xp.as<double>());
+          hipLaunchKernelGGL(k_chol_step, dim3((nb - kb) * (nb - kb + 1) / 2), dim3(256), 0, s, dS, c.diagL.as<double>(), c.diagInv.as<double>(), n, kb,
+                             c.status.as<int>());
+        hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), sizeof(double) * n, s, dS, c.diagInv.as<double>(), n, dbs, c.xp.as<double>());
         hipLaunchKernelGGL(k_backsub, dim3((nL + 127) / 128), dim3(128), 0, s, Ed, c.ptStart.as<int>(), nL, c.Hpl.as<double>(), c.Dinv.as<double>(),
                            c.bl.as<double>(), c.xp.as<double>(), c.xl.as<double>());
         t.stop();
@@ -253,8 +279,13 @@ int optimize(Run& R_, int iterations, int stage) {
                            c.poses[nxt].as<double>(), c.pts[nxt].as<double>(), c.poseOf.as<int>(), nPf, c.ptOf.as<int>(), nL, c.xp.as<double>(),
                            c.xl.as<double>());
         // computeScale: pose part once (rank 0), landmark part per rank
-        hipLaunchKernelGGL(k_scale, dim3(1), dim3(256), 0, s, c.xp.as<double>(), dbp, (!multi || O.rank == 0) ? 6 * nPf : 0, c.xl.as<double>(),
-                           c.bl.as<double>(), 3 * nL, lambda, c.scal.as<double>(), 2);
+        {
+          const int np6 = (!multi || O.rank == 0) ? 6 * nPf : 0;
+          const int nb2 = (np6 + 3 * nL + 255) / 256;
+          hipLaunchKernelGGL(k_scale, dim3(nb2), dim3(256), 0, s, c.xp.as<double>(), dbp, np6, c.xl.as<double>(), c.bl.as<double>(), 3 * nL, lambda,
+                             c.partial.as<double>() + nBlkE);
+          hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, c.partial.as<double>() + nBlkE, nb2, c.scal.as<double>(), 2);
+        }
         t.stop();
         if (multi) { if ((rc = allreduce(R_, c.scal.as<double>() + 2, 1, 0))) return rc; }
       }
@@ -426,18 +457,19 @@ int ydorb_ba_dense_solve(int32_t device, const double* A, int32_t n0, const doub
     for (int j = 0; j < n; j++) hA[(size_t)i * n + j] = (i < n0 && j < n0) ? A[(size_t)i * n0 + j] : (i == j ? 1.0 : 0.0);
     if (i < n0) hb[i] = b[i];
   }
-  double *dA = nullptr, *dD = nullptr, *db = nullptr, *dx = nullptr;
+  double *dA = nullptr, *dD = nullptr, *dI = nullptr, *db = nullptr, *dx = nullptr;
   int* dst = nullptr;
   HIPCHK(hipMalloc(&dA, sizeof(double) * n * n));
   HIPCHK(hipMalloc(&dD, sizeof(double) * nb * NB * NB));
+  HIPCHK(hipMalloc(&dI, sizeof(double) * nb * NB * NB));
   HIPCHK(hipMalloc(&db, sizeof(double) * n));
   HIPCHK(hipMalloc(&dx, sizeof(double) * n));
   HIPCHK(hipMalloc(&dst, sizeof(int) * 2));
   HIPCHK(hipMemcpy(dA, hA.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(db, hb.data(), sizeof(double) * n, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(dst, 0, sizeof(int) * 2));
-  for (int kb = 0; kb < nb; kb++) hipLaunchKernelGGL(k_chol_panel, dim3(nb - kb), dim3(256), 0, 0, dA, dD, n, kb, dst);
-  hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(256), sizeof(double) * n, 0, dA, dD, n, db, dx);
+  for (int kb = 0; kb < nb; kb++) hipLaunchKernelGGL(k_chol_step, dim3((nb - kb) * (nb - kb + 1) / 2), dim3(256), 0, 0, dA, dD, dI, n, kb, dst);
+  hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), sizeof(double) * n, 0, dA, dI, n, db, dx);
   HIPCHK(hipGetLastError());
   std::vector<double> hx(n);
   int hst[2];
@@ -445,7 +477,7 @@ int ydorb_ba_dense_solve(int32_t device, const double* A, int32_t n0, const doub
   HIPCHK(hipMemcpy(hst, dst, sizeof(hst), hipMemcpyDeviceToHost));
   *ok = hst[0] == 0;
   for (int i = 0; i < n0; i++) x[i] = hx[i];
-  (void)hipFree(dA); (void)hipFree(dD); (void)hipFree(db); (void)hipFree(dx); (void)hipFree(dst);
+  (void)hipFree(dA); (void)hipFree(dD); (void)hipFree(dI); (void)hipFree(db); (void)hipFree(dx); (void)hipFree(dst);
   return YDORB_OK;
 }
 
