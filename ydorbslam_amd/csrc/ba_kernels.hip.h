@@ -277,16 +277,36 @@ __global__ __launch_bounds__(256) void k_build_poses(EdgeSoA Ed, const int* __re
 #pragma unroll
     for (int r = 0; r < 6; r++) b[r] += B[0][r] * omr[0] + B[1][r] * omr[1] + B[2][r] * omr[2];
   }
-  int k = 0;
-  for (int r = 0; r < 6; r++)
-    for (int c = r; c < 6; c++, k++) {
-      const R s = block_sum(h[k], lds);
-      if (threadIdx.x == 0) { Hpp[(size_t)36 * i + r * 6 + c] = s; Hpp[(size_t)36 * i + c * 6 + r] = s; }
-    }
-  for (int r = 0; r < 6; r++) {
-    const R s = block_sum(b[r], lds);
-    if (threadIdx.x == 0) bp[6 * i + r] = s;
+  // 27 sums: butterfly inside each wave, one LDS hand-off of the 4 wave partials, 27 threads finish (fixed order)
+  __shared__ R part[4][27];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 21; k++) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) h[k] += __shfl_xor(h[k], o, 64);
+    if (lane == 0) part[wv][k] = h[k];
   }
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) b[k] += __shfl_xor(b[k], o, 64);
+    if (lane == 0) part[wv][21 + k] = b[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    const int k = threadIdx.x;
+    const R sum = part[0][k] + part[1][k] + part[2][k] + part[3][k];
+    if (k < 21) {
+      int r = 0, rem = k;
+      while (rem >= 6 - r) { rem -= 6 - r; r++; }
+      const int c = r + rem;
+      Hpp[(size_t)36 * i + r * 6 + c] = sum;
+      Hpp[(size_t)36 * i + c * 6 + r] = sum;
+    } else {
+      bp[6 * i + (k - 21)] = sum;
+    }
+  }
+  (void)lds;
 }
 
 // max |diagonal| of the Hessian (computeLambdaInit, levenberg.cpp:150-164) -> out[slot]
@@ -474,17 +494,23 @@ __global__ __launch_bounds__(256) void k_schur_pairs(const int* __restrict__ sta
     const int cnt = min(64, s1 - chunk);
     const int2 it = lane < cnt ? items[chunk + lane] : make_int2(0, 0);
     const int nk = 3 * cnt;
-#pragma unroll 4
-    for (int kk0 = 0; kk0 < nk; kk0 += 4) {
-      const int kk = kk0 + kq;
-      const int t = kk / 3, c = kk - 3 * t;
-      const int ea = __shfl(it.x, t & 63, 64), eb = __shfl(it.y, t & 63, 64);
-      R a = 0.0, b = 0.0;
-      if (live && kk < nk) {
-        a = Hpl[(size_t)18 * eb + i16 * 3 + c];
-        b = BD[(size_t)18 * ea + i16 * 3 + c];
+    // 16 MFMA steps per group: all 32 operand loads of a group are issued before the first MFMA waits on one of them
+    for (int kg = 0; kg < nk; kg += 64) {
+      R av[16], bv[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int kk = kg + 4 * u + kq;
+        const int t = kk / 3, c = kk - 3 * t;
+        const int ea = __shfl(it.x, t & 63, 64), eb = __shfl(it.y, t & 63, 64);
+        av[u] = 0.0; bv[u] = 0.0;
+        if (live && kk < nk) {
+          av[u] = Hpl[(size_t)18 * eb + i16 * 3 + c];
+          bv[u] = BD[(size_t)18 * ea + i16 * 3 + c];
+        }
       }
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+        if (kg + 4 * u < nk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
     }
   }
   if (live) {
@@ -517,7 +543,7 @@ constexpr int NBP = NB + 1;
 // Lane i (< 32) keeps row i in 32 registers (all loops fully unrolled, so every index is a compile-time constant); per pivot
 // step the scaled column goes through a 32-entry LDS vector that every lane reads back with independent (pipelined)
 // broadcast loads.  The first version updated the trailing block element-by-element in LDS: ~30 us per tile.
-__device__ __forceinline__ bool potrf_wave(R (*D)[NBP], R* col, int lane) {
+__device__ __forceinline__ bool potrf_wave(R (*D)[NBP], R* col, R* rdiag, int lane) {
   const int i = lane & 31;
   R a[NB];
 #pragma unroll
@@ -527,10 +553,11 @@ __device__ __forceinline__ bool potrf_wave(R (*D)[NBP], R* col, int lane) {
   for (int j = 0; j < NB; j++) {
     const R d = __shfl(a[j], j, 64);   // pivot: element (j, j) lives in lane j
     if (!(d > 0)) ok = false;
-    const R sd = sqrt(d);
-    const R lij = i == j ? sd : a[j] / sd;   // rows i < j hold stale values in a[j]; they are never used again
+    const R inv = rsqrt(d);                    // one reciprocal square root per pivot instead of a divide per row
+    const R lij = i == j ? d * inv : a[j] * inv;   // rows i < j hold stale values in a[j]; they are never used again
     a[j] = lij;
     if (lane < NB) col[i] = lij;
+    if (lane == j) rdiag[j] = inv;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -556,19 +583,35 @@ __device__ __forceinline__ int tri_index(int t, int* row) {  // t -> (row, col) 
 }
 
 __global__ __launch_bounds__(256) void k_chol_step(R* __restrict__ S, R* __restrict__ diagL, R* __restrict__ diagInv, int n, int kb,
-                                                   int* __restrict__ status) {
+                                                   int* __restrict__ status, R* __restrict__ bvec, R* __restrict__ yv) {
   __shared__ R Ta[NB][NBP];   // this tile
   __shared__ R Dg[NB][NBP];   // diagonal tile of the panel (panel workgroups only)
   __shared__ R La[NB][NBP];   // L(i, kb-1)
   __shared__ R Lb[NB][NBP];   // L(j, kb-1)
   __shared__ R Lk[NB][NBP];   // L(kb, kb-1)
   __shared__ R colv[NB];
+  __shared__ R rdiag[NB];   // 1 / L_jj
   __shared__ int sOk;
   const int tid = threadIdx.x, tr = tid >> 3, tc4 = (tid & 7) * 4;
   int ri;
   const int cj = tri_index(blockIdx.x, &ri);
   const int i = kb + ri, j = kb + cj;          // tile (i, j), i >= j >= kb
   const bool panel = j == kb;
+  // The diagonal workgroup also carries the forward substitution L y = b along (b is touched by this workgroup only):
+  // b_r -= L(r, panel kb-1) y_{kb-1} for every remaining row, and after the panel is factored y_kb = L_kk^-1 b_kb.
+  if (i == kb && j == kb && kb > 0) {
+    __shared__ R yprev[NB];
+    if (tid < NB) yprev[tid] = yv[(kb - 1) * NB + tid];
+    __syncthreads();
+    for (int r = kb * NB + tid; r < n; r += 256) {
+      const R* row = S + (size_t)r * n + (kb - 1) * NB;
+      R sres = 0;
+#pragma unroll 8
+      for (int k = 0; k < NB; k++) sres += row[k] * yprev[k];
+      bvec[r] -= sres;
+    }
+    __syncthreads();
+  }
   R acc[4], accD[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int c = 0; c < 4; c++) {
@@ -606,10 +649,15 @@ __global__ __launch_bounds__(256) void k_chol_step(R* __restrict__ S, R* __restr
 #pragma unroll
   for (int c = 0; c < 4; c++) { Ta[tr][tc4 + c] = acc[c]; Dg[tr][tc4 + c] = accD[c]; }
   __syncthreads();
+#ifndef CHOL_SKIP_POTRF
   if (tid < 64) {
-    const bool ok = potrf_wave(Dg, colv, tid);
+    const bool ok = potrf_wave(Dg, colv, rdiag, tid);
     if (tid == 0) sOk = ok ? 1 : 0;
   }
+#else
+  if (tid == 0) sOk = 1;
+  if (tid < NB) rdiag[tid] = 1.0;
+#endif
   __syncthreads();
   if (!sOk) {
     if (tid == 0) atomicMax(status, 1);
@@ -617,18 +665,41 @@ __global__ __launch_bounds__(256) void k_chol_step(R* __restrict__ S, R* __restr
   }
   // inverse of the diagonal factor (column c by lane c: forward substitution on e_c), kept in LDS: the panel solve
   // X L_kk^T = T then is a 32x32x32 product X = T * Linv^T on all 256 threads instead of 32 serial substitutions
+  // Linv by 2x2 blocks of 16: L = [A 0; B C]  ->  Linv = [A^-1 0; -C^-1 B A^-1  C^-1].  The two 16x16 inverses run side by side
+  // (lanes 0-15 / 16-31, one column each: a 120-term chain instead of the 528-term chain of a direct 32x32 inverse, which
+  // measured 9 us), the off-diagonal block is two 16x16x16 products on all 256 threads.
   if (tid < NB) {
-    const int c = tid;
-    R z[NB];
+    const int off = (tid >> 4) * 16, c = tid & 15;
+    R z[16];
 #pragma unroll
-    for (int r = 0; r < NB; r++) {
-      R s = r == c ? 1.0 : 0.0;
+    for (int r = 0; r < 16; r++) {
+      R sres = r == c ? 1.0 : 0.0;
 #pragma unroll
-      for (int k = 0; k < NB; k++) if (k < r) s -= Dg[r][k] * z[k];
-      z[r] = r < c ? 0.0 : s / Dg[r][r];
+      for (int k = 0; k < 16; k++) if (k < r) sres -= Dg[off + r][off + k] * z[k];
+      z[r] = r < c ? 0.0 : sres * rdiag[off + r];
     }
 #pragma unroll
-    for (int r = 0; r < NB; r++) La[r][c] = z[r];   // La is free after the update: La = Linv
+    for (int r = 0; r < 16; r++) La[off + r][off + c] = z[r];   // La is free after the update: La = Linv
+  }
+  {
+    const int r = tid >> 4, c = tid & 15;
+    La[r][16 + c] = 0.0;   // upper-right block
+  }
+  __syncthreads();
+  {
+    const int r = tid >> 4, c = tid & 15;   // T1 = B A^-1
+    R t1 = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t1 += Dg[16 + r][k] * La[k][c];
+    Lb[r][c] = t1;
+  }
+  __syncthreads();
+  {
+    const int r = tid >> 4, c = tid & 15;   // M = -C^-1 T1
+    R m = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) m -= La[16 + r][16 + k] * Lb[k][c];
+    La[16 + r][c] = m;
   }
   __syncthreads();
   if (i == kb) {
@@ -636,6 +707,11 @@ __global__ __launch_bounds__(256) void k_chol_step(R* __restrict__ S, R* __restr
     for (int c = 0; c < 4; c++) {
       diagL[(size_t)kb * NB * NB + tr * NB + tc4 + c] = tc4 + c <= tr ? Dg[tr][tc4 + c] : 0;
       diagInv[(size_t)kb * NB * NB + tr * NB + tc4 + c] = La[tr][tc4 + c];
+    }
+    if (tid < NB) {
+      R sres = 0;
+      for (int k = 0; k <= tid; k++) sres += La[tid][k] * bvec[kb * NB + k];
+      yv[kb * NB + tid] = sres;
     }
     return;
   }
@@ -650,40 +726,15 @@ __global__ __launch_bounds__(256) void k_chol_step(R* __restrict__ S, R* __restr
   for (int c = 0; c < 4; c++) S[(size_t)(i * NB + tr) * n + kb * NB + tc4 + c] = xo[c];
 }
 
-// x = S^-1 b with S = L L^T (single workgroup of 1024 threads, blocked by 32, diagonal blocks applied through their inverses):
-// forward  y_k = Linv_kk b_k ; b_i -= L(i,k) y_k (i > k)      backward  x_k = Linv_kk^T y_k ; y_j -= L(k,j)^T x_k (j < k)
-__global__ __launch_bounds__(1024) void k_chol_solve(const R* __restrict__ L, const R* __restrict__ diagInv, int n, const R* __restrict__ b,
+// Backward substitution L^T x = y (y comes out of the factorisation launches), single workgroup, blocked by 32 with the
+// diagonal blocks applied through their inverses:  x_k = Linv_kk^T y_k ;  y_j -= L(k,j)^T x_k  (j < k).
+__global__ __launch_bounds__(1024) void k_chol_solve(const R* __restrict__ L, const R* __restrict__ diagInv, int n, const R* __restrict__ yin,
                                                      R* __restrict__ x) {
   extern __shared__ R y[];  // [n]
   __shared__ R yk[NB];
   const int tid = threadIdx.x, nb = n / NB;
-  for (int i = tid; i < n; i += 1024) y[i] = b[i];
+  for (int i = tid; i < n; i += 1024) y[i] = yin[i];
   __syncthreads();
-  for (int kb = 0; kb < nb; kb++) {
-    if (tid < NB) {
-      const R* inv = diagInv + (size_t)kb * NB * NB + tid * NB;
-      R s = 0;
-#pragma unroll 8
-      for (int k = 0; k <= tid; k++) s += inv[k] * y[kb * NB + k];
-      yk[tid] = s;
-    }
-    __syncthreads();
-    if (tid < NB) y[kb * NB + tid] = yk[tid];
-    // rows below: 32 threads per row chunk -> thread (row r = tid / 4 ... ) use 4 threads per row, 8 columns each
-    for (int r0 = (kb + 1) * NB; r0 < n; r0 += 256) {
-      const int r = r0 + (tid >> 2), q = tid & 3;
-      R s = 0;
-      if (r < n) {
-        const R* row = L + (size_t)r * n + kb * NB + q * 8;
-#pragma unroll
-        for (int k = 0; k < 8; k++) s += row[k] * yk[q * 8 + k];
-      }
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      if (r < n && q == 0) y[r] -= s;
-    }
-    __syncthreads();
-  }
   for (int kb = nb - 1; kb >= 0; kb--) {
     if (tid < NB) {
       const R* inv = diagInv + (size_t)kb * NB * NB;   // x_k[c] = sum_{r >= c} Linv[r][c] y_k[r]

@@ -54,7 +54,7 @@ struct Ctx {  // per-device scratch, reused across calls (localBundleAdjust runs
   hipStream_t stream = nullptr;
   DBuf poses[2], pts[2], ePoseAll, ePtAll, depth;
   DBuf ePose, ePidx, ePt, eMeas, eInfo, eRobust, eLm, ptStart, poseStart, poseEdges, poseOf, ptOf;
-  DBuf err, partial, Hll, bl, Hpl, BD, Hpp, bp, S, diagL, diagInv, bs, Dinv, db, xp, xl, scal, status, pairCnt, pairStart, pairCursor, pairA, pairB;
+  DBuf err, partial, Hll, bl, Hpl, BD, Hpp, bp, S, diagL, diagInv, bs, Dinv, db, xp, xl, yv, scal, status, pairCnt, pairStart, pairCursor, pairA, pairB;
   hipEvent_t ev[2 * PH_COUNT + 2]{};
   bool evInit = false;
 };
@@ -128,13 +128,21 @@ int optimize(Run& R_, int iterations, int stage) {
   }
   const int nPf = (int)poseOf.size();
   (void)nP;
-  std::sort(act.begin(), act.end(), [&](int a, int b) {
-    const int la = ptIdx[P.edge_point[a]], lb = ptIdx[P.edge_point[b]];
-    if (la != lb) return la < lb;
-    const int pa = poseIdx[P.edge_pose[a]], pb = poseIdx[P.edge_pose[b]];
-    if (pa != pb) return pa < pb;
-    return a < b;
-  });
+  {  // order by (landmark index, pose index, edge index): counting sort by landmark, then a tiny insertion sort per landmark
+    std::vector<int> start(nL + 1, 0), sorted(Ea);
+    for (int e : act) start[ptIdx[P.edge_point[e]] + 1]++;
+    for (int l = 0; l < nL; l++) start[l + 1] += start[l];
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    for (int e : act) sorted[fill[ptIdx[P.edge_point[e]]]++] = e;   // act is ascending: stable
+    for (int l = 0; l < nL; l++)
+      for (int a = start[l] + 1; a < start[l + 1]; a++) {
+        const int e = sorted[a], pe = poseIdx[P.edge_pose[e]];
+        int b = a - 1;
+        while (b >= start[l] && (poseIdx[P.edge_pose[sorted[b]]] > pe || (poseIdx[P.edge_pose[sorted[b]]] == pe && sorted[b] > e))) { sorted[b + 1] = sorted[b]; b--; }
+        sorted[b + 1] = e;
+      }
+    act.swap(sorted);
+  }
   std::vector<int> hPose(Ea), hPidx(Ea), hPt(Ea), hLm(Ea), hPtStart(nL + 1, 0), hPoseStart(nPf + 1, 0), hPoseEdges;
   std::vector<double> hMeas((size_t)3 * Ea), hInfo(Ea);
   std::vector<uint8_t> hRobust(Ea);
@@ -166,7 +174,7 @@ int optimize(Run& R_, int iterations, int stage) {
       (rc = c.BD.ensure(sizeof(double) * 18 * (size_t)Ea)) ||
       (rc = c.Hpp.ensure(sizeof(double) * 42 * std::max(nPf, 1))) || (rc = c.S.ensure(sizeof(double) * ((size_t)n * n + n))) ||
       (rc = c.diagL.ensure(sizeof(double) * (size_t)nb * NB * NB)) || (rc = c.diagInv.ensure(sizeof(double) * (size_t)nb * NB * NB)) || (rc = c.Dinv.ensure(sizeof(double) * 6 * nL)) || (rc = c.db.ensure(sizeof(double) * 3 * nL)) ||
-      (rc = c.xp.ensure(sizeof(double) * n)) || (rc = c.xl.ensure(sizeof(double) * 3 * nL)) || (rc = c.scal.ensure(sizeof(double) * 8)) ||
+      (rc = c.xp.ensure(sizeof(double) * n)) || (rc = c.yv.ensure(sizeof(double) * n)) || (rc = c.xl.ensure(sizeof(double) * 3 * nL)) || (rc = c.scal.ensure(sizeof(double) * 8)) ||
       (rc = c.status.ensure(sizeof(int) * 2)))
     return rc;
   // Hpp and bp are contiguous ([36 nPf | 6 nPf]) so one all-reduce covers both; bs follows S for the same reason
@@ -265,8 +273,8 @@ int optimize(Run& R_, int iterations, int stage) {
         PhaseTimer t(R_, PH_SOLVE);
         for (int kb = 0; kb < nb; kb++)
           hipLaunchKernelGGL(k_chol_step, dim3((nb - kb) * (nb - kb + 1) / 2), dim3(256), 0, s, dS, c.diagL.as<double>(), c.diagInv.as<double>(), n, kb,
-                             c.status.as<int>());
-        hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), sizeof(double) * n, s, dS, c.diagInv.as<double>(), n, dbs, c.xp.as<double>());
+                             c.status.as<int>(), dbs, c.yv.as<double>());
+        hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), sizeof(double) * n, s, dS, c.diagInv.as<double>(), n, c.yv.as<double>(), c.xp.as<double>());
         hipLaunchKernelGGL(k_backsub, dim3((nL + 127) / 128), dim3(128), 0, s, Ed, c.ptStart.as<int>(), nL, c.Hpl.as<double>(), c.Dinv.as<double>(),
                            c.bl.as<double>(), c.xp.as<double>(), c.xl.as<double>());
         t.stop();
@@ -457,19 +465,20 @@ int ydorb_ba_dense_solve(int32_t device, const double* A, int32_t n0, const doub
     for (int j = 0; j < n; j++) hA[(size_t)i * n + j] = (i < n0 && j < n0) ? A[(size_t)i * n0 + j] : (i == j ? 1.0 : 0.0);
     if (i < n0) hb[i] = b[i];
   }
-  double *dA = nullptr, *dD = nullptr, *dI = nullptr, *db = nullptr, *dx = nullptr;
+  double *dA = nullptr, *dD = nullptr, *dI = nullptr, *db = nullptr, *dx = nullptr, *dy = nullptr;
   int* dst = nullptr;
   HIPCHK(hipMalloc(&dA, sizeof(double) * n * n));
   HIPCHK(hipMalloc(&dD, sizeof(double) * nb * NB * NB));
   HIPCHK(hipMalloc(&dI, sizeof(double) * nb * NB * NB));
   HIPCHK(hipMalloc(&db, sizeof(double) * n));
   HIPCHK(hipMalloc(&dx, sizeof(double) * n));
+  HIPCHK(hipMalloc(&dy, sizeof(double) * n));
   HIPCHK(hipMalloc(&dst, sizeof(int) * 2));
   HIPCHK(hipMemcpy(dA, hA.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(db, hb.data(), sizeof(double) * n, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(dst, 0, sizeof(int) * 2));
-  for (int kb = 0; kb < nb; kb++) hipLaunchKernelGGL(k_chol_step, dim3((nb - kb) * (nb - kb + 1) / 2), dim3(256), 0, 0, dA, dD, dI, n, kb, dst);
-  hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), sizeof(double) * n, 0, dA, dI, n, db, dx);
+  for (int kb = 0; kb < nb; kb++) hipLaunchKernelGGL(k_chol_step, dim3((nb - kb) * (nb - kb + 1) / 2), dim3(256), 0, 0, dA, dD, dI, n, kb, dst, db, dy);
+  hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), sizeof(double) * n, 0, dA, dI, n, dy, dx);
   HIPCHK(hipGetLastError());
   std::vector<double> hx(n);
   int hst[2];
@@ -477,7 +486,7 @@ int ydorb_ba_dense_solve(int32_t device, const double* A, int32_t n0, const doub
   HIPCHK(hipMemcpy(hst, dst, sizeof(hst), hipMemcpyDeviceToHost));
   *ok = hst[0] == 0;
   for (int i = 0; i < n0; i++) x[i] = hx[i];
-  (void)hipFree(dA); (void)hipFree(dD); (void)hipFree(dI); (void)hipFree(db); (void)hipFree(dx); (void)hipFree(dst);
+  (void)hipFree(dA); (void)hipFree(dD); (void)hipFree(dI); (void)hipFree(db); (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dst);
   return YDORB_OK;
 }
 
