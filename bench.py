@@ -55,12 +55,37 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
+    # YDORB_BENCH_BACKEND=gloo + YDORB_BENCH_ONE_GPU=1: rehearse the N > 1 logic with every rank on cuda:0 and the collectives
+    # staged through host memory (RCCL refuses two ranks on one device).  The driver's real runs use RCCL ("nccl").
+    backend = os.environ.get("YDORB_BENCH_BACKEND", "nccl")
+    if os.environ.get("YDORB_BENCH_ONE_GPU"):
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    staged = world > 1 and backend != "nccl"
+
+    def all_reduce_(t, op):
+        if staged:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
+
+    def all_gather_into(out, inp):
+        if staged:
+            parts = [torch.zeros_like(inp, device="cpu") for _ in range(world)]
+            dist.all_gather(parts, inp.cpu())
+            out.copy_(torch.cat(parts))
+        else:
+            dist.all_gather_into_tensor(out, inp)
 
     import ydorbslam_amd as y
     from ydorbslam_amd.synth import synth_frame, synth_ba_problem
@@ -99,7 +124,7 @@ def main():
             send[:cap * 28] = d_kps[F - 1].view(torch.uint8).reshape(-1)
             send[cap * 28:cap * 60] = d_desc[F - 1].reshape(-1)
             send[cap * 60:] = d_n[F - 1:F].view(torch.uint8)
-            dist.all_gather_into_tensor(gathered, send)
+            all_gather_into(gathered, send)
             prev = (rank - 1) % world
             g = gathered[prev * rec:(prev + 1) * rec]
             b_kps[0] = g[:cap * 28].view(torch.float32).reshape(cap, 7)
@@ -129,8 +154,8 @@ def main():
     matched_local = int(d_counts.sum().item())
     kp_all = torch.tensor([kp_local], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
-        dist.all_reduce(kp_all, op=dist.ReduceOp.SUM)
+        all_reduce_(t_all, dist.ReduceOp.MAX)
+        all_reduce_(kp_all, dist.ReduceOp.SUM)
     dt = float(t_all.item())
     kp_total = float(kp_all.item())
     value = kp_total * args.steps / dt / 1e6
@@ -185,20 +210,13 @@ def main():
     if not args.no_ba:
         prob = synth_ba_problem(100, 10000, 8, seed=1)
         if world > 1:  # shard landmarks (and their edges) across ranks; every rank holds all poses
-            keep_pts = np.arange(len(prob["points"])) % world == rank
-            remap = np.cumsum(keep_pts) - 1
-            ke = keep_pts[prob["edge_point"]]
-            sub = dict(prob)
-            sub["points"] = prob["points"][keep_pts]
-            sub["edge_pose"] = prob["edge_pose"][ke]
-            sub["edge_point"] = remap[prob["edge_point"][ke]].astype(np.int32)
-            sub["meas"], sub["info"] = prob["meas"][ke], prob["info"][ke]
-            prob = sub
-            comm = torch.zeros(600 * 608 + 4096, dtype=torch.float64, device=dev)
+            from ydorbslam_amd.parallel import shard_ba_problem
+            prob, _, _ = shard_ba_problem(prob, rank, world)
+            comm = torch.zeros(640 * 641 + 4096, dtype=torch.float64, device=dev)  # >= n*n + n doubles, n = 6*K rounded up to 32
 
             def allreduce(user, d_buf, count, op):
                 try:
-                    dist.all_reduce(comm[:count], op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+                    all_reduce_(comm[:count], dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
                     torch.cuda.synchronize()
                     return 0
                 except Exception:  # noqa: BLE001
@@ -219,7 +237,7 @@ def main():
         tb = time.perf_counter() - t0
         tb_all = torch.tensor([tb], dtype=torch.float64, device=dev)
         if world > 1:
-            dist.all_reduce(tb_all, op=dist.ReduceOp.MAX)
+            all_reduce_(tb_all, dist.ReduceOp.MAX)
         tb = float(tb_all.item())
         flops_schur = 89.9e6  # Schur part of one LM trial at C5 / 8 obs
         ms = r["ms"]
