@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=128, help="frames per step and per GPU")
+    ap.add_argument("--frames", type=int, default=512, help="frames per step and per GPU")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic frames (tiled to --frames)")
     ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the CPU-oracle baseline sample")
     ap.add_argument("--no-ba", action="store_true")
@@ -98,12 +98,20 @@ def main():
     cap = ex.max_keypoints
     sf = ex.tables()["scale"]
     d_img = torch.from_numpy(imgs).to(dev)
-    d_kps = torch.zeros((F, cap, 7), dtype=torch.float32, device=dev)
-    d_desc = torch.zeros((F, cap, 32), dtype=torch.uint8, device=dev)
-    d_n = torch.zeros(F, dtype=torch.int32, device=dev)
-    d_assigned = torch.zeros((F - 1, cap), dtype=torch.int32, device=dev)
-    d_counts = torch.zeros(F - 1, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    # Two output sets + two explicit streams: extraction of step k+1 (stream A) overlaps the matching of step k (stream B).
+    # (The default stream's handle is 0, which the C ABI reads as "use the handle's own stream": always pass real streams.)
+    d_kps = [torch.zeros((F, cap, 7), dtype=torch.float32, device=dev) for _ in range(2)]
+    d_desc = [torch.zeros((F, cap, 32), dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_n = [torch.zeros(F, dtype=torch.int32, device=dev) for _ in range(2)]
+    d_assigned = [torch.zeros((F - 1, cap), dtype=torch.int32, device=dev) for _ in range(2)]
+    d_counts = [torch.zeros(F - 1, dtype=torch.int32, device=dev) for _ in range(2)]
+    sA, sB = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    ev_extracted = [torch.cuda.Event() for _ in range(2)]
+    ev_matched = [torch.cuda.Event() for _ in range(2)]
+    for e in ev_matched:
+        e.record(sB)
+    mts = [mt, y.OrbMatcher(0.9, True, device=local_rank)]   # one matcher (own scratch) per output set
+    step_no = [0]
     # cross-rank boundary pair (only N > 1): all-gather of [keypoints | descriptors] of each rank's last frame
     if world > 1:
         rec = cap * (28 + 32) + 4
@@ -117,22 +125,30 @@ def main():
         mt2 = y.OrbMatcher(0.9, True, device=local_rank)
 
     def step():
-        ex.extract_batch_device(d_img.data_ptr(), W, H, W, W * H, F, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(), stream)
-        mt.match_consecutive_device(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, F, W, H, 15.0, sf, d_assigned.data_ptr(),
-                                    d_counts.data_ptr(), None, stream)
+        b = step_no[0] & 1
+        step_no[0] += 1
+        sA.wait_event(ev_matched[b])          # the matcher that last read this output set is done
+        ex.extract_batch_device(d_img.data_ptr(), W, H, W, W * H, F, d_kps[b].data_ptr(), d_desc[b].data_ptr(), cap, d_n[b].data_ptr(),
+                                sA.cuda_stream)
+        ev_extracted[b].record(sA)
+        sB.wait_event(ev_extracted[b])
+        mts[b].match_consecutive_device(d_kps[b].data_ptr(), d_desc[b].data_ptr(), d_n[b].data_ptr(), cap, F, W, H, 15.0, sf,
+                                        d_assigned[b].data_ptr(), d_counts[b].data_ptr(), None, sB.cuda_stream)
         if world > 1:
-            send[:cap * 28] = d_kps[F - 1].view(torch.uint8).reshape(-1)
-            send[cap * 28:cap * 60] = d_desc[F - 1].reshape(-1)
-            send[cap * 60:] = d_n[F - 1:F].view(torch.uint8)
-            all_gather_into(gathered, send)
-            prev = (rank - 1) % world
-            g = gathered[prev * rec:(prev + 1) * rec]
-            b_kps[0] = g[:cap * 28].view(torch.float32).reshape(cap, 7)
-            b_desc[0] = g[cap * 28:cap * 60].reshape(cap, 32)
-            b_n[0:1] = g[cap * 60:].view(torch.int32)
-            b_kps[1], b_desc[1], b_n[1:2] = d_kps[0], d_desc[0], d_n[0:1]
-            mt2.match_consecutive_device(b_kps.data_ptr(), b_desc.data_ptr(), b_n.data_ptr(), cap, 2, W, H, 15.0, sf, b_assigned.data_ptr(),
-                                         b_counts.data_ptr(), None, stream)
+            with torch.cuda.stream(sB):
+                send[:cap * 28] = d_kps[b][F - 1].view(torch.uint8).reshape(-1)
+                send[cap * 28:cap * 60] = d_desc[b][F - 1].reshape(-1)
+                send[cap * 60:] = d_n[b][F - 1:F].view(torch.uint8)
+                all_gather_into(gathered, send)
+                prev = (rank - 1) % world
+                g = gathered[prev * rec:(prev + 1) * rec]
+                b_kps[0] = g[:cap * 28].view(torch.float32).reshape(cap, 7)
+                b_desc[0] = g[cap * 28:cap * 60].reshape(cap, 32)
+                b_n[0:1] = g[cap * 60:].view(torch.int32)
+                b_kps[1], b_desc[1], b_n[1:2] = d_kps[b][0], d_desc[b][0], d_n[b][0:1]
+                mt2.match_consecutive_device(b_kps.data_ptr(), b_desc.data_ptr(), b_n.data_ptr(), cap, 2, W, H, 15.0, sf, b_assigned.data_ptr(),
+                                             b_counts.data_ptr(), None, sB.cuda_stream)
+        ev_matched[b].record(sB)
 
     def barrier():
         torch.cuda.synchronize()
@@ -148,10 +164,11 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    mt.synchronize()  # surfaces a record-pool overflow, if any
+    for m_ in mts:
+        m_.synchronize()  # surfaces a record-pool overflow, if any
     t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
-    kp_local = int(d_n.sum().item())
-    matched_local = int(d_counts.sum().item())
+    kp_local = int(d_n[0].sum().item())
+    matched_local = int(d_counts[0].sum().item())
     kp_all = torch.tensor([kp_local], dtype=torch.float64, device=dev)
     if world > 1:
         all_reduce_(t_all, dist.ReduceOp.MAX)
@@ -168,10 +185,11 @@ def main():
     for _ in range(5):
         ex2.extract_batch(imgs)
     for _ in range(5):
-        mt.match_consecutive_device(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, F, W, H, 15.0, sf, d_assigned.data_ptr(),
-                                    d_counts.data_ptr())
+        mt.match_consecutive_device(d_kps[0].data_ptr(), d_desc[0].data_ptr(), d_n[0].data_ptr(), cap, F, W, H, 15.0, sf, d_assigned[0].data_ptr(),
+                                    d_counts[0].data_ptr())
         mt.synchronize()
-    mt.match_consecutive_device(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, F, W, H, 15.0, sf, d_assigned.data_ptr(), d_counts.data_ptr())
+    mt.match_consecutive_device(d_kps[0].data_ptr(), d_desc[0].data_ptr(), d_n[0].data_ptr(), cap, F, W, H, 15.0, sf, d_assigned[0].data_ptr(),
+                                d_counts[0].data_ptr())
     mt.synchronize()
     stages = dict(ex2.stage_times())
     stages.update(mt.stage_times())
@@ -184,7 +202,7 @@ def main():
     kbytes = {
         "pyramid": W * H + pyr_pad,                       # read image, write padded pyramid
         "fast_cells": pyr_pad,                            # read every pyramid pixel once (candidates are << 1 %)
-        "quadtree": 8 * 4200 * 4,                         # read ~4.2 k packed candidates per level (measured average), write keypoints
+        "quadtree_after_blur": 8 * 4200 * 4,                         # read ~4.2 k packed candidates per level (measured average), write keypoints
         "blur": 2 * (A_frame - W * H - NFEAT * 60),       # read pyramid, write blurred levels
         "orient_describe": int(n_kp_frame) * (60 + 2 * 1849),  # 43x43 patch of the level and of the blurred level + 60 B out
         "grid_build": int(n_kp_frame) * (28 + 4),

@@ -446,12 +446,12 @@ struct QtWaveCtx {
 // node ids [ldsCandCap] u16 x2, cellBase[maxCells+1]
 __global__ __launch_bounds__(kQtThreads) void k_quadtree(PlanDev P, const uint32_t* __restrict__ cellCount,
                                                  const uint32_t* __restrict__ cellCand, uint32_t* __restrict__ qtCand,
-                                                 uint16_t* __restrict__ qtNode, size_t qtFrameStride, int nodeCap, int ldsCandCap,
+                                                 uint16_t* __restrict__ qtNode, size_t qtFrameStride, int nodeCap, int ldsCandCap, int levelBase,
                                                  uint32_t* __restrict__ lvlKp, int* __restrict__ lvlCount, int* __restrict__ status) {
   extern __shared__ __align__(16) uint8_t smem[];
   __shared__ unsigned w32[16];
   __shared__ unsigned long long w64[16];
-  const int level = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+  const int level = levelBase + blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
   const LevelDev L = P.lv[level];
   uint8_t* sp = smem;
   QtShared S;

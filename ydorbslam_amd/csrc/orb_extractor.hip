@@ -30,15 +30,16 @@ struct HostPlan {
   PlanDev dev{};
   std::vector<CellDev> cells;
   size_t pyrFrameStride = 0, blurFrameStride = 0, qtFrameStride = 0;
-  int nodeCap = 0, maxCellsPerLevel = 0, ldsCandCap = 0;
-  size_t qtLds = 0;
+  // quad-tree launch geometry per level: node table for 4*quota nodes, LDS-resident candidates up to candCap (HBM beyond)
+  struct QtLevel { int nodeCap, candCap; size_t lds; } qt[kMaxLevels]{};
+  size_t qtLdsMax = 0;
   std::vector<int> tabInt;      // xofs|yofs per level
   std::vector<short> tabShort;  // alpha|beta per level
   struct TabOff { int xofs, yofs, alpha, beta; } tab[kMaxLevels]{};
 };
 
 enum Stage { ST_PYR = 0, ST_FAST, ST_QT, ST_BLUR, ST_DESC, ST_COUNT };
-const char* kStageNames[ST_COUNT] = {"pyramid", "fast_cells", "quadtree", "blur", "orient_describe"};
+const char* kStageNames[ST_COUNT] = {"pyramid", "fast_cells", "blur", "quadtree_after_blur", "orient_describe"};
 
 }  // namespace
 
@@ -49,6 +50,8 @@ struct ydorb_extractor {
   int maxX[16]{};
   int sumQuota = 0;
   hipStream_t stream = nullptr;
+  hipStream_t qtStream[kMaxLevels]{};   // side streams of the per-level quad-tree launches
+  hipEvent_t evFork = nullptr, evJoin[kMaxLevels]{};
   HostPlan plan;
   bool planValid = false;
   int batchCap = 0;
@@ -153,7 +156,6 @@ int buildPlan(ydorb_extractor* e, int w, int h, HostPlan& P) {
       }
     }
     L.nCells = (int)P.cells.size() - L.cellBegin;
-    P.maxCellsPerLevel = std::max(P.maxCellsPerLevel, L.nCells);
     // resize tables (cv::resize INTER_LINEAR 8U: float coordinate, 11-bit coefficients), level >= 1
     if (l > 0) {
       const LevelDev& Lp = D.lv[l - 1];
@@ -197,19 +199,26 @@ int buildPlan(ydorb_extractor* e, int w, int h, HostPlan& P) {
   P.pyrFrameStride = padOff;
   P.blurFrameStride = blurOff;
   P.qtFrameStride = (size_t)candOff;
-  int maxQuota = 1;
-  for (int l = 0; l < D.nLevels; l++) maxQuota = std::max(maxQuota, D.lv[l].quota);
-  P.nodeCap = 4 * maxQuota;
-  P.qtLds = (size_t)P.nodeCap * (8 + 8 + 8 + 8 + 4 + 4 + 4 + 4) + (size_t)(P.maxCellsPerLevel + 1) * 4;
-  // a level with up to ldsCandCap FAST candidates keeps its whole candidate state (2 x u32 + 2 x u16 per entry) in LDS
-#ifndef QT_LDSCAP
-#define QT_LDSCAP 2560
-#endif
-  P.ldsCandCap = (int)std::min<size_t>(QT_LDSCAP, (120 * 1024 > P.qtLds ? (120 * 1024 - P.qtLds) / 12 : 0)) / 64 * 64;
-  P.qtLds += (size_t)P.ldsCandCap * 12;
-  if (P.qtLds > 150 * 1024) {
-    set_error("n_features=%d needs %zu B of LDS for the quad-tree (max 150 KiB)", e->cfg.n_features, P.qtLds);
-    return YDORB_ERR_UNSUPPORTED;
+  // One quad-tree launch per level on its own stream, each with exactly the LDS that level needs: with one uniform
+  // launch the level-0 footprint (~100 KB) limited every (frame, level) unit to one or two per CU although the small
+  // levels need < 30 KB.  candCap: expected candidate density grows with the level (measured 1/65 .. 1/25 of the band
+  // area on noise-like frames); a level with more candidates than candCap runs from HBM scratch instead (same result).
+  for (int l = 0; l < D.nLevels; l++) {
+    const LevelDev& L = D.lv[l];
+    HostPlan::QtLevel& Q = P.qt[l];
+    Q.nodeCap = 4 * std::max(L.quota, 1);
+    const long band = (long)std::max(L.w - 2 * kBorder, 1) * std::max(L.h - 2 * kBorder, 1);
+    Q.candCap = (int)std::min<long>(4608, std::max<long>(512, band / 22)) / 64 * 64;
+    Q.lds = (size_t)Q.nodeCap * 48 + (size_t)Q.candCap * 12 + (size_t)(L.nCells + 1) * 4;
+    if (Q.lds > 150 * 1024) {  // very large n_features: keep the node table, drop the LDS candidates
+      Q.candCap = 0;
+      Q.lds = (size_t)Q.nodeCap * 48 + (size_t)(L.nCells + 1) * 4;
+    }
+    if (Q.lds > 150 * 1024) {
+      set_error("n_features=%d needs %zu B of LDS for the level-%d quad-tree (max 150 KiB)", e->cfg.n_features, Q.lds, l);
+      return YDORB_ERR_UNSUPPORTED;
+    }
+    P.qtLdsMax = std::max(P.qtLdsMax, Q.lds);
   }
   return YDORB_OK;
 }
@@ -254,8 +263,8 @@ int ensurePlan(ydorb_extractor* e, int w, int h, int nFrames) {
   if (!P.tabShort.empty()) HIPCHK(hipMemcpyAsync(e->d_tabShort, P.tabShort.data(), sizeof(short) * P.tabShort.size(), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipMemsetAsync(e->d_status, 0, sizeof(int), e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
-  if (P.qtLds > 48 * 1024)
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.qtLds));
+  if (P.qtLdsMax > 48 * 1024)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.qtLdsMax));
   e->planValid = true;
   return YDORB_OK;
 }
@@ -284,15 +293,22 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
     hipLaunchKernelGGL(k_fast_cells, dim3(D.nCellsTotal, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, D, e->d_cells,
                        std::min(std::max(e->cfg.ini_fast_thr, 0), 255), e->d_cellCount, e->d_cellCand);
   if (prof) HIPCHK(hipEventRecord(e->ev[2], s));
-  hipLaunchKernelGGL(k_quadtree, dim3(D.nLevels, nFrames), dim3(kQtThreads), P.qtLds, s, D, e->d_cellCount, e->d_cellCand,
-                     e->d_qtCand, e->d_qtNode, P.qtFrameStride, P.nodeCap, P.ldsCandCap, e->d_lvlKp, e->d_lvlCount, e->d_status);
-  if (prof) HIPCHK(hipEventRecord(e->ev[3], s));
+  // fork: one quad-tree launch per level on the side streams; the blur (needs only the pyramid) runs on `s` meanwhile
+  HIPCHK(hipEventRecord(e->evFork, s));
+  for (int l = 0; l < D.nLevels; l++) {
+    HIPCHK(hipStreamWaitEvent(e->qtStream[l], e->evFork, 0));
+    hipLaunchKernelGGL(k_quadtree, dim3(1, nFrames), dim3(kQtThreads), P.qt[l].lds, e->qtStream[l], D, e->d_cellCount, e->d_cellCand,
+                       e->d_qtCand, e->d_qtNode, P.qtFrameStride, P.qt[l].nodeCap, P.qt[l].candCap, l, e->d_lvlKp, e->d_lvlCount, e->d_status);
+    HIPCHK(hipEventRecord(e->evJoin[l], e->qtStream[l]));
+  }
   {
     int maxTiles = 0;
     for (int l = 0; l < D.nLevels; l++) maxTiles = std::max(maxTiles, ((D.lv[l].w + 63) / 64) * ((D.lv[l].h + 15) / 16));
     hipLaunchKernelGGL(k_blur, dim3(maxTiles, D.nLevels, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
                        P.blurFrameStride, D);
   }
+  if (prof) HIPCHK(hipEventRecord(e->ev[3], s));   // end of the blur; the quad-tree stage is the interval up to the join below
+  for (int l = 0; l < D.nLevels; l++) HIPCHK(hipStreamWaitEvent(s, e->evJoin[l], 0));
   if (prof) HIPCHK(hipEventRecord(e->ev[4], s));
   hipLaunchKernelGGL(k_orient_describe, dim3((D.sumQuota + 3) / 4, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
                      P.blurFrameStride, D, e->d_lvlKp, e->d_lvlCount, d_kps, d_desc, cap, d_nOut, e->d_lvlAngle);
@@ -371,6 +387,11 @@ int ydorb_extractor_create(const YdExtractorConfig* cfg, ydorb_extractor_t** out
     return YDORB_ERR_HIP;
   }
   for (auto& ev : e->ev) (void)hipEventCreate(&ev);
+  (void)hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming);
+  for (int l = 0; l < kMaxLevels; l++) {
+    (void)hipStreamCreateWithFlags(&e->qtStream[l], hipStreamNonBlocking);
+    (void)hipEventCreateWithFlags(&e->evJoin[l], hipEventDisableTiming);
+  }
   *out = e;
   return YDORB_OK;
 }
@@ -381,6 +402,11 @@ void ydorb_extractor_destroy(ydorb_extractor_t* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   freeBuffers(e);
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+  for (int l = 0; l < kMaxLevels; l++) {
+    if (e->qtStream[l]) { (void)hipStreamSynchronize(e->qtStream[l]); (void)hipStreamDestroy(e->qtStream[l]); }
+    if (e->evJoin[l]) (void)hipEventDestroy(e->evJoin[l]);
+  }
+  if (e->evFork) (void)hipEventDestroy(e->evFork);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
