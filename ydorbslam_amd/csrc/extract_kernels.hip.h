@@ -244,21 +244,27 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     return;
   }
   const uint8_t* roi = pyr + (size_t)f * pyrFrameStride + L.padOff + (size_t)kPad * L.pitch + kPad;
-  for (int i = threadIdx.x; i < tw * th; i += 256) {
-    const int ty = i / tw, tx = i - ty * tw;
-    tile[ty * kTileMax + tx] = roi[(size_t)(c.y0 + ty) * L.pitch + c.x0 + tx];
+  {  // tile load: (unaligned) dwords, 18 per row cover up to 72 px (reads past tw stay inside the level's 19-px padding)
+    const int wpr = (tw + 3) >> 2;
+    const float rw = 1.0f / (float)wpr;
+    for (int i = threadIdx.x; i < wpr * th; i += 256) {
+      const int ty = (int)(((float)i + 0.5f) * rw), wd = i - ty * wpr;
+      *reinterpret_cast<uint32_t*>(&tile[ty * kTileMax + 4 * wd]) =
+          *reinterpret_cast<const u32_unaligned*>(roi + (size_t)(c.y0 + ty) * L.pitch + c.x0 + 4 * wd);
+    }
   }
   const int sw = bw + 2, sh = bh + 2;  // score map with a zero ring
   for (int i = threadIdx.x; i < sw * sh; i += 256) score[i] = 0;
   __syncthreads();
   const int nBand = bw * bh;
+  const float rbw = 1.0f / (float)bw;   // i / bw as (int)((i + 0.5f) * rbw): exact for i < 4096
   // stage A: compass test over the band
   int n1 = 0;
   for (int base = 0; base < nBand; base += 256) {
     const int i = base + threadIdx.x;
     bool keep = false;
     if (i < nBand) {
-      const int by = i / bw, bx = i - by * bw;
+      const int by = (int)(((float)i + 0.5f) * rbw), bx = i - by * bw;
       const uint8_t* p = &tile[(by + 3) * kTileMax + bx + 3];
       const int v = p[0], hi = v + thr, lo = v - thr;
       const int r0 = p[3 * kTileMax], r4 = p[3], r8 = p[-3 * kTileMax], r12 = p[-3];
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     unsigned ent = 0;
     if (j < n1) {
       const int i = list[j];
-      const int by = i / bw, bx = i - by * bw;
+      const int by = (int)(((float)i + 0.5f) * rbw), bx = i - by * bw;
       const uint8_t* p = &tile[(by + 3) * kTileMax + bx + 3];
       const int v = p[0];
       int ring[16];
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
   for (int j = threadIdx.x; j < n2; j += 256) {
     const unsigned ent = list[j];
     const int i = ent & 0xFFF;
-    const int by = i / bw, bx = i - by * bw;
+    const int by = (int)(((float)i + 0.5f) * rbw), bx = i - by * bw;
     const uint8_t* p = &tile[(by + 3) * kTileMax + bx + 3];
     int ring[16];
     fast_ring(p, ring);
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     int bx = 0, by = 0, s = 0;
     if (j < n2) {
       const int i = list[j] & 0xFFF;
-      by = i / bw;
+      by = (int)(((float)i + 0.5f) * rbw);
       bx = i - by * bw;
       const uint8_t* q = &score[(by + 1) * sw + bx + 1];
       s = q[0];
