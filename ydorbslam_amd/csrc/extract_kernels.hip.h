@@ -233,7 +233,16 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
   __shared__ uint8_t score[(kTileMax - 4) * (kTileMax - 4)];
   __shared__ uint16_t list[(kTileMax - 6) * (kTileMax - 6)];   // pixel index (12 bits) | dark << 14 | bright << 15
   __shared__ int waveCnt[4];
-  const int cellId = blockIdx.x, f = blockIdx.y;
+  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own L2); gridDim.x is a multiple of 8, so
+  // block (bx, f) runs on XCD bx % 8.  Inside every group of 8 frames the (bx, f) pairs are permuted so that XCD x processes ALL
+  // cells of frame 8*(f/8) + x: the 6-px halo a cell shares with its neighbours (and the level a frame's cells share) is then
+  // fetched into one L2 instead of eight, while different XCDs still stream different frames (no channel hot-spot).
+  int cellId = blockIdx.x, f = blockIdx.y;
+  if ((f | 7) < (int)gridDim.y) {   // a full group of 8 frames
+    cellId = (f & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    f = (f & ~7) | (blockIdx.x & 7);
+  }
+  if (cellId >= P.nCellsTotal) return;
   const CellDev c = cells[cellId];
   const LevelDev L = P.lv[c.level];
   const int tw = c.x1 - c.x0, th = c.y1 - c.y0;
@@ -530,11 +539,16 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, s
   constexpr int TW = 64, TH = 16, SH = TH + 6, SWW = 18;  // source tile: 22 rows x 18 dwords (72 B: cols x0-3 .. x0+68)
   __shared__ uint32_t src[SH * SWW];
   __shared__ __align__(8) uint16_t hb[SH * TW];
-  const int level = blockIdx.y, f = blockIdx.z;
+  const int level = blockIdx.y;
+  int f = blockIdx.z, tileId = blockIdx.x;
+  if ((f | 7) < (int)gridDim.z) {   // XCD-aware (see k_fast_cells): XCD x handles every tile of frame 8*(f/8) + x
+    tileId = (f & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    f = (f & ~7) | (blockIdx.x & 7);
+  }
   const LevelDev L = P.lv[level];
   const int tilesX = (L.w + TW - 1) / TW, tilesY = (L.h + TH - 1) / TH;
-  if ((int)blockIdx.x >= tilesX * tilesY) return;
-  const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
+  if (tileId >= tilesX * tilesY) return;
+  const int ty = tileId / tilesX, tx = tileId - ty * tilesX;
   const int x0 = tx * TW, y0 = ty * TH;
   // padded-row coordinates: level x <-> x + 19, so the tile's first source column x0-3 sits at byte x0+16: dword aligned
   // (pitch and padOff are multiples of 64), and the source loads are whole dwords.

@@ -290,7 +290,7 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   }
   if (prof) HIPCHK(hipEventRecord(e->ev[1], s));
   if (D.nCellsTotal > 0)
-    hipLaunchKernelGGL(k_fast_cells, dim3(D.nCellsTotal, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, D, e->d_cells,
+    hipLaunchKernelGGL(k_fast_cells, dim3((D.nCellsTotal + 7) / 8 * 8, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, D, e->d_cells,
                        std::min(std::max(e->cfg.ini_fast_thr, 0), 255), e->d_cellCount, e->d_cellCand);
   if (prof) HIPCHK(hipEventRecord(e->ev[2], s));
   // fork: one quad-tree launch per level on the side streams; the blur (needs only the pyramid) runs on `s` meanwhile
@@ -304,7 +304,7 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   {
     int maxTiles = 0;
     for (int l = 0; l < D.nLevels; l++) maxTiles = std::max(maxTiles, ((D.lv[l].w + 63) / 64) * ((D.lv[l].h + 15) / 16));
-    hipLaunchKernelGGL(k_blur, dim3(maxTiles, D.nLevels, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
+    hipLaunchKernelGGL(k_blur, dim3((maxTiles + 7) / 8 * 8, D.nLevels, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
                        P.blurFrameStride, D);
   }
   if (prof) HIPCHK(hipEventRecord(e->ev[3], s));   // end of the blur; the quad-tree stage is the interval up to the join below
