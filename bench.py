@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--frames", type=int, default=512, help="frames per step and per GPU")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic frames (tiled to --frames)")
     ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the CPU-oracle baseline sample")
+    ap.add_argument("--extractors", type=int, default=2, help="extractor handles (each with its own stream) the frames of a step are split over")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -93,7 +94,12 @@ def main():
     F = args.frames
     distinct = [synth_frame(W, H, rank * 1000 + i) for i in range(min(args.distinct, F))]
     imgs = np.stack([distinct[i % len(distinct)] for i in range(F)])
-    ex = y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=F)
+    # The frames of a step are split over `--extractors` handles, each with its own stream (like the reference's two extractor
+    # objects for stereo): while one handle sits in its latency-bound quad-tree stage the other's pyramid/FAST kernels fill the chip.
+    NEX = max(1, min(args.extractors, F // 8))
+    parts = [(i * F // NEX, (i + 1) * F // NEX) for i in range(NEX)]
+    exs = [y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=b - a) for a, b in parts]
+    ex = exs[0]
     mt = y.OrbMatcher(0.9, True, device=local_rank)
     cap = ex.max_keypoints
     sf = ex.tables()["scale"]
@@ -105,8 +111,8 @@ def main():
     d_n = [torch.zeros(F, dtype=torch.int32, device=dev) for _ in range(2)]
     d_assigned = [torch.zeros((F - 1, cap), dtype=torch.int32, device=dev) for _ in range(2)]
     d_counts = [torch.zeros(F - 1, dtype=torch.int32, device=dev) for _ in range(2)]
-    sA, sB = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-    ev_extracted = [torch.cuda.Event() for _ in range(2)]
+    sAs, sB = [torch.cuda.Stream(device=dev) for _ in range(NEX)], torch.cuda.Stream(device=dev)
+    ev_extracted = [[torch.cuda.Event() for _ in range(NEX)] for _ in range(2)]
     ev_matched = [torch.cuda.Event() for _ in range(2)]
     for e in ev_matched:
         e.record(sB)
@@ -127,11 +133,13 @@ def main():
     def step():
         b = step_no[0] & 1
         step_no[0] += 1
-        sA.wait_event(ev_matched[b])          # the matcher that last read this output set is done
-        ex.extract_batch_device(d_img.data_ptr(), W, H, W, W * H, F, d_kps[b].data_ptr(), d_desc[b].data_ptr(), cap, d_n[b].data_ptr(),
-                                sA.cuda_stream)
-        ev_extracted[b].record(sA)
-        sB.wait_event(ev_extracted[b])
+        for i, (f0, f1) in enumerate(parts):
+            sA = sAs[i]
+            sA.wait_event(ev_matched[b])          # the matcher that last read this output set is done
+            exs[i].extract_batch_device(d_img[f0].data_ptr(), W, H, W, W * H, f1 - f0, d_kps[b][f0].data_ptr(), d_desc[b][f0].data_ptr(), cap,
+                                        d_n[b][f0:].data_ptr(), sA.cuda_stream)
+            ev_extracted[b][i].record(sA)
+            sB.wait_event(ev_extracted[b][i])
         mts[b].match_consecutive_device(d_kps[b].data_ptr(), d_desc[b].data_ptr(), d_n[b].data_ptr(), cap, F, W, H, 15.0, sf,
                                         d_assigned[b].data_ptr(), d_counts[b].data_ptr(), None, sB.cuda_stream)
         if world > 1:
@@ -179,11 +187,12 @@ def main():
     ms_per_step = dt / args.steps * 1e3
 
     # ---- roofline of the dominant kernel: per-stage device time, HIP events on the launch stream -------------------
-    ex2 = y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=F)
+    FL = parts[0][1] - parts[0][0]   # frames per extractor launch in the timed run
+    ex2 = y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=FL)
     ex2.set_profiling(True)
     mt.set_profiling(True)
     for _ in range(5):
-        ex2.extract_batch(imgs)
+        ex2.extract_batch(imgs[:FL])
     for _ in range(5):
         mt.match_consecutive_device(d_kps[0].data_ptr(), d_desc[0].data_ptr(), d_n[0].data_ptr(), cap, F, W, H, 15.0, sf, d_assigned[0].data_ptr(),
                                     d_counts[0].data_ptr())
@@ -210,17 +219,32 @@ def main():
         "resolve": int(n_kp_frame) * 24 * 4,
     }
     t_dom = stages[dom] * 1e-3
-    achieved = kbytes.get(dom, A_frame) * F / t_dom if t_dom > 0 else 0.0
+    launch_frames = F if dom in ("grid_build", "gather_distances", "resolve") else FL
+    achieved = kbytes.get(dom, A_frame) * launch_frames / t_dom if t_dom > 0 else 0.0
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01c_pmc_hbm_traffic.csv: separate
+    # FETCH_SIZE / WRITE_SIZE runs of the same kernels at 128 frames per launch; FETCH under-counts this 4-byte access pattern
+    # by 1.33x, calibrated on k_pyr_level0's known read size; WRITE_SIZE is exact) scaled to this run's frames per launch.
+    traffic = None
+    try:
+        import csv
+        stage_kernels = {"pyramid": ("k_pyr_level0", "k_pyr_resize"), "fast_cells": ("k_fast_cells",), "blur": ("k_blur",),
+                         "quadtree_after_blur": ("k_quadtree",), "orient_describe": ("k_orient_describe",)}
+        rows = {r["kernel"]: r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01c_pmc_hbm_traffic.csv")))}
+        if dom in stage_kernels:
+            per_frame = sum(float(rows[k]["fetch_MB_per_frame_raw"]) * 1.33 + float(rows[k]["write_MB_per_frame"]) for k in stage_kernels[dom])
+            traffic = per_frame * 1e6 * (F / NEX)
+    except Exception:  # noqa: BLE001
+        traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK, "traffic": None,
+                "frac": achieved / HBM_PEAK, "traffic": traffic,
                 "pipeline_achieved_GBps": A_frame * F * args.steps / dt / 1e9, "pipeline_frac": A_frame * F * args.steps / dt / HBM_PEAK,
-                "stage_ms_per_batch": {k: round(v, 4) for k, v in stages.items()}}
+                "stage_ms_per_launch": {k: round(v, 4) for k, v in stages.items()}, "frames_per_extract_launch": FL, "frames_per_match_launch": F}
 
     out = {"metric": "ORB extract+match Mkeypoints/sec", "value": value, "unit": "Mkeypoints/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u8", "data": "synthetic",
            "config": {"workload": "TUM-fr1-size 640x480 mono stream, 1000 feat/frame, extract + consecutive-frame searchByProjection",
-                      "frames_per_step_per_gpu": F, "distinct_frames": len(distinct), "keypoints_per_frame": n_kp_frame,
+                      "frames_per_step_per_gpu": F, "extractor_handles": NEX, "distinct_frames": len(distinct), "keypoints_per_frame": n_kp_frame,
                       "matches_per_pair": matched_local / max(F - 1, 1), "parallelism": "frames sharded x%d" % world},
            "roofline": roofline}
 

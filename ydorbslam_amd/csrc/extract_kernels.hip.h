@@ -663,8 +663,12 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
                                                          YdKeyPointDev* __restrict__ kps, uint8_t* __restrict__ desc, int cap,
                                                          int* __restrict__ nOut, float* __restrict__ lvlAngle) {
   const int lane = threadIdx.x & 63;
-  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int f = blockIdx.y;
+  int bx = blockIdx.x, f = blockIdx.y;
+  if ((f | 7) < (int)gridDim.y) {   // XCD-aware (see k_fast_cells): every keypoint of a frame reads its patches through one L2
+    bx = (f & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    f = (f & ~7) | (blockIdx.x & 7);
+  }
+  const int slot = bx * 4 + (threadIdx.x >> 6);
   if (slot >= P.sumQuota) return;
   int level = 0, before = 0, tot = 0;
   for (int l = 0; l < P.nLevels; l++) {

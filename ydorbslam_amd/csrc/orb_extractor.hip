@@ -310,7 +310,7 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   if (prof) HIPCHK(hipEventRecord(e->ev[3], s));   // end of the blur; the quad-tree stage is the interval up to the join below
   for (int l = 0; l < D.nLevels; l++) HIPCHK(hipStreamWaitEvent(s, e->evJoin[l], 0));
   if (prof) HIPCHK(hipEventRecord(e->ev[4], s));
-  hipLaunchKernelGGL(k_orient_describe, dim3((D.sumQuota + 3) / 4, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
+  hipLaunchKernelGGL(k_orient_describe, dim3(((D.sumQuota + 3) / 4 + 7) / 8 * 8, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
                      P.blurFrameStride, D, e->d_lvlKp, e->d_lvlCount, d_kps, d_desc, cap, d_nOut, e->d_lvlAngle);
   if (prof) HIPCHK(hipEventRecord(e->ev[5], s));
   HIPCHK(hipGetLastError());
