@@ -106,7 +106,9 @@ int ydorb_extractor_read_level(ydorb_extractor_t* h, int32_t frame, int32_t leve
 /* Test/diagnostic access to intermediate stages of the last call (parity tests compare each stage
  * with the oracle).  what: 0 = blurred level (hgt x w bytes), 1 = pre-quad-tree candidates
  * (YdKeyPoint[], border-relative coords as at orbExtractor.cpp:587-589), 2 = per-level keypoints after
- * orientation (YdKeyPoint[], level coords).  Returns bytes written in *written. */
+ * orientation (YdKeyPoint[], level coords), 3 = one byte: which quad-tree kernel produced the (frame, level) unit
+ * (0 = flat histogram/sort form, 1 = pass form; YDORB_QT_PASS=1 in the environment at create forces 1).
+ * Returns bytes written in *written. */
 int ydorb_extractor_debug_read(ydorb_extractor_t* h, int32_t what, int32_t frame, int32_t level, void* dst,
                                size_t dst_bytes, size_t* written);
 

@@ -103,3 +103,30 @@ def test_strided_input(oracle_lib):
     ck, cd = cpu.extract(np.ascontiguousarray(view))
     _same_kps(kps[:n.value], ck)
     assert np.array_equal(desc[:n.value], cd)
+
+
+def test_quadtree_flat_and_pass_kernels_agree(oracle_lib, monkeypatch):
+    """The thinning has two device forms: the flat one (histogram pyramid / all-pairs prefixes + one stable sort,
+    quadtree_flat.h) and the pass one (quadtree_core.h, taken for units the flat form hands over).  Both must give the
+    oracle's keypoints on dense frames, sparse frames (deep trees: few candidates, nearly all kept) and the real image."""
+    import os
+    import ydorbslam_amd as y
+    from oracle.orb_oracle import OrbExtractorOracle
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dbow3_image0_orb.npz"))
+    frames = [synth_frame(640, 480, 11), g["image"], synth_frame(640, 480, 12).copy(), np.full((480, 640), 90, np.uint8)]
+    frames[2][:240] = 128                                             # half-empty
+    frames[3][100:150, 100:160] = synth_frame(640, 480, 13)[100:150, 100:160]   # one small textured patch
+    imgs = np.stack(frames)
+    flat = y.OrbExtractor(1000, 1.2, 8, 20, 7, max_batch=len(frames))
+    monkeypatch.setenv("YDORB_QT_PASS", "1")
+    passk = y.OrbExtractor(1000, 1.2, 8, 20, 7, max_batch=len(frames))
+    monkeypatch.delenv("YDORB_QT_PASS")
+    rf, rp = flat.extract_batch(imgs), passk.extract_batch(imgs)
+    for f, img in enumerate(frames):
+        ck, cd = OrbExtractorOracle(1000, 1.2, 8, 20, 7).extract(img)
+        for (k, d) in (rf[f], rp[f]):
+            _same_kps(k, ck)
+            assert np.array_equal(d, cd)
+        for l in range(8):
+            assert flat.debug_read(3, l, f) == 0      # the flat kernel itself finished every one of these units
+            assert passk.debug_read(3, l, f) == 1

@@ -123,6 +123,43 @@ def test_product_quadtree_core_matches_oracle(oracle_lib, qt_harness):
             assert np.array_equal(out[:n] >> 24, k["response"].astype(np.uint32))
 
 
+def test_flat_quadtree_formulation_matches_pass_algorithm(qt_harness):
+    """quadtree_flat.h: histogram-pyramid form (7 levels, reports -2 for deeper trees) and all-pairs form (15 levels) against the
+    pass algorithm (itself checked against the oracle above) on random, clustered and shuffled candidate sets."""
+    rng = np.random.default_rng(5)
+    deep = 0
+    for t in range(400):
+        W, H = int(rng.integers(2, 1300)), int(rng.integers(2, 500))
+        mode = int(rng.integers(0, 4))
+        n = min(int(rng.integers(1, 3000)) if mode else int(rng.integers(1, 40)), W * H)
+        if mode == 2:
+            cx, cy, k = rng.integers(0, W, 6), rng.integers(0, H, 6), rng.integers(0, 6, n)
+            x = np.clip(cx[k] + rng.normal(0, 5, n), 0, W - 1).astype(np.int64)
+            y = np.clip(cy[k] + rng.normal(0, 5, n), 0, H - 1).astype(np.int64)
+            pix = np.unique(y * W + x)
+        else:
+            pix = np.sort(rng.choice(W * H, n, replace=False))
+        if mode == 3:
+            pix = rng.permutation(pix)
+        n = len(pix)
+        r = rng.integers(7, int(rng.choice([9, 30, 255])), n).astype(np.uint32)
+        packed = ((pix % W).astype(np.uint32) | ((pix // W).astype(np.uint32) << 12) | (r << 24)).astype(np.uint32)
+        quota = int(rng.choice([1, 2, 5, 30, 60, 120, 217, 400, 1000]))
+        ref, a, b = (np.zeros(4 * quota + 8, np.uint32) for _ in range(3))
+        P = C.c_int(0)
+        pp = packed.ctypes.data_as(C.c_void_p)
+        n0 = qt_harness.qt_cpu_distribute(pp, n, W, H, quota, ref.ctypes.data_as(C.c_void_p))
+        n1 = qt_harness.qt_flat_distribute(pp, n, W, H, quota, a.ctypes.data_as(C.c_void_p), C.byref(P))
+        if n1 == -2:
+            deep += 1
+        else:
+            assert n1 == n0 and np.array_equal(a[:n0], ref[:n0])
+        if n <= 1024:
+            n2 = qt_harness.qt_pair_distribute(pp, n, W, H, quota, b.ctypes.data_as(C.c_void_p), C.byref(P))
+            assert n2 == n0 and np.array_equal(b[:n0], ref[:n0])
+    assert 0 < deep < 200
+
+
 def test_sort_front_emulation_matches_libstdcxx(qt_harness):
     """Best-per-node uses std::sort(...).front() (orbExtractor.cpp:536-539); ties depend on libstdc++'s introsort."""
     rng = np.random.default_rng(0)

@@ -10,7 +10,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <rocprim/block/block_radix_sort.hpp>
 #include "quadtree_core.h"
+#include "quadtree_flat.h"
 
 #pragma clang fp contract(off)
 
@@ -462,11 +464,13 @@ struct QtWaveCtx {
 __global__ __launch_bounds__(kQtThreads) void k_quadtree(PlanDev P, const uint32_t* __restrict__ cellCount,
                                                  const uint32_t* __restrict__ cellCand, uint32_t* __restrict__ qtCand,
                                                  uint16_t* __restrict__ qtNode, size_t qtFrameStride, int nodeCap, int ldsCandCap, int levelBase,
-                                                 uint32_t* __restrict__ lvlKp, int* __restrict__ lvlCount, int* __restrict__ status) {
+                                                 uint32_t* __restrict__ lvlKp, int* __restrict__ lvlCount, int* __restrict__ status,
+                                                 const uint8_t* __restrict__ needPass) {
   extern __shared__ __align__(16) uint8_t smem[];
   __shared__ unsigned w32[16];
   __shared__ unsigned long long w64[16];
   const int level = levelBase + blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+  if (needPass && !needPass[f * kMaxLevels + level]) return;   // k_quadtree_flat already produced this unit
   const LevelDev L = P.lv[level];
   uint8_t* sp = smem;
   QtShared S;
@@ -527,6 +531,345 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(PlanDev P, const uint32
     }
   }
   if (lane == 0) lvlCount[f * kMaxLevels + level] = nOut;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Quad-tree thinning without passes (quadtree_flat.h): path keys -> histogram pyramid (all-pairs prefixes when a unit with
+// <= 1024 candidates has a tree deeper than the pyramid) -> number of passes P the reference would run -> final list rank R per candidate -> ONE stable sort by R ->
+// best keypoint of the first `quota` nodes.  One 512-thread workgroup per (frame, level); units the flat form cannot take
+// (more candidates than 512*ITEMS, or a tree deeper than the pyramid) raise needPass and k_quadtree (the pass algorithm)
+// processes exactly those afterwards.
+// LDS: cand u32[CAP] | union{hist pyramid u16[21845], sort storage + 512 hand-off keys, keys of the std::sort replay u32[CAP],
+//      all-pairs key/R arrays, cellBase} | head flags u8[CAP] | nodeStart u16[quota+2] | per-node max keys u32[2][quota+1]
+// ------------------------------------------------------------------------------------------------
+#ifdef QT_FLAT_TIMING
+__device__ long long g_qtClk[kMaxLevels][16];
+#define QT_CLK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_qtClk[level][i] = wall_clock64(); } while (0)
+#else
+#define QT_CLK(i) do { } while (0)
+#endif
+constexpr int kQtFlatThreads = 512;
+constexpr int kQtFlatUnion = 43696;   // kQtFlatBins u16 rounded up to 16 B; >= sort storage (<= 32 KB) + 2 KB, >= 4*CAP for CAP <= 8192
+constexpr int kQtSmall = 1024;        // all-pairs variant up to this many candidates
+inline size_t qt_flat_lds_bytes(int items, int quota) {
+  const size_t cap = (size_t)kQtFlatThreads * items;
+  return 4 * cap + kQtFlatUnion + cap + 2 * ((size_t)quota + 2) + 8 * ((size_t)quota + 2) + 16;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)v, d, 64), hi = __shfl_xor((unsigned)(v >> 32), d, 64);
+    v += ((unsigned long long)hi << 32) | lo;
+  }
+  return v;
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(kQtFlatThreads) void k_quadtree_flat(PlanDev P, const uint32_t* __restrict__ cellCount,
+                                                                  const uint32_t* __restrict__ cellCand, int level,
+                                                                  uint32_t* __restrict__ lvlKp, int* __restrict__ lvlCount,
+                                                                  uint8_t* __restrict__ needPass, int* __restrict__ lvlMaxN) {
+  constexpr int NT = kQtFlatThreads, CAP = NT * ITEMS;
+  using Sort = rocprim::block_radix_sort<uint32_t, NT, ITEMS, uint32_t>;
+  static_assert(sizeof(typename Sort::storage_type) + 4 * NT <= kQtFlatUnion && 4 * CAP <= kQtFlatUnion, "union region too small");
+  extern __shared__ __align__(16) uint8_t smem[];
+  __shared__ unsigned w32[16];
+  __shared__ unsigned long long w64[16];
+  __shared__ unsigned long long sRed[4];
+  __shared__ int sDiff[kQtPairDepth + 3], sLeaf[kQtPairDepth + 2];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const LevelDev L = P.lv[level];
+  QT_LDS uint32_t* cand = (QT_LDS uint32_t*)smem;
+  uint8_t* un = smem + 4 * CAP;
+  QT_LDS uint16_t* hist = (QT_LDS uint16_t*)un;
+  QT_LDS uint32_t* hist32 = (QT_LDS uint32_t*)un;
+  QT_LDS uint32_t* cellBase = (QT_LDS uint32_t*)un;
+  QT_LDS uint32_t* keysAll = (QT_LDS uint32_t*)un;
+  QT_LDS uint32_t* lastKey = (QT_LDS uint32_t*)(un + kQtFlatUnion - 4 * NT);
+  QT_LDS uint32_t* key30 = (QT_LDS uint32_t*)un;                                   // all-pairs arrays: keys, then ranks
+  QT_LDS unsigned long long* R64 = (QT_LDS unsigned long long*)(un + 4 * kQtSmall);
+  QT_LDS uint8_t* head = (QT_LDS uint8_t*)(un + kQtFlatUnion);
+  QT_LDS uint16_t* nodeStart = (QT_LDS uint16_t*)(un + kQtFlatUnion + CAP);
+  QtBlockCtx cx{w32, w64};
+  const int unit = f * kMaxLevels + level;
+  const int quota = L.quota;
+  QT_LDS uint32_t* nodeMaxLo = (QT_LDS uint32_t*)(un + kQtFlatUnion + CAP + ((2 * (quota + 2) + 3) & ~3));   // [quota+1] each
+  QT_LDS uint32_t* nodeMaxHi = nodeMaxLo + quota + 1;
+
+  QT_CLK(0);
+  // concatenate the level's cells in (row, col) order == keyPointsToDistr (orbExtractor.cpp:584-590)
+  const uint32_t* cnts = cellCount + (size_t)f * P.nCellsTotal + L.cellBegin;
+  unsigned nU = 0;
+  for (int c0 = 0; c0 < L.nCells; c0 += NT) {
+    const int c = c0 + tid;
+    const unsigned v = c < L.nCells ? cnts[c] : 0u;
+    unsigned tot;
+    const unsigned incl = cx.scan_incl_u32(v, &tot);
+    if (c < L.nCells) cellBase[c] = nU + incl - v;
+    nU += tot;
+  }
+  if (tid < kQtPairDepth + 3) sDiff[tid] = 0;
+  if (tid < kQtPairDepth + 2) sLeaf[tid] = 0;
+  if (tid < 4) sRed[tid] = 0;
+  cx.sync();
+  const int n = (int)nU;
+  if (tid == 0 && n > lvlMaxN[level]) atomicMax(&lvlMaxN[level], n);   // the host sizes the next launch from this
+  if (n > CAP) {                       // too many candidates for this launch's LDS: the pass kernel takes the unit
+    if (tid == 0) needPass[unit] = 1;
+    return;
+  }
+  if (n == 0 || quota <= 0) {
+    if (tid == 0) { needPass[unit] = 0; lvlCount[unit] = 0; }
+    return;
+  }
+  for (int c = tid; c < L.nCells; c += NT) {
+    const unsigned m = cnts[c], b = cellBase[c];
+    const uint32_t* src = cellCand + ((size_t)f * P.nCellsTotal + L.cellBegin + c) * P.cellCap;
+    unsigned i = 0;
+    for (; i + 4 <= m; i += 4) {       // independent loads in flight
+      const uint32_t v0 = src[i], v1 = src[i + 1], v2 = src[i + 2], v3 = src[i + 3];
+      cand[b + i] = v0; cand[b + i + 1] = v1; cand[b + i + 2] = v2; cand[b + i + 3] = v3;
+    }
+    for (; i < m; i++) cand[b + i] = src[i];
+  }
+  cx.sync();
+  QT_CLK(1);
+  const int rootX1 = L.w - 2 * kBorder, rootY1 = L.h - 2 * kBorder;
+  int Pn = 0, K = 0;
+  bool pairs = false;
+
+  {
+    // ---- histogram pyramid over 7 levels of path digits ------------------------------------------------------------------
+    constexpr int D = kQtFlatDepth;
+    uint32_t c[ITEMS], ky[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) {
+      const int i = tid * ITEMS + j;
+      c[j] = i < n ? cand[i] : 0u;
+      ky[j] = qt_path_key<kQtFlatDepth>(c[j], rootX1, rootY1);
+    }
+    for (int i = tid; i < (kQtFlatBins + 1) / 2; i += NT) hist32[i] = 0;   // cellBase (same bytes) was last read before the barrier above
+    cx.sync();
+    {
+      const int off = qt_flat_level_off(D);
+#pragma unroll
+      for (int j = 0; j < ITEMS; j++)
+        if (tid * ITEMS + j < n) {
+          const int idx = off + (int)ky[j];
+          __hip_atomic_fetch_add(hist32 + (idx >> 1), 1u << (16 * (idx & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    cx.sync();
+    QT_CLK(2);
+    // parents from children, level by level; a parent with >= 2 candidates makes its occupied children list nodes of the
+    // next pass and its single-candidate children leaves.  Packed 16-bit tallies: [nodes d=1..4][nodes 5..7][leaves 1..4][leaves 5..7]
+    unsigned long long tn0 = 0, tn1 = 0, tl0 = 0, tl1 = 0;
+#pragma unroll
+    for (int d = D - 1; d >= 0; d--) {
+      const int offC = qt_flat_level_off(d + 1), offP = qt_flat_level_off(d);
+      for (int b = tid; b < (1 << (2 * d)); b += NT) {
+        const unsigned c0 = hist[offC + 4 * b], c1 = hist[offC + 4 * b + 1], c2 = hist[offC + 4 * b + 2], c3 = hist[offC + 4 * b + 3];
+        const unsigned sum = c0 + c1 + c2 + c3;
+        hist[offP + b] = (uint16_t)sum;
+        if (sum >= 2) {
+          const unsigned long long nn = (c0 != 0) + (c1 != 0) + (c2 != 0) + (c3 != 0), ll = (c0 == 1) + (c1 == 1) + (c2 == 1) + (c3 == 1);
+          const int dd = d + 1;   // depth of the children
+          if (dd <= 4) { tn0 += nn << (16 * (dd - 1)); tl0 += ll << (16 * (dd - 1)); }
+          else { tn1 += nn << (16 * (dd - 5)); tl1 += ll << (16 * (dd - 5)); }
+        }
+      }
+      cx.sync();
+    }
+    QT_CLK(3);
+    tn0 = wave_sum_u64(tn0); tn1 = wave_sum_u64(tn1); tl0 = wave_sum_u64(tl0); tl1 = wave_sum_u64(tl1);
+    if ((tid & 63) == 0) {
+      __hip_atomic_fetch_add(&sRed[0], tn0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&sRed[1], tn1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&sRed[2], tl0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&sRed[3], tl1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    cx.sync();
+    {
+      int nodes[D + 1], leaves[D + 1];
+      nodes[0] = 1; leaves[0] = n == 1;
+      const unsigned long long a0 = sRed[0], a1 = sRed[1], b0 = sRed[2], b1 = sRed[3];
+#pragma unroll
+      for (int d = 1; d <= D; d++) {
+        nodes[d] = (int)(((d <= 4 ? a0 : a1) >> (16 * ((d - 1) & 3))) & 0xFFFF);
+        leaves[d] = (int)(((d <= 4 ? b0 : b1) >> (16 * ((d - 1) & 3))) & 0xFFFF);
+      }
+      Pn = qt_flat_passes(nodes, leaves, quota, &K, D);
+    }
+    QT_CLK(4);
+    if (Pn < 0) {
+      if (n > kQtSmall) {                // deep tree with many candidates: pass kernel
+        if (tid == 0) needPass[unit] = 1;
+        return;
+      }
+      pairs = true;                      // deep tree, few candidates (sparse scene): all-pairs form below, any depth up to 15
+    } else {
+      const int endBit = 2 * Pn + 4;
+      // depth at which each candidate's node stops splitting: the first depth where it is alone (count 1 stays 1 below), else P
+      int dd[ITEMS];
+#pragma unroll
+      for (int j = 0; j < ITEMS; j++) dd[j] = Pn;
+      for (int d = Pn - 1; d >= 0; d--) {
+        const int off = qt_flat_level_off(d), sh = 2 * (D - d);
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++)
+          if (hist[off + (int)(ky[j] >> sh)] == 1) dd[j] = d;
+      }
+      uint32_t R[ITEMS];
+#pragma unroll
+      for (int j = 0; j < ITEMS; j++) {
+        const int d = dd[j];
+        R[j] = ((uint32_t)(Pn - d) << (2 * Pn)) | ((ky[j] >> (2 * (D - d))) ^ qt_flat_mask(d));
+        if (tid * ITEMS + j >= n) R[j] = (1u << endBit) - 1u;   // padding sorts behind every real entry (group 15)
+      }
+      cx.sync();   // the pyramid is dead: its bytes become the sort's exchange buffer
+      QT_CLK(5);
+      Sort().sort(R, c, *reinterpret_cast<typename Sort::storage_type*>(un), 0, endBit);
+      QT_CLK(6);
+      lastKey[tid] = R[ITEMS - 1];
+      cx.sync();
+      uint32_t prev = tid ? lastKey[tid - 1] : 0xFFFFFFFFu;
+#pragma unroll
+      for (int j = 0; j < ITEMS; j++) {
+        const int i = tid * ITEMS + j;
+        if (i < n) { cand[i] = c[j]; head[i] = R[j] != prev; }
+        prev = R[j];
+      }
+    }
+  }
+  if (pairs) {
+    // ---- few candidates, deep tree: pairwise common prefixes of 30-bit keys ------------------------------------------------
+    constexpr int D = kQtPairDepth, PER = kQtSmall / NT;
+    static_assert(PER == 2, "two candidates per thread");
+    const int i0 = tid, i1 = tid + NT, n4 = (n + 3) & ~3;
+    const uint32_t c0 = i0 < n ? cand[i0] : 0u, c1 = i1 < n ? cand[i1] : 0u;
+    const uint32_t k0 = qt_path_key<kQtPairDepth>(c0, rootX1, rootY1), k1 = qt_path_key<kQtPairDepth>(c1, rootX1, rootY1);
+    cx.sync();   // pyramid reads are done
+    if (i0 < n4) key30[i0] = i0 < n ? k0 : 0xFFFFFFFFu;   // padding: clz(x) = 0 -> depth 0, neutral
+    if (i1 < n4) key30[i1] = i1 < n ? k1 : 0xFFFFFFFFu;
+    cx.sync();
+    int s0 = 0, e0 = 0, s1 = 0, e1 = 0;
+    for (int q = 0; q < n4; q += 4) {
+      const uint4 kq = *reinterpret_cast<const QT_LDS uint4*>(key30 + q);
+      const uint32_t kk[4] = {kq.x, kq.y, kq.z, kq.w};
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const uint32_t x0 = k0 ^ kk[t], x1 = k1 ^ kk[t];
+        const int d0 = q + t == i0 ? 0 : (x0 ? ((__clz(x0) - 2) >> 1) + 1 : D + 1);
+        const int d1 = q + t == i1 ? 0 : (x1 ? ((__clz(x1) - 2) >> 1) + 1 : D + 1);
+        s0 = max(s0, d0); s1 = max(s1, d1);
+        if (q + t < i0) e0 = max(e0, d0);
+        if (q + t < i1) e1 = max(e1, d1);
+      }
+    }
+    if (i0 < n) {
+      if (e0 <= D) { atomicAdd(&sDiff[e0], 1); atomicAdd(&sDiff[min(s0, D) + 1], -1); }
+      if (s0 <= D) atomicAdd(&sLeaf[s0], 1);
+    }
+    if (i1 < n) {
+      if (e1 <= D) { atomicAdd(&sDiff[e1], 1); atomicAdd(&sDiff[min(s1, D) + 1], -1); }
+      if (s1 <= D) atomicAdd(&sLeaf[s1], 1);
+    }
+    cx.sync();
+    {
+      int nodes[D + 1], leaves[D + 1], run = 0;
+#pragma unroll
+      for (int d = 0; d <= D; d++) { run += sDiff[d]; nodes[d] = run; leaves[d] = sLeaf[d]; }
+      Pn = qt_flat_passes(nodes, leaves, quota, &K, D);
+    }
+    if (Pn < 0) {                        // cannot happen for 12-bit coordinates; the pass kernel would cope
+      if (tid == 0) needPass[unit] = 1;
+      return;
+    }
+    const int dA = min(Pn, s0), dB = min(Pn, s1);
+    const unsigned long long R0 = ((unsigned long long)(Pn - dA) << (2 * Pn)) | (unsigned long long)((k0 >> (2 * (D - dA))) ^ qt_flat_mask(dA));
+    const unsigned long long R1 = ((unsigned long long)(Pn - dB) << (2 * Pn)) | (unsigned long long)((k1 >> (2 * (D - dB))) ^ qt_flat_mask(dB));
+    if (i0 < n4) R64[i0] = i0 < n ? R0 : ~0ull;
+    if (i1 < n4) R64[i1] = i1 < n ? R1 : ~0ull;
+    cx.sync();
+    int r0 = 0, r1 = 0;
+    bool f0 = true, f1 = true;
+    for (int q = 0; q < n4; q += 2) {
+      const ulonglong2 o = *reinterpret_cast<const QT_LDS ulonglong2*>(R64 + q);
+      const unsigned long long oo[2] = {o.x, o.y};
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const bool eq0 = oo[t] == R0 && q + t < i0, eq1 = oo[t] == R1 && q + t < i1;
+        r0 += (oo[t] < R0) || eq0; r1 += (oo[t] < R1) || eq1;
+        f0 = f0 && !eq0; f1 = f1 && !eq1;
+      }
+    }
+    cx.sync();   // every key/cand read is done: the sorted order can overwrite cand[]
+    if (i0 < n) { cand[r0] = c0; head[r0] = f0; }
+    if (i1 < n) { cand[r1] = c1; head[r1] = f1; }
+  }
+  cx.sync();
+  QT_CLK(7);
+
+  // ---- common tail: node boundaries, then best keypoint per node in list order, truncated to the quota (:534-543) ---------
+  const int nOut = K < quota ? K : quota;
+  const int per = (n + NT - 1) / NT;
+  int firstNode;
+  {
+    int mine = 0;
+    for (int j = 0; j < per; j++) {
+      const int p = tid * per + j;
+      if (p < n) mine += head[p];
+    }
+    unsigned total;
+    const unsigned incl = cx.scan_incl_u32((unsigned)mine, &total);
+    firstNode = (int)incl - mine;   // nodes started before this thread's range
+    int k = firstNode;
+    for (int j = 0; j < per; j++) {
+      const int p = tid * per + j;
+      if (p < n && head[p]) {
+        if (k <= nOut) nodeStart[k] = (uint16_t)p;
+        k++;
+      }
+    }
+    if (tid == 0 && K <= nOut) nodeStart[K] = (uint16_t)n;
+    for (int k2 = tid; k2 < nOut; k2 += NT) { nodeMaxLo[k2] = 0; nodeMaxHi[k2] = 0; }
+    if ((int)total != K) {           // cannot happen: the pyramid/pair count and the sorted runs describe the same list
+      if (tid == 0) needPass[unit] = 1;
+      return;
+    }
+  }
+  cx.sync();   // also retires the union's previous tenant (sort hand-off / R64) before keysAll is written
+  {
+    // Per node: the maximum response with the smallest and with the largest member index.  When both name the same member the
+    // maximum is unique and std::sort's front() is that member whatever the sort did internally; only tied nodes with more
+    // than 16 members need the introsort replay (<= 16 members: insertion sort, first maximum).
+    int k = firstNode - 1;           // node of the position just before this thread's range
+    for (int j = 0; j < per; j++) {
+      const int p = tid * per + j;
+      if (p < n) {
+        k += head[p];
+        if (k < nOut) {
+          const uint32_t mi = (uint32_t)(p - nodeStart[k]), rs = (uint32_t)qt_r(cand[p]) << 16;
+          keysAll[p] = rs | mi;
+          __hip_atomic_fetch_max(nodeMaxLo + k, rs | (0xFFFFu - mi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_max(nodeMaxHi + k, rs | mi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+  }
+  cx.sync();
+  QT_CLK(8);
+  uint32_t* outKp = lvlKp + (size_t)f * P.sumQuota + L.kpOff;
+  for (int k = tid; k < nOut; k += NT) {
+    const int b = nodeStart[k], m = nodeStart[k + 1] - b;
+    const int lo = (int)(0xFFFFu - (nodeMaxLo[k] & 0xFFFFu)), hi = (int)(nodeMaxHi[k] & 0xFFFFu);
+    int best = lo;
+    if (m > 16 && lo != hi) best = qt_sort_front(keysAll + b, m);
+    outKp[k] = cand[b + best];
+  }
+  QT_CLK(9);
+  if (tid == 0) { needPass[unit] = 0; lvlCount[unit] = nOut; }
 }
 
 // ------------------------------------------------------------------------------------------------

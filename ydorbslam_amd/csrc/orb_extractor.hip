@@ -3,6 +3,7 @@
 // constructor tables on the host, everything per-frame on the GPU.  There is no CPU fallback: without
 // a usable HIP device every entry point returns YDORB_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cmath>
@@ -31,7 +32,7 @@ struct HostPlan {
   std::vector<CellDev> cells;
   size_t pyrFrameStride = 0, blurFrameStride = 0, qtFrameStride = 0;
   // quad-tree launch geometry per level: node table for 4*quota nodes, LDS-resident candidates up to candCap (HBM beyond)
-  struct QtLevel { int nodeCap, candCap; size_t lds; } qt[kMaxLevels]{};
+  struct QtLevel { int nodeCap, candCap; size_t lds; int flatItems; size_t flatLds; } qt[kMaxLevels]{};
   size_t qtLdsMax = 0;
   std::vector<int> tabInt;      // xofs|yofs per level
   std::vector<short> tabShort;  // alpha|beta per level
@@ -59,7 +60,9 @@ struct ydorb_extractor {
   uint8_t *d_img = nullptr, *d_pyr = nullptr, *d_blur = nullptr;
   uint32_t *d_cellCount = nullptr, *d_cellCand = nullptr, *d_qtCand = nullptr, *d_qtKeys = nullptr, *d_lvlKp = nullptr;
   uint16_t* d_qtNode = nullptr;
+  uint8_t* d_needPass = nullptr;   // [frame][level]: 1 = the flat quad-tree kernel left the unit to the pass kernel
   int *d_lvlCount = nullptr, *d_status = nullptr, *d_nOut = nullptr;
+  int *d_lvlMaxN = nullptr, *h_lvlMaxN = nullptr;   // largest candidate count seen per level (device max, copied back after every call)
   float* d_lvlAngle = nullptr;
   CellDev* d_cells = nullptr;
   int* d_tabInt = nullptr;
@@ -76,6 +79,7 @@ struct ydorb_extractor {
   int lastFrames = 0;
   // profiling
   bool profiling = false;
+  bool forcePassQuadtree = false;  // YDORB_QT_PASS=1 at create: run every unit through the pass kernel (tests compare both)
   hipEvent_t ev[ST_COUNT + 1]{};
   double stageMs[ST_COUNT]{};
   int stageCalls = 0;
@@ -95,14 +99,23 @@ namespace {
 void freeBuffers(ydorb_extractor* e) {
   auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
   F(e->d_img); F(e->d_pyr); F(e->d_blur); F(e->d_cellCount); F(e->d_cellCand); F(e->d_qtCand); F(e->d_qtKeys);
-  F(e->d_lvlKp); F(e->d_qtNode); F(e->d_lvlCount); F(e->d_status); F(e->d_nOut); F(e->d_lvlAngle); F(e->d_cells);
+  F(e->d_lvlKp); F(e->d_qtNode); F(e->d_needPass); F(e->d_lvlCount); F(e->d_lvlMaxN); F(e->d_status); F(e->d_nOut); F(e->d_lvlAngle); F(e->d_cells);
   F(e->d_tabInt); F(e->d_tabShort); F(e->d_kps); F(e->d_desc);
   auto H = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
-  H(e->h_img); H(e->h_kps); H(e->h_desc); H(e->h_nOut); H(e->h_status);
+  H(e->h_img); H(e->h_kps); H(e->h_desc); H(e->h_nOut); H(e->h_status); H(e->h_lvlMaxN);
   e->planValid = false;
 }
 
 // Level sizes, cell grid, scratch layout, resize tables for a w x h input.
+
+// smallest supported items-per-thread of k_quadtree_flat whose 512*items slots hold `want` candidates (16 = the largest)
+static int flatItemsFor(long want) {
+  const int steps[5] = {2, 4, 8, 12, 16};
+  for (int i = 0; i < 5; i++)
+    if ((long)kQtFlatThreads * steps[i] >= want) return steps[i];
+  return 16;
+}
+
 int buildPlan(ydorb_extractor* e, int w, int h, HostPlan& P) {
   P = HostPlan();
   P.w = w; P.h = h;
@@ -219,6 +232,11 @@ int buildPlan(ydorb_extractor* e, int w, int h, HostPlan& P) {
       return YDORB_ERR_UNSUPPORTED;
     }
     P.qtLdsMax = std::max(P.qtLdsMax, Q.lds);
+    // flat kernel: 512*items candidate slots.  First guess from the densities above (L0 1/45 .. L7 1/20 of the band); enqueue()
+    // re-sizes it from the candidate counts the device actually saw.  A unit with more candidates goes to the pass kernel.
+    Q.flatItems = flatItemsFor((long)((double)band / (45.0 - 3.5 * l)) + 64);
+    Q.flatLds = qt_flat_lds_bytes(Q.flatItems, L.quota);
+    if (Q.flatLds > 150 * 1024) { Q.flatItems = 0; Q.flatLds = 0; }   // huge quotas: pass kernel only
   }
   return YDORB_OK;
 }
@@ -242,10 +260,15 @@ int ensurePlan(ydorb_extractor* e, int w, int h, int nFrames) {
   HIPCHK(hipMalloc(&e->d_cellCand, sizeof(uint32_t) * (size_t)D.nCellsTotal * D.cellCap * B));
   HIPCHK(hipMalloc(&e->d_qtCand, sizeof(uint32_t) * 2 * P.qtFrameStride * B));
   HIPCHK(hipMalloc(&e->d_qtNode, sizeof(uint16_t) * 2 * P.qtFrameStride * B));
+  HIPCHK(hipMalloc(&e->d_needPass, (size_t)kMaxLevels * B));
 
   HIPCHK(hipMalloc(&e->d_lvlKp, sizeof(uint32_t) * (size_t)D.sumQuota * B));
   HIPCHK(hipMalloc(&e->d_lvlAngle, sizeof(float) * (size_t)D.sumQuota * B));
   HIPCHK(hipMalloc(&e->d_lvlCount, sizeof(int) * kMaxLevels * B));
+  HIPCHK(hipMalloc(&e->d_lvlMaxN, sizeof(int) * kMaxLevels));
+  HIPCHK(hipMemsetAsync(e->d_lvlMaxN, 0, sizeof(int) * kMaxLevels, e->stream));
+  HIPCHK(hipHostMalloc(&e->h_lvlMaxN, sizeof(int) * kMaxLevels));
+  memset(e->h_lvlMaxN, 0, sizeof(int) * kMaxLevels);
   HIPCHK(hipMalloc(&e->d_status, sizeof(int)));
   HIPCHK(hipMalloc(&e->d_nOut, sizeof(int) * B));
   HIPCHK(hipMalloc(&e->d_cells, sizeof(CellDev) * std::max<size_t>(P.cells.size(), 1)));
@@ -265,13 +288,42 @@ int ensurePlan(ydorb_extractor* e, int w, int h, int nFrames) {
   HIPCHK(hipStreamSynchronize(e->stream));
   if (P.qtLdsMax > 48 * 1024)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.qtLdsMax));
+  {
+    size_t ldsFlat = 0;   // any level may later be re-sized up to 16 items (retuneQuadtree)
+    for (int l = 0; l < D.nLevels; l++)
+      if (P.qt[l].flatItems) ldsFlat = std::max(ldsFlat, std::min<size_t>(qt_flat_lds_bytes(16, D.lv[l].quota), 150 * 1024));
+    if (ldsFlat > 48 * 1024) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_flat<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFlat));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_flat<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFlat));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_flat<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFlat));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_flat<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFlat));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_flat<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFlat));
+    }
+  }
   e->planValid = true;
   return YDORB_OK;
+}
+
+// Adapt the flat quad-tree kernel's LDS footprint to the scene: the device keeps the largest candidate count per level, the
+// copy-back at the end of every call brings it here (a call behind, which is fine — both kernels give the same keypoints).
+static void retuneQuadtree(ydorb_extractor* e) {
+  HostPlan& P = e->plan;
+  for (int l = 0; l < P.dev.nLevels; l++) {
+    HostPlan::QtLevel& Q = P.qt[l];
+    const int seen = e->h_lvlMaxN[l];
+    if (!Q.flatItems || seen <= 0) continue;
+    const int items = flatItemsFor((long)seen + seen / 8 + 32);
+    if (items != Q.flatItems && qt_flat_lds_bytes(items, P.dev.lv[l].quota) <= 150 * 1024) {
+      Q.flatItems = items;
+      Q.flatLds = qt_flat_lds_bytes(items, P.dev.lv[l].quota);
+    }
+  }
 }
 
 // Enqueue the whole front-end for nFrames device-resident images on `s`.
 int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameStride, int nFrames, YdKeyPointDev* d_kps,
             uint8_t* d_desc, int cap, int* d_nOut, hipStream_t s) {
+  retuneQuadtree(e);
   const HostPlan& P = e->plan;
   const PlanDev& D = P.dev;
   const bool prof = e->profiling && s == e->stream;
@@ -293,19 +345,37 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
     hipLaunchKernelGGL(k_fast_cells, dim3((D.nCellsTotal + 7) / 8 * 8, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, D, e->d_cells,
                        std::min(std::max(e->cfg.ini_fast_thr, 0), 255), e->d_cellCount, e->d_cellCand);
   if (prof) HIPCHK(hipEventRecord(e->ev[2], s));
-  // fork: one quad-tree launch per level on the side streams; the blur (needs only the pyramid) runs on `s` meanwhile
+  // fork: the blur (needs only the pyramid) goes first on `s` so that it heads its hardware queue; the quad-tree launches, one
+  // per level on the side streams, wait for the FAST results only and overlap it
   HIPCHK(hipEventRecord(e->evFork, s));
-  for (int l = 0; l < D.nLevels; l++) {
-    HIPCHK(hipStreamWaitEvent(e->qtStream[l], e->evFork, 0));
-    hipLaunchKernelGGL(k_quadtree, dim3(1, nFrames), dim3(kQtThreads), P.qt[l].lds, e->qtStream[l], D, e->d_cellCount, e->d_cellCand,
-                       e->d_qtCand, e->d_qtNode, P.qtFrameStride, P.qt[l].nodeCap, P.qt[l].candCap, l, e->d_lvlKp, e->d_lvlCount, e->d_status);
-    HIPCHK(hipEventRecord(e->evJoin[l], e->qtStream[l]));
-  }
   {
     int maxTiles = 0;
     for (int l = 0; l < D.nLevels; l++) maxTiles = std::max(maxTiles, ((D.lv[l].w + 63) / 64) * ((D.lv[l].h + 15) / 16));
     hipLaunchKernelGGL(k_blur, dim3((maxTiles + 7) / 8 * 8, D.nLevels, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
                        P.blurFrameStride, D);
+  }
+  for (int l = 0; l < D.nLevels; l++) {
+    HIPCHK(hipStreamWaitEvent(e->qtStream[l], e->evFork, 0));
+    const HostPlan::QtLevel& Q = P.qt[l];
+    const uint8_t* needPass = nullptr;
+    if (Q.flatItems && !e->forcePassQuadtree) {
+      needPass = e->d_needPass;
+#define YD_QT_FLAT(IT)                                                                                                              \
+  hipLaunchKernelGGL(k_quadtree_flat<IT>, dim3(nFrames), dim3(kQtFlatThreads), Q.flatLds, e->qtStream[l], D, e->d_cellCount,        \
+                     e->d_cellCand, l, e->d_lvlKp, e->d_lvlCount, e->d_needPass, e->d_lvlMaxN)
+      switch (Q.flatItems) {
+        case 2: YD_QT_FLAT(2); break;
+        case 4: YD_QT_FLAT(4); break;
+        case 8: YD_QT_FLAT(8); break;
+        case 12: YD_QT_FLAT(12); break;
+        default: YD_QT_FLAT(16); break;
+      }
+#undef YD_QT_FLAT
+    }
+    // pass algorithm: every unit when the flat kernel is off, otherwise only the units it flagged (the others exit at once)
+    hipLaunchKernelGGL(k_quadtree, dim3(1, nFrames), dim3(kQtThreads), Q.lds, e->qtStream[l], D, e->d_cellCount, e->d_cellCand,
+                       e->d_qtCand, e->d_qtNode, P.qtFrameStride, Q.nodeCap, Q.candCap, l, e->d_lvlKp, e->d_lvlCount, e->d_status, needPass);
+    HIPCHK(hipEventRecord(e->evJoin[l], e->qtStream[l]));
   }
   if (prof) HIPCHK(hipEventRecord(e->ev[3], s));   // end of the blur; the quad-tree stage is the interval up to the join below
   for (int l = 0; l < D.nLevels; l++) HIPCHK(hipStreamWaitEvent(s, e->evJoin[l], 0));
@@ -313,6 +383,7 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   hipLaunchKernelGGL(k_orient_describe, dim3(((D.sumQuota + 3) / 4 + 7) / 8 * 8, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
                      P.blurFrameStride, D, e->d_lvlKp, e->d_lvlCount, d_kps, d_desc, cap, d_nOut, e->d_lvlAngle);
   if (prof) HIPCHK(hipEventRecord(e->ev[5], s));
+  HIPCHK(hipMemcpyAsync(e->h_lvlMaxN, e->d_lvlMaxN, sizeof(int) * kMaxLevels, hipMemcpyDeviceToHost, s));
   HIPCHK(hipGetLastError());
   e->lastFrames = nFrames;
   return YDORB_OK;
@@ -348,6 +419,7 @@ int ydorb_extractor_create(const YdExtractorConfig* cfg, ydorb_extractor_t** out
   if (rc) return rc;
   ydorb_extractor* e = new ydorb_extractor();
   e->cfg = *cfg;
+  if (const char* v = getenv("YDORB_QT_PASS")) e->forcePassQuadtree = v[0] == '1';
   e->cfg.min_fast_thr = cfg->ini_fast_thr;  // reference quirk, orbExtractor.cpp:318
   // constructor tables, orbExtractor.cpp:319-353
   const int L = cfg->n_levels;
@@ -566,6 +638,24 @@ int ydorb_extractor_debug_read(ydorb_extractor_t* e, int32_t what, int32_t frame
     *written = (size_t)n * sizeof(YdKeyPoint);
     return YDORB_OK;
   }
+  if (what == 3) {   // which quad-tree kernel produced the unit: 0 = flat, 1 = pass
+    if (dst_bytes < 1) { set_error("need 1 byte"); return YDORB_ERR_CAPACITY; }
+    uint8_t v = 1;
+    if (!e->forcePassQuadtree && P.qt[level].flatItems)
+      HIPCHK(hipMemcpy(&v, e->d_needPass + (size_t)frame * kMaxLevels + level, 1, hipMemcpyDeviceToHost));
+    *(uint8_t*)dst = v;
+    *written = 1;
+    return YDORB_OK;
+  }
+#ifdef QT_FLAT_TIMING
+  if (what == 4) {
+    long long clk[kMaxLevels][16];
+    HIPCHK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_qtClk), sizeof(clk)));
+    memcpy(dst, clk[level], sizeof(clk[level]));
+    *written = sizeof(clk[level]);
+    return YDORB_OK;
+  }
+#endif
   set_error("unknown debug stage %d", what);
   return YDORB_ERR_INVALID_ARG;
 }

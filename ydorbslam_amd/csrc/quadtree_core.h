@@ -125,10 +125,11 @@ template <class P> YD_HD inline int qt_sort_front(P a, int m) {
         else qt_swap(a, 0, y);
       }
       int f = 1, l = hi;  // __unguarded_partition(first+1, last, pivot=first)
+      const uint32_t piv = a[0];   // slot 0 is never touched by the swaps below (f >= 1)
       for (;;) {
-        while (qt_gt(a[f], a[0])) ++f;
+        while (qt_gt(a[f], piv)) ++f;
         --l;
-        while (qt_gt(a[0], a[l])) --l;
+        while (qt_gt(piv, a[l])) --l;
         if (!(f < l)) break;
         qt_swap(a, f, l);
         ++f;

@@ -91,6 +91,10 @@ class OrbExtractor:
             out = np.zeros((h, w), np.uint8)
             check(self._L.ydorb_extractor_debug_read(self._h, 0, frame, level, _p(out), out.size, C.byref(written)))
             return out
+        if what == 3:
+            out = np.zeros(1, np.uint8)
+            check(self._L.ydorb_extractor_debug_read(self._h, 3, frame, level, _p(out), 1, C.byref(written)))
+            return int(out[0])
         out = np.zeros(1 << 17, KP_DTYPE)
         check(self._L.ydorb_extractor_debug_read(self._h, what, frame, level, _p(out), out.nbytes, C.byref(written)))
         return out[: written.value // KP_DTYPE.itemsize].copy()
