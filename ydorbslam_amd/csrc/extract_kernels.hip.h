@@ -63,34 +63,40 @@ typedef unsigned long long __attribute__((aligned(1))) u64_unaligned;
 
 // Workgroup = 64 x 4 threads; a thread writes one dword (4 px) in each of kPyrRows consecutive rows, so a workgroup covers
 // 256 B x 16 rows and the per-column tables are loaded once per thread (one-row workgroups were dispatch-bound).
-constexpr int kPyrRows = 4;
+#ifndef PYR_ROWS
+#define PYR_ROWS 4
+#endif
+constexpr int kPyrRows = PYR_ROWS;
+// Both kernels issue every load of a thread's kPyrRows rows before the first use (rows past the bottom are clamped and their
+// store masked), so a thread keeps 2*kPyrRows independent loads in flight instead of one row at a time.
 __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ img, int stride, size_t frameStride,
                                                     uint8_t* __restrict__ pyr, size_t pyrFrameStride, LevelDev L) {
   const int wx = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int yb = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kPyrRows;
+  const int yb = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * kPyrRows;
   if (wx * 4 >= L.pitch) return;
   const uint8_t* src = img + (size_t)blockIdx.z * frameStride;
   uint8_t* dst = pyr + (size_t)blockIdx.z * pyrFrameStride + L.padOff + wx * 4;
-  const int x0 = wx * 4 - kPad;
+  const int x0 = wx * 4 - kPad, hp = L.h + 2 * kPad;
   const bool interior = x0 >= 0 && x0 + 3 < L.w;
   int rx[4];
 #pragma unroll
   for (int b = 0; b < 4; b++) rx[b] = x0 + b < L.w + kPad ? reflect101(x0 + b, L.w) : -1;
+  uint32_t v[kPyrRows];
 #pragma unroll
   for (int r = 0; r < kPyrRows; r++) {
-    const int y = yb + r;
-    if (y >= L.h + 2 * kPad) break;
-    const uint8_t* row = src + (size_t)reflect101(y - kPad, L.h) * stride;
-    uint32_t v = 0;
+    const uint8_t* row = src + (size_t)reflect101(min(yb + r, hp - 1) - kPad, L.h) * stride;
+    v[r] = 0;
     if (interior) {
-      v = *reinterpret_cast<const u32_unaligned*>(row + x0);
+      v[r] = *reinterpret_cast<const u32_unaligned*>(row + x0);
     } else {
 #pragma unroll
       for (int b = 0; b < 4; b++)
-        if (rx[b] >= 0) v |= (uint32_t)row[rx[b]] << (8 * b);
+        if (rx[b] >= 0) v[r] |= (uint32_t)row[rx[b]] << (8 * b);
     }
-    *reinterpret_cast<uint32_t*>(dst + (size_t)y * L.pitch) = v;
   }
+#pragma unroll
+  for (int r = 0; r < kPyrRows; r++)
+    if (yb + r < hp) *reinterpret_cast<uint32_t*>(dst + (size_t)(yb + r) * L.pitch) = v[r];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -98,18 +104,19 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ 
 // Border pixels are recomputed from the reflected interior coordinate instead of re-read, so the level
 // is written exactly once.  Coefficient tables (11-bit fixed point) are built on the host.
 // Interior fast path: the 4 outputs of a thread read source columns sx[0] .. sx[3]+1, at most 8 consecutive bytes for
-// scale factors <= 2, fetched as one unaligned 8-byte load per source row.
+// scale factors <= 2, fetched as one unaligned 8-byte load per source row.  The row tables are indexed by a wave-uniform
+// row number (scalar loads).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, size_t pyrFrameStride, LevelDev Lp, LevelDev L,
                                                     const int* __restrict__ xofs, const short* __restrict__ alpha,
                                                     const int* __restrict__ yofs, const short* __restrict__ beta) {
   const int wx = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int yb = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kPyrRows;
+  const int yb = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * kPyrRows;
   if (wx * 4 >= L.pitch) return;
   uint8_t* frame = pyr + (size_t)blockIdx.z * pyrFrameStride;
   const uint8_t* S = frame + Lp.padOff + (size_t)kPad * Lp.pitch + kPad;  // ROI origin of the source level
   uint8_t* dst = frame + L.padOff + wx * 4;
-  const int x0 = wx * 4 - kPad;
+  const int x0 = wx * 4 - kPad, hp = L.h + 2 * kPad;
   int sx[4], sx1[4], a0[4], a1[4];
 #pragma unroll
   for (int b = 0; b < 4; b++) {
@@ -121,103 +128,91 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, s
     }
   }
   const bool fast = x0 >= 0 && x0 + 3 < L.w && sx[3] - sx[0] <= 6 && sx[0] + 7 < Lp.w + kPad;
+  const uint8_t *r0p[kPyrRows], *r1p[kPyrRows];
+  int b0[kPyrRows], b1[kPyrRows];
 #pragma unroll
   for (int r = 0; r < kPyrRows; r++) {
-    const int y = yb + r;
-    if (y >= L.h + 2 * kPad) break;
-    const int dy = reflect101(y - kPad, L.h);
+    const int dy = reflect101(min(yb + r, hp - 1) - kPad, L.h);
     const int sy = yofs[dy];
-    const int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
-    const uint8_t* r0p = S + (size_t)min(max(sy, 0), Lp.h - 1) * Lp.pitch;
-    const uint8_t* r1p = S + (size_t)min(max(sy + 1, 0), Lp.h - 1) * Lp.pitch;
-    uint32_t v = 0;
-    if (fast) {
-      const unsigned long long w0 = *reinterpret_cast<const u64_unaligned*>(r0p + sx[0]);
-      const unsigned long long w1 = *reinterpret_cast<const u64_unaligned*>(r1p + sx[0]);
+    b0[r] = beta[2 * dy]; b1[r] = beta[2 * dy + 1];
+    r0p[r] = S + (size_t)min(max(sy, 0), Lp.h - 1) * Lp.pitch;
+    r1p[r] = S + (size_t)min(max(sy + 1, 0), Lp.h - 1) * Lp.pitch;
+  }
+  uint32_t v[kPyrRows];
+  if (fast) {
+    unsigned long long w0[kPyrRows], w1[kPyrRows];
+#pragma unroll
+    for (int r = 0; r < kPyrRows; r++) {
+      w0[r] = *reinterpret_cast<const u64_unaligned*>(r0p[r] + sx[0]);
+      w1[r] = *reinterpret_cast<const u64_unaligned*>(r1p[r] + sx[0]);
+    }
+#pragma unroll
+    for (int r = 0; r < kPyrRows; r++) {
+      v[r] = 0;
 #pragma unroll
       for (int b = 0; b < 4; b++) {
         const int sh = 8 * (sx[b] - sx[0]);
-        const int h0 = (int)((w0 >> sh) & 255) * a0[b] + (int)((w0 >> (sh + 8)) & 255) * a1[b];
-        const int h1 = (int)((w1 >> sh) & 255) * a0[b] + (int)((w1 >> (sh + 8)) & 255) * a1[b];
-        const int o = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-        v |= (uint32_t)(o & 0xFF) << (8 * b);
+        const int h0 = (int)((w0[r] >> sh) & 255) * a0[b] + (int)((w0[r] >> (sh + 8)) & 255) * a1[b];
+        const int h1 = (int)((w1[r] >> sh) & 255) * a0[b] + (int)((w1[r] >> (sh + 8)) & 255) * a1[b];
+        const int o = (((b0[r] * (h0 >> 4)) >> 16) + ((b1[r] * (h1 >> 4)) >> 16) + 2) >> 2;
+        v[r] |= (uint32_t)(o & 0xFF) << (8 * b);
       }
-    } else {
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < kPyrRows; r++) {
+      v[r] = 0;
 #pragma unroll
       for (int b = 0; b < 4; b++)
         if (sx[b] >= 0) {
-          const int h0 = r0p[sx[b]] * a0[b] + r0p[sx1[b]] * a1[b];
-          const int h1 = r1p[sx[b]] * a0[b] + r1p[sx1[b]] * a1[b];
-          const int o = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-          v |= (uint32_t)(o & 0xFF) << (8 * b);
+          const int h0 = r0p[r][sx[b]] * a0[b] + r0p[r][sx1[b]] * a1[b];
+          const int h1 = r1p[r][sx[b]] * a0[b] + r1p[r][sx1[b]] * a1[b];
+          const int o = (((b0[r] * (h0 >> 4)) >> 16) + ((b1[r] * (h1 >> 4)) >> 16) + 2) >> 2;
+          v[r] |= (uint32_t)(o & 0xFF) << (8 * b);
         }
     }
-    *reinterpret_cast<uint32_t*>(dst + (size_t)y * L.pitch) = v;
   }
+#pragma unroll
+  for (int r = 0; r < kPyrRows; r++)
+    if (yb + r < hp) *reinterpret_cast<uint32_t*>(dst + (size_t)(yb + r) * L.pitch) = v[r];
 }
 
 // ------------------------------------------------------------------------------------------------
-// FAST-9/16 (cv::FAST, call site orbExtractor.cpp:581) split into the three tests a pixel has to pass, so that each
-// later (more expensive) test runs only on a dense list of survivors:
-//   compass test : a 9-arc of the 16-ring always contains >= 2 of the 4 compass pixels, so < 2 brighter and < 2 darker
-//                  compass pixels means "not a corner" (8 compares);
-//   segment test : 16-bit darker / brighter ring masks, 9 contiguous bits via shift-and (strict compares, like OpenCV);
-//   corner score : max over the 16 arcs of min(v - p) resp. min(p - v), minus 1  ==  OpenCV's cornerScore<16> recurrence
-//                  for every pixel that passes the segment test.
+// FAST-9/16 (cv::FAST, call site orbExtractor.cpp:581).  The kernel is VALU-issue bound (rocprofv3: SQ_ACTIVE_INST_VALU x 4
+// = SIMD cycles of the launch), so the three tests are arranged for few vector instructions and no workgroup traffic:
+//   compass test : a 9-arc of the 16-ring always contains >= 2 of the 4 compass pixels, so "second largest compass pixel
+//                  > v + t or second smallest < v - t" is necessary (min/max network, 2 compares);
+//   arc test + score : d = v - ring as 8 packed i16 pairs (d[j], d[j+8]); max over the 16 arcs of min(d) and of min(-d) by a
+//                  doubling network of v_pk_min/max_i16 (rotations by 8 are the half swap, free via op_sel).  The larger of
+//                  the two IS OpenCV's cornerScore<16> + 1, and "> t" IS the strict 9-contiguous segment test, so one
+//                  network answers both;
+//   NMS          : strictly greater than the 8 neighbours in the cell's score map.
+// Each of the 4 waves owns a contiguous block of band rows and keeps its survivors in its own LDS segment, compacted in place
+// with ballots: inside a wave LDS accesses are ordered, so there is no workgroup barrier until the score map is complete.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool fast_run9(unsigned m) {
-  m |= m << 16;
-  const unsigned a = m & (m >> 1), b = a & (a >> 2), c = b & (b >> 4);
-  return (c & (m >> 8)) != 0;
-}
-__device__ __forceinline__ void fast_ring(const uint8_t* p, int (&ring)[16]) {
-  ring[0] = p[3 * kTileMax];       ring[1] = p[3 * kTileMax + 1];   ring[2] = p[2 * kTileMax + 2];   ring[3] = p[kTileMax + 3];
-  ring[4] = p[3];                  ring[5] = p[-kTileMax + 3];      ring[6] = p[-2 * kTileMax + 2];  ring[7] = p[-3 * kTileMax + 1];
-  ring[8] = p[-3 * kTileMax];      ring[9] = p[-3 * kTileMax - 1];  ring[10] = p[-2 * kTileMax - 2]; ring[11] = p[-kTileMax - 3];
-  ring[12] = p[-3];                ring[13] = p[kTileMax - 3];      ring[14] = p[2 * kTileMax - 2];  ring[15] = p[3 * kTileMax - 1];
-}
-__device__ __forceinline__ int fast_score(int v, const int (&ring)[16], int thr, bool isDark, bool isBright) {
-  int d[16];
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 pk_swap(s16x2 x) { return __builtin_shufflevector(x, x, 1, 0); }
+__device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+// max over the 16 circular 9-arcs of the minimum (MIN = true) or min over the arcs of the maximum (MIN = false) of d[0..15]
+template <bool MIN>
+__device__ __forceinline__ int fast_arc_extreme(const s16x2 (&P)[8]) {
+  s16x2 a[8], b[8];
 #pragma unroll
-  for (int k = 0; k < 16; k++) d[k] = v - ring[k];
-  int best = thr;
-  if (isDark) {  // max over arcs of min(d)
-    int m2[16], m4[16], m8[16];
+  for (int j = 0; j < 8; j++) { const s16x2 o = j < 7 ? P[j + 1] : pk_swap(P[0]); a[j] = MIN ? pk_min(P[j], o) : pk_max(P[j], o); }          // 2 wide
 #pragma unroll
-    for (int k = 0; k < 16; k++) m2[k] = min(d[k], d[(k + 1) & 15]);
+  for (int j = 0; j < 8; j++) { const s16x2 o = j < 6 ? a[j + 2] : pk_swap(a[j - 6]); b[j] = MIN ? pk_min(a[j], o) : pk_max(a[j], o); }      // 4 wide
 #pragma unroll
-    for (int k = 0; k < 16; k++) m4[k] = min(m2[k], m2[(k + 2) & 15]);
+  for (int j = 0; j < 8; j++) { const s16x2 o = j < 4 ? b[j + 4] : pk_swap(b[j - 4]); a[j] = MIN ? pk_min(b[j], o) : pk_max(b[j], o); }      // 8 wide
 #pragma unroll
-    for (int k = 0; k < 16; k++) m8[k] = min(m4[k], m4[(k + 4) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++) best = max(best, min(m8[k], d[(k + 8) & 15]));
-  }
-  if (isBright) {  // max over arcs of min(-d) = -(min over arcs of max(d))
-    int m2[16], m4[16], m8[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) m2[k] = max(d[k], d[(k + 1) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++) m4[k] = max(m2[k], m2[(k + 2) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++) m8[k] = max(m4[k], m4[(k + 4) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++) best = max(best, -max(m8[k], d[(k + 8) & 15]));
-  }
-  return best - 1;
+  for (int j = 0; j < 8; j++) { const s16x2 o = pk_swap(P[j]); b[j] = MIN ? pk_min(a[j], o) : pk_max(a[j], o); }                             // 9 wide
+  s16x2 r;
+  if (MIN) r = pk_max(pk_max(pk_max(b[0], b[1]), pk_max(b[2], b[3])), pk_max(pk_max(b[4], b[5]), pk_max(b[6], b[7])));
+  else r = pk_min(pk_min(pk_min(b[0], b[1]), pk_min(b[2], b[3])), pk_min(pk_min(b[4], b[5]), pk_min(b[6], b[7])));
+  return MIN ? max((int)r.x, (int)r.y) : min((int)r.x, (int)r.y);
 }
 
-// ordered (stable) compaction of one 256-item round: returns this thread's output slot (or -1) and advances *total
-__device__ __forceinline__ int fast_compact(bool keep, int* waveCnt, int& total) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const unsigned long long m = __ballot(keep);
-  __syncthreads();                       // previous round's readers of waveCnt are done
-  if (lane == 0) waveCnt[wv] = __popcll(m);
-  __syncthreads();
-  int off = total;
-  for (int j = 0; j < wv; j++) off += waveCnt[j];
-  total += waveCnt[0] + waveCnt[1] + waveCnt[2] + waveCnt[3];
-  return keep ? off + __popcll(m & ((1ull << lane) - 1ull)) : -1;
-}
+constexpr int kFastSeg = ((kTileMax - 6 + 3) / 4) * (kTileMax - 6);   // band pixels one wave can own
 
 // ------------------------------------------------------------------------------------------------
 // One workgroup per (cell, frame): cv::FAST(cell sub-image, thr, nms=true) — orbExtractor.cpp:562-590.
@@ -226,15 +221,14 @@ __device__ __forceinline__ int fast_compact(bool keep, int* waveCnt, int& total)
 // cv::FAST returns them) into the cell's fixed slot; the quad-tree kernel concatenates cells in
 // (row, col) order, which reproduces keyPointsToDistr.  The retry at :583 uses the same threshold
 // (m_int_minFastThd is initialised from _initFastThd, :318), so it is a no-op and is not launched.
-// Every list is produced by stable compaction in pixel order, so the final list needs no sort.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyrFrameStride, PlanDev P,
                                                     const CellDev* __restrict__ cells, int thr,
                                                     uint32_t* __restrict__ cellCount, uint32_t* __restrict__ cellCand) {
   __shared__ __align__(4) uint8_t tile[kTileMax * kTileMax];
   __shared__ uint8_t score[(kTileMax - 4) * (kTileMax - 4)];
-  __shared__ uint16_t list[(kTileMax - 6) * (kTileMax - 6)];   // pixel index (12 bits) | dark << 14 | bright << 15
-  __shared__ int waveCnt[4];
+  __shared__ uint16_t list[4][kFastSeg];   // per wave: (band row << 7) | band column
+  __shared__ int cntD[4];
   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own L2); gridDim.x is a multiple of 8, so
   // block (bx, f) runs on XCD bx % 8.  Inside every group of 8 frames the (bx, f) pairs are permuted so that XCD x processes ALL
   // cells of frame 8*(f/8) + x: the 6-px halo a cell shares with its neighbours (and the level a frame's cells share) is then
@@ -265,85 +259,100 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     }
   }
   const int sw = bw + 2, sh = bh + 2;  // score map with a zero ring
-  for (int i = threadIdx.x; i < sw * sh; i += 256) score[i] = 0;
+  for (int i = threadIdx.x; i < (sw * sh + 3) >> 2; i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
   __syncthreads();
-  const int nBand = bw * bh;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  uint16_t* seg = list[wv];
   const float rbw = 1.0f / (float)bw;   // i / bw as (int)((i + 0.5f) * rbw): exact for i < 4096
-  // stage A: compass test over the band
+  // stage A: compass test over this wave's rows of the band
   int n1 = 0;
-  for (int base = 0; base < nBand; base += 256) {
-    const int i = base + threadIdx.x;
-    bool keep = false;
-    if (i < nBand) {
-      const int by = (int)(((float)i + 0.5f) * rbw), bx = i - by * bw;
-      const uint8_t* p = &tile[(by + 3) * kTileMax + bx + 3];
-      const int v = p[0], hi = v + thr, lo = v - thr;
-      const int r0 = p[3 * kTileMax], r4 = p[3], r8 = p[-3 * kTileMax], r12 = p[-3];
-      const int nb = (r0 > hi) + (r4 > hi) + (r8 > hi) + (r12 > hi), nd = (r0 < lo) + (r4 < lo) + (r8 < lo) + (r12 < lo);
-      keep = nb >= 2 || nd >= 2;
+  {
+    const int iEnd = ((bh * (wv + 1)) >> 2) * bw;
+    for (int base = ((bh * wv) >> 2) * bw; base < iEnd; base += 64) {
+      const int i = base + lane;
+      bool keep = false;
+      unsigned ent = 0;
+      if (i < iEnd) {
+        const int by = (int)(((float)i + 0.5f) * rbw), bx = i - by * bw;
+        const uint8_t* p = &tile[(by + 3) * kTileMax + bx + 3];
+        const int v = p[0];
+        const int a = p[3 * kTileMax], b = p[-3 * kTileMax], cc = p[3], d = p[-3];
+        const int lo1 = min(a, b), hi1 = max(a, b), lo2 = min(cc, d), hi2 = max(cc, d);
+        const int second = max(max(lo1, lo2), min(hi1, hi2)), third = min(min(hi1, hi2), max(lo1, lo2));
+        keep = second > v + thr || third < v - thr;   // >= 2 brighter or >= 2 darker compass pixels
+        ent = (unsigned)(by << 7) | (unsigned)bx;
+      }
+      const unsigned long long m = __ballot(keep);
+      if (keep) seg[n1 + __popcll(m & below)] = (uint16_t)ent;
+      n1 += __popcll(m);
     }
-    const int pos = fast_compact(keep, waveCnt, n1);
-    if (pos >= 0) list[pos] = (uint16_t)i;   // pos <= i: in-place safe
   }
-  __syncthreads();
-  // stage B: segment test on the survivors (in place: the output index never passes the input index)
+  // stage B: arc test and score in one network; corners stay in the segment (compacted in place: writes never pass the reads)
   int n2 = 0;
-  for (int base = 0; base < n1; base += 256) {
-    const int j = base + threadIdx.x;
+  for (int base = 0; base < n1; base += 64) {
+    const int j = base + lane;
     bool keep = false;
     unsigned ent = 0;
+    int sc = 0, si = 0;
     if (j < n1) {
-      const int i = list[j];
-      const int by = (int)(((float)i + 0.5f) * rbw), bx = i - by * bw;
+      ent = seg[j];
+      const int by = ent >> 7, bx = ent & 127;
       const uint8_t* p = &tile[(by + 3) * kTileMax + bx + 3];
-      const int v = p[0];
-      int ring[16];
-      fast_ring(p, ring);
-      unsigned dark = 0, bright = 0;
-#pragma unroll
-      for (int k = 0; k < 16; k++) {
-        dark |= (unsigned)(ring[k] < v - thr) << k;
-        bright |= (unsigned)(ring[k] > v + thr) << k;
-      }
-      const bool isDark = fast_run9(dark), isBright = fast_run9(bright);
-      keep = isDark || isBright;
-      ent = (unsigned)i | (isDark ? 0x4000u : 0u) | (isBright ? 0x8000u : 0u);
+      const short v = (short)p[0];
+      const s16x2 vv = {v, v};
+      s16x2 Pd[8];
+      Pd[0] = vv - s16x2{(short)p[3 * kTileMax], (short)p[-3 * kTileMax]};
+      Pd[1] = vv - s16x2{(short)p[3 * kTileMax + 1], (short)p[-3 * kTileMax - 1]};
+      Pd[2] = vv - s16x2{(short)p[2 * kTileMax + 2], (short)p[-2 * kTileMax - 2]};
+      Pd[3] = vv - s16x2{(short)p[kTileMax + 3], (short)p[-kTileMax - 3]};
+      Pd[4] = vv - s16x2{(short)p[3], (short)p[-3]};
+      Pd[5] = vv - s16x2{(short)p[-kTileMax + 3], (short)p[kTileMax - 3]};
+      Pd[6] = vv - s16x2{(short)p[-2 * kTileMax + 2], (short)p[2 * kTileMax - 2]};
+      Pd[7] = vv - s16x2{(short)p[-3 * kTileMax + 1], (short)p[3 * kTileMax - 1]};
+      const int best = max(fast_arc_extreme<true>(Pd), -fast_arc_extreme<false>(Pd));   // darker arcs / brighter arcs
+      keep = best > thr;
+      sc = best - 1;                               // cornerScore<16>: max(t, arcs) - 1
+      si = (by + 1) * sw + bx + 1;
     }
-    const int pos = fast_compact(keep, waveCnt, n2);   // its barriers also order this round's list reads before the writes
-    if (pos >= 0) list[pos] = (uint16_t)ent;
+    const unsigned long long m = __ballot(keep);
+    if (keep) {
+      seg[n2 + __popcll(m & below)] = (uint16_t)ent;
+      score[si] = (uint8_t)sc;
+    }
+    n2 += __popcll(m);
   }
   __syncthreads();
-  // stage C: corner score, corners only
-  for (int j = threadIdx.x; j < n2; j += 256) {
-    const unsigned ent = list[j];
-    const int i = ent & 0xFFF;
-    const int by = (int)(((float)i + 0.5f) * rbw), bx = i - by * bw;
-    const uint8_t* p = &tile[(by + 3) * kTileMax + bx + 3];
-    int ring[16];
-    fast_ring(p, ring);
-    score[(by + 1) * sw + bx + 1] = (uint8_t)fast_score(p[0], ring, thr, (ent & 0x4000u) != 0, (ent & 0x8000u) != 0);
-  }
-  __syncthreads();
-  // stage D: NMS (strictly greater than the 8 neighbours; zeros outside the band) + ordered output
-  uint32_t* dst = cellCand + slot * P.cellCap;
+  // stage C: NMS (strictly greater than the 8 neighbours; zeros outside the band), again compacted in place
   int n3 = 0;
-  for (int base = 0; base < n2; base += 256) {
-    const int j = base + threadIdx.x;
+  for (int base = 0; base < n2; base += 64) {
+    const int j = base + lane;
     bool keep = false;
-    int bx = 0, by = 0, s = 0;
+    unsigned ent = 0;
     if (j < n2) {
-      const int i = list[j] & 0xFFF;
-      by = (int)(((float)i + 0.5f) * rbw);
-      bx = i - by * bw;
-      const uint8_t* q = &score[(by + 1) * sw + bx + 1];
-      s = q[0];
+      ent = seg[j];
+      const uint8_t* q = &score[((ent >> 7) + 1) * sw + (ent & 127) + 1];
+      const int s = q[0];
       keep = s > q[-1] && s > q[1] && s > q[-sw - 1] && s > q[-sw] && s > q[-sw + 1] && s > q[sw - 1] && s > q[sw] && s > q[sw + 1];
     }
-    const int pos = fast_compact(keep, waveCnt, n3);
-    if (pos >= 0 && pos < P.cellCap) dst[pos] = qt_pack(c.x0 + 3 + bx - kBorder, c.y0 + 3 + by - kBorder, s);
+    const unsigned long long m = __ballot(keep);
+    if (keep) seg[n3 + __popcll(m & below)] = (uint16_t)ent;
+    n3 += __popcll(m);
   }
-  if (threadIdx.x == 0) cellCount[slot] = (uint32_t)min(n3, P.cellCap);
+  if (lane == 0) cntD[wv] = n3;
+  __syncthreads();
+  // ordered output: the waves' row blocks are consecutive, so wave w's keypoints follow those of waves < w
+  int off = 0;
+  for (int w = 0; w < wv; w++) off += cntD[w];
+  uint32_t* dst = cellCand + slot * P.cellCap;
+  for (int j = lane; j < n3; j += 64) {
+    const unsigned ent = seg[j];
+    const int by = ent >> 7, bx = ent & 127, pos = off + j;
+    if (pos < P.cellCap) dst[pos] = qt_pack(c.x0 + 3 + bx - kBorder, c.y0 + 3 + by - kBorder, score[(by + 1) * sw + bx + 1]);
+  }
+  if (threadIdx.x == 0) cellCount[slot] = (uint32_t)min(cntD[0] + cntD[1] + cntD[2] + cntD[3], P.cellCap);
 }
+
 
 struct QtBlockCtx {   // workgroup of kQtThreads threads: barriers + LDS hand-off of the per-wave scan totals
   unsigned* w32;
