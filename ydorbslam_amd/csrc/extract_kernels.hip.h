@@ -884,13 +884,14 @@ __global__ __launch_bounds__(kQtFlatThreads) void k_quadtree_flat(PlanDev P, con
 // ------------------------------------------------------------------------------------------------
 // cv::GaussianBlur(level, 7x7, sigma 2, BORDER_REFLECT_101) in OpenCV's 8.8 fixed-point form
 // (orbExtractor.cpp:385-386).  The pyramid's own 19-px reflect-101 pad supplies the border.
-// 64x16 output tile per workgroup: LDS-staged source, separable 16-bit horizontal / 32-bit vertical.
+// 64x16 output tile per workgroup: LDS-staged source, separable: 16-bit horizontal sums (v_dot4_u32_u8), 32-bit vertical
+// (v_dot2_u32_u16) — the same integers as the scalar form, (sum + 32768) >> 16.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, size_t pyrFrameStride, uint8_t* __restrict__ blur,
                                               size_t blurFrameStride, PlanDev P) {
   constexpr int TW = 64, TH = 16, SH = TH + 6, SWW = 18;  // source tile: 22 rows x 18 dwords (72 B: cols x0-3 .. x0+68)
   __shared__ uint32_t src[SH * SWW];
-  __shared__ __align__(8) uint16_t hb[SH * TW];
+  __shared__ __align__(16) uint32_t hb[(SH / 2) * TW];   // horizontal sums, rows paired: (row 2p | row 2p+1 << 16)
   const int level = blockIdx.y;
   int f = blockIdx.z, tileId = blockIdx.x;
   if ((f | 7) < (int)gridDim.z) {   // XCD-aware (see k_fast_cells): XCD x handles every tile of frame 8*(f/8) + x
@@ -911,30 +912,47 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, s
     src[i] = pcol < L.pitch ? *reinterpret_cast<const uint32_t*>(padded + (size_t)prow * L.pitch + pcol) : 0u;
   }
   __syncthreads();
-  // horizontal pass: 4 outputs per thread from 3 dwords (bytes c4 .. c4+11 of the source row)
-  for (int i = threadIdx.x; i < SH * (TW / 4); i += 256) {
-    const int r = i >> 4, g = i & 15;
-    const uint32_t w0 = src[r * SWW + g], w1 = src[r * SWW + g + 1], w2 = src[r * SWW + g + 2];
-    int b[12];
+  // horizontal pass, two source rows per thread: the 7 taps of an output are two v_dot4_u32_u8 over the byte windows
+  // [k, k+4) and [k+4, k+8) of the row (v_alignbyte), and the two rows' results share a dword, (row 2p | row 2p+1 << 16), so
+  // that the vertical pass can take two taps per v_dot2_u32_u16.  (The kernel is VALU-issue bound; this halves its VALU count.)
+  if (threadIdx.x < (SH / 2) * (TW / 4)) {
+    const int rp = threadIdx.x >> 4, g = threadIdx.x & 15;
+    uint32_t o[2][4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { b[k] = (w0 >> (8 * k)) & 255; b[4 + k] = (w1 >> (8 * k)) & 255; b[8 + k] = (w2 >> (8 * k)) & 255; }
-    uint32_t o[4];
+    for (int h = 0; h < 2; h++) {
+      const int r = 2 * rp + h;
+      const uint32_t w0 = src[r * SWW + g], w1 = src[r * SWW + g + 1], w2 = src[r * SWW + g + 2];
 #pragma unroll
-    for (int k = 0; k < 4; k++) o[k] = 18 * (b[k] + b[k + 6]) + 34 * (b[k + 1] + b[k + 5]) + 48 * (b[k + 2] + b[k + 4]) + 56 * b[k + 3];
-    *reinterpret_cast<uint2*>(&hb[r * TW + g * 4]) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+      for (int k = 0; k < 4; k++) {
+        const uint32_t lo4 = k ? __builtin_amdgcn_alignbyte(w1, w0, k) : w0, hi4 = k ? __builtin_amdgcn_alignbyte(w2, w1, k) : w1;
+        o[h][k] = __builtin_amdgcn_udot4(hi4, 0x00122230u, __builtin_amdgcn_udot4(lo4, 0x38302212u, 0u, false), false);   // 18 34 48 56 | 48 34 18
+      }
+    }
+    *reinterpret_cast<uint4*>(&hb[rp * TW + g * 4]) =
+        make_uint4(o[0][0] | (o[1][0] << 16), o[0][1] | (o[1][1] << 16), o[0][2] | (o[1][2] << 16), o[0][3] | (o[1][3] << 16));
   }
   __syncthreads();
   const int r = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
   const int gy = y0 + r;
   if (gy < L.h && x0 + c4 < L.blurPitch) {
-    uint32_t acc[4] = {0, 0, 0, 0};
-    const uint32_t kw[7] = {18, 34, 48, 56, 48, 34, 18};
+    // rows r .. r+6 live in row pairs r/2 .. r/2+3; an odd r starts in the upper half of its first pair
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const bool odd = r & 1;
+    const u16x2 k0 = odd ? u16x2{0, 18} : u16x2{18, 34}, k1 = odd ? u16x2{34, 48} : u16x2{48, 56};
+    const u16x2 k2 = odd ? u16x2{56, 48} : u16x2{48, 34}, k3 = odd ? u16x2{34, 18} : u16x2{18, 0};
+    const uint32_t* hp = &hb[(r >> 1) * TW + c4];
+    const uint4 p0 = *reinterpret_cast<const uint4*>(hp), p1 = *reinterpret_cast<const uint4*>(hp + TW);
+    const uint4 p2 = *reinterpret_cast<const uint4*>(hp + 2 * TW), p3 = *reinterpret_cast<const uint4*>(hp + 3 * TW);
+    const uint32_t q0[4] = {p0.x, p0.y, p0.z, p0.w}, q1[4] = {p1.x, p1.y, p1.z, p1.w}, q2[4] = {p2.x, p2.y, p2.z, p2.w}, q3[4] = {p3.x, p3.y, p3.z, p3.w};
+    uint32_t acc[4];
 #pragma unroll
-    for (int j = 0; j < 7; j++) {
-      const uint2 h = *reinterpret_cast<const uint2*>(&hb[(r + j) * TW + c4]);
-      acc[0] += kw[j] * (h.x & 0xFFFF); acc[1] += kw[j] * (h.x >> 16); acc[2] += kw[j] * (h.y & 0xFFFF); acc[3] += kw[j] * (h.y >> 16);
+    for (int k = 0; k < 4; k++) {
+      acc[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, q0[k]), k0, 32768u, false);
+      acc[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, q1[k]), k1, acc[k], false);
+      acc[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, q2[k]), k2, acc[k], false);
+      acc[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, q3[k]), k3, acc[k], false);
     }
-    const uint32_t out = ((acc[0] + 32768u) >> 16) | (((acc[1] + 32768u) >> 16) << 8) | (((acc[2] + 32768u) >> 16) << 16) | (((acc[3] + 32768u) >> 16) << 24);
+    const uint32_t out = (acc[0] >> 16) | ((acc[1] >> 16) << 8) | ((acc[2] >> 16) << 16) | ((acc[3] >> 16) << 24);
     *reinterpret_cast<uint32_t*>(blur + (size_t)f * blurFrameStride + L.blurOff + (size_t)gy * L.blurPitch + x0 + c4) = out;
   }
 }
