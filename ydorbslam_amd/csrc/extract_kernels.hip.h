@@ -1015,7 +1015,7 @@ __device__ __forceinline__ void sincos_det(float xf, float* sinOut, float* cosOu
   *cosOut = (float)cv;
 }
 
-__device__ const int8_t kPatternDev[1024] = {
+__device__ __align__(16) const float kPatternDev[1024] = {   // (x0, y0, x1, y1) per test, already as float: the kernel is VALU-bound
 #include "orb_pattern_data.inc"
 };
 
@@ -1024,6 +1024,8 @@ __device__ const int8_t kPatternDev[1024] = {
 // own m_v_maxXcords table), then steered rBRIEF on the blurred level (:422-454) and the final
 // cv::KeyPoint (:391-396, :595-601).  Lane l evaluates tests l, 64+l, 128+l, 192+l; a 64-bit ballot of
 // (t0 < t1) is exactly 8 consecutive descriptor bytes.
+// Everything that is the same for the whole wave (slot, level, keypoint, patch origin) is kept in scalar registers, and the
+// pixel loads use a scalar base + non-negative 32-bit lane offset (the base is moved up-left of the patch).
 // ------------------------------------------------------------------------------------------------
 struct YdKeyPointDev { float x, y, size, angle, response; int octave, class_id; };
 
@@ -1038,7 +1040,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
     bx = (f & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     f = (f & ~7) | (blockIdx.x & 7);
   }
-  const int slot = bx * 4 + (threadIdx.x >> 6);
+  const int slot = bx * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (slot >= P.sumQuota) return;
   int level = 0, before = 0, tot = 0;
   for (int l = 0; l < P.nLevels; l++) {
@@ -1052,18 +1054,27 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
   if (k >= lvlCount[f * kMaxLevels + level]) return;
   const int outIdx = before + k;
   if (outIdx >= cap) return;
-  const uint32_t pk = lvlKp[(size_t)f * P.sumQuota + slot];
+  const uint32_t pk = __builtin_amdgcn_readfirstlane(lvlKp[(size_t)f * P.sumQuota + slot]);
   const int kx = qt_x(pk) + kBorder, ky = qt_y(pk) + kBorder;
   const uint8_t* roi = pyr + (size_t)f * pyrFrameStride + L.padOff + (size_t)kPad * L.pitch + kPad;
-  const uint8_t* ctr = roi + (ptrdiff_t)ky * L.pitch + kx;
-  // --- orientation ---
+  // --- orientation.  The reference's m_v_maxXcords is 0 for most rows (only the centre column counts there) and up to 26 for
+  // the rest, so: one lane per single-column row (all of them in one step), then one step per wide row with u = lane - 32.
+  const uint8_t* org = roi + (ptrdiff_t)(ky - 15) * L.pitch + (kx - 32);   // row ky-15, column kx-32: every offset below is >= 0
   const int u = lane - 32;
+  unsigned narrow = 0;                     // bit v: row v has maxX == 0 (wave-uniform, scalar)
+#pragma unroll
+  for (int v = 1; v <= 15; v++) narrow |= (unsigned)(P.maxX[v] == 0) << v;
   int m10 = 0, m01 = 0;
-  if (u >= -15 && u <= 15) m10 = u * ctr[u];
+  if (u >= -15 && u <= 15) m10 = u * org[(unsigned)(15 * L.pitch + lane)];
+  if (lane >= 1 && lane <= 15 && ((narrow >> lane) & 1u)) {
+    const int pos = org[(unsigned)((15 + lane) * L.pitch + 32)], neg = org[(unsigned)((15 - lane) * L.pitch + 32)];
+    m01 = lane * (pos - neg);              // u == 0: no m10 term
+  }
+#pragma unroll
   for (int v = 1; v <= 15; v++) {
     const int d = P.maxX[v];
-    if (u >= -d && u <= d) {
-      const int pos = ctr[(ptrdiff_t)v * L.pitch + u], neg = ctr[-(ptrdiff_t)v * L.pitch + u];
+    if (d > 0 && u >= -d && u <= d) {
+      const int pos = org[(unsigned)((15 + v) * L.pitch + lane)], neg = org[(unsigned)((15 - v) * L.pitch + lane)];
       m01 += v * (pos - neg);
       m10 += u * (pos + neg);
     }
@@ -1078,17 +1089,17 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
   const float rad = __fmul_rn(angle, (float)(3.14159265358979323846 / 180.0));
   float sinB, cosA;
   sincos_det(rad, &sinB, &cosA);
-  const uint8_t* bl = blur + (size_t)f * blurFrameStride + L.blurOff + (size_t)ky * L.blurPitch + kx;
+  constexpr int kBias = 24;   // |rotated pattern coordinate| <= 13 * sqrt(2) + 0.5 < 24 (and the reference keeps 19 px of margin)
+  const uint8_t* bl = blur + (size_t)f * blurFrameStride + L.blurOff + (ptrdiff_t)(ky - kBias) * L.blurPitch + (kx - kBias);
   unsigned long long words[4];
 #pragma unroll
   for (int t = 0; t < 4; t++) {
-    const int8_t* pt = &kPatternDev[4 * (t * 64 + lane)];
-    const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
-    const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sinB), __fmul_rn(y0, cosA)));
-    const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, cosA), __fmul_rn(y0, sinB)));
-    const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sinB), __fmul_rn(y1, cosA)));
-    const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, cosA), __fmul_rn(y1, sinB)));
-    const int t0 = bl[(ptrdiff_t)r0 * L.blurPitch + c0], t1 = bl[(ptrdiff_t)r1 * L.blurPitch + c1];
+    const float4 pt = reinterpret_cast<const float4*>(kPatternDev)[t * 64 + lane];
+    const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(pt.x, sinB), __fmul_rn(pt.y, cosA)));
+    const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(pt.x, cosA), __fmul_rn(pt.y, sinB)));
+    const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(pt.z, sinB), __fmul_rn(pt.w, cosA)));
+    const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(pt.z, cosA), __fmul_rn(pt.w, sinB)));
+    const int t0 = bl[(unsigned)((r0 + kBias) * L.blurPitch + c0 + kBias)], t1 = bl[(unsigned)((r1 + kBias) * L.blurPitch + c1 + kBias)];
     words[t] = __ballot(t0 < t1);
   }
   if (lane < 4) {
