@@ -105,10 +105,10 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ 
 // is written exactly once.  Coefficient tables (11-bit fixed point) are built on the host.
 // Interior fast path: the 4 outputs of a thread read source columns sx[0] .. sx[3]+1, at most 8 consecutive bytes for
 // scale factors <= 2, fetched as one unaligned 8-byte load per source row.  The row tables are indexed by a wave-uniform
-// row number (scalar loads).
+// row number (scalar loads); the source column is computed in the kernel, only the weights come from the column table.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, size_t pyrFrameStride, LevelDev Lp, LevelDev L,
-                                                    const int* __restrict__ xofs, const short* __restrict__ alpha,
+                                                    double scaleX, const short* __restrict__ alpha,
                                                     const int* __restrict__ yofs, const short* __restrict__ beta) {
   const int wx = blockIdx.x * 64 + (threadIdx.x & 63);
   const int yb = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * kPyrRows;
@@ -123,7 +123,11 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, s
     sx[b] = -1; sx1[b] = 0; a0[b] = 0; a1[b] = 0;
     if (x0 + b < L.w + kPad) {
       const int dx = reflect101(x0 + b, L.w);
-      sx[b] = xofs[dx]; a0[b] = alpha[2 * dx]; a1[b] = alpha[2 * dx + 1];
+      // source column computed here (the same IEEE sequence as the host's coefficient table): the pixel loads then wait for
+      // no table load, only the weights do
+      const float fx = (float)__dsub_rn(__dmul_rn((double)dx + 0.5, scaleX), 0.5);
+      sx[b] = min(max((int)floorf(fx), 0), Lp.w - 1);
+      a0[b] = alpha[2 * dx]; a1[b] = alpha[2 * dx + 1];
       sx1[b] = min(sx[b] + 1, Lp.w - 1);   // a1 == 0 whenever sx+1 is outside
     }
   }
@@ -140,6 +144,17 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, s
   }
   uint32_t v[kPyrRows];
   if (fast) {
+    // Both taps of an output as one u16 pair picked out of the 8 loaded bytes (v_perm_b32, selector fixed per column) and
+    // weighted by (alpha0, alpha1) in one v_dot2_u32_u16: the kernel is VALU-bound and this is a third of the scalar form.
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    uint32_t sel[4];
+    u16x2 ab[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const uint32_t off = (uint32_t)(sx[b] - sx[0]);
+      sel[b] = off | 0x0c000c00u | ((off + 1) << 16);        // byte off -> bits 0..7, byte off+1 -> bits 16..23, zeros between
+      ab[b] = u16x2{(unsigned short)a0[b], (unsigned short)a1[b]};
+    }
     unsigned long long w0[kPyrRows], w1[kPyrRows];
 #pragma unroll
     for (int r = 0; r < kPyrRows; r++) {
@@ -151,9 +166,10 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, s
       v[r] = 0;
 #pragma unroll
       for (int b = 0; b < 4; b++) {
-        const int sh = 8 * (sx[b] - sx[0]);
-        const int h0 = (int)((w0[r] >> sh) & 255) * a0[b] + (int)((w0[r] >> (sh + 8)) & 255) * a1[b];
-        const int h1 = (int)((w1[r] >> sh) & 255) * a0[b] + (int)((w1[r] >> (sh + 8)) & 255) * a1[b];
+        const uint32_t p0 = __builtin_amdgcn_perm((uint32_t)(w0[r] >> 32), (uint32_t)w0[r], sel[b]);
+        const uint32_t p1 = __builtin_amdgcn_perm((uint32_t)(w1[r] >> 32), (uint32_t)w1[r], sel[b]);
+        const int h0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p0), ab[b], 0u, false);
+        const int h1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p1), ab[b], 0u, false);
         const int o = (((b0[r] * (h0 >> 4)) >> 16) + ((b1[r] * (h1 >> 4)) >> 16) + 2) >> 2;
         v[r] |= (uint32_t)(o & 0xFF) << (8 * b);
       }

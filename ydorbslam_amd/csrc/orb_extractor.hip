@@ -336,7 +336,7 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
       const LevelDev& L = D.lv[l];
       dim3 gl((L.pitch / 4 + 63) / 64, (L.h + 2 * kPad + 4 * kPyrRows - 1) / (4 * kPyrRows), nFrames);
       hipLaunchKernelGGL(k_pyr_resize, gl, dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, D.lv[l - 1], L,
-                         e->d_tabInt + P.tab[l].xofs, e->d_tabShort + P.tab[l].alpha, e->d_tabInt + P.tab[l].yofs,
+                         1. / ((double)L.w / D.lv[l - 1].w), e->d_tabShort + P.tab[l].alpha, e->d_tabInt + P.tab[l].yofs,
                          e->d_tabShort + P.tab[l].beta);
     }
   }
