@@ -42,8 +42,10 @@ struct LevelDev {
 struct PlanDev {
   int nLevels, nCellsTotal, cellCap, sumQuota;
   int maxX[16];             // m_v_maxXcords[0..15]
+  int blurTileBegin[kMaxLevels + 1];   // first 64x32 blur tile of each level in the flat per-frame tile list
   LevelDev lv[kMaxLevels];
 };
+constexpr int kBlurTW = 64, kBlurTH = 32;
 struct CellDev {            // FAST sub-image [x0,x1) x [y0,y1) in level coordinates (orbExtractor.cpp:562-581)
   short level, x0, y0, x1, y1, pad0, pad1, pad2;
 };
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
                                                     uint32_t* __restrict__ cellCount, uint32_t* __restrict__ cellCand) {
   __shared__ __align__(4) uint8_t tile[kTileMax * kTileMax];
   __shared__ uint8_t score[(kTileMax - 4) * (kTileMax - 4)];
-  __shared__ uint16_t list[4][kFastSeg];   // per wave: (band row << 7) | band column
+  __shared__ uint16_t list[4][kFastSeg];   // per wave: (band row << 7) | band column | darker-arcs flag << 14 | brighter << 15
   __shared__ int cntD[4];
   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own L2); gridDim.x is a multiple of 8, so
   // block (bx, f) runs on XCD bx % 8.  Inside every group of 8 frames the (bx, f) pairs are permuted so that XCD x processes ALL
@@ -296,8 +298,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         const int a = p[3 * kTileMax], b = p[-3 * kTileMax], cc = p[3], d = p[-3];
         const int lo1 = min(a, b), hi1 = max(a, b), lo2 = min(cc, d), hi2 = max(cc, d);
         const int second = max(max(lo1, lo2), min(hi1, hi2)), third = min(min(hi1, hi2), max(lo1, lo2));
-        keep = second > v + thr || third < v - thr;   // >= 2 brighter or >= 2 darker compass pixels
-        ent = (unsigned)(by << 7) | (unsigned)bx;
+        const bool cb = second > v + thr, cd = third < v - thr;   // >= 2 brighter / >= 2 darker compass pixels
+        keep = cb || cd;
+        ent = (unsigned)(by << 7) | (unsigned)bx | (cd ? 0x4000u : 0u) | (cb ? 0x8000u : 0u);   // which arc polarity can still pass
       }
       const unsigned long long m = __ballot(keep);
       if (keep) seg[n1 + __popcll(m & below)] = (uint16_t)ent;
@@ -313,20 +316,28 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     int sc = 0, si = 0;
     if (j < n1) {
       ent = seg[j];
-      const int by = ent >> 7, bx = ent & 127;
+      const int by = (ent >> 7) & 127, bx = ent & 127;
       const uint8_t* p = &tile[(by + 3) * kTileMax + bx + 3];
       const short v = (short)p[0];
       const s16x2 vv = {v, v};
+      // One polarity per pixel: the compass test already says whether the darker or the brighter arcs can pass (a pixel cannot
+      // be a corner both ways: 9 + 9 > 16), so d is sign-adjusted and ONE min-network runs.  The few pixels whose compass test
+      // passed both ways get the second polarity in a wave-uniform extra step.
+      const bool dark = (ent & 0x4000u) != 0;
+      const s16x2 sg = dark ? s16x2{1, 1} : s16x2{-1, -1};
       s16x2 Pd[8];
-      Pd[0] = vv - s16x2{(short)p[3 * kTileMax], (short)p[-3 * kTileMax]};
-      Pd[1] = vv - s16x2{(short)p[3 * kTileMax + 1], (short)p[-3 * kTileMax - 1]};
-      Pd[2] = vv - s16x2{(short)p[2 * kTileMax + 2], (short)p[-2 * kTileMax - 2]};
-      Pd[3] = vv - s16x2{(short)p[kTileMax + 3], (short)p[-kTileMax - 3]};
-      Pd[4] = vv - s16x2{(short)p[3], (short)p[-3]};
-      Pd[5] = vv - s16x2{(short)p[-kTileMax + 3], (short)p[kTileMax - 3]};
-      Pd[6] = vv - s16x2{(short)p[-2 * kTileMax + 2], (short)p[2 * kTileMax - 2]};
-      Pd[7] = vv - s16x2{(short)p[-3 * kTileMax + 1], (short)p[3 * kTileMax - 1]};
-      const int best = max(fast_arc_extreme<true>(Pd), -fast_arc_extreme<false>(Pd));   // darker arcs / brighter arcs
+      Pd[0] = (vv - s16x2{(short)p[3 * kTileMax], (short)p[-3 * kTileMax]}) * sg;
+      Pd[1] = (vv - s16x2{(short)p[3 * kTileMax + 1], (short)p[-3 * kTileMax - 1]}) * sg;
+      Pd[2] = (vv - s16x2{(short)p[2 * kTileMax + 2], (short)p[-2 * kTileMax - 2]}) * sg;
+      Pd[3] = (vv - s16x2{(short)p[kTileMax + 3], (short)p[-kTileMax - 3]}) * sg;
+      Pd[4] = (vv - s16x2{(short)p[3], (short)p[-3]}) * sg;
+      Pd[5] = (vv - s16x2{(short)p[-kTileMax + 3], (short)p[kTileMax - 3]}) * sg;
+      Pd[6] = (vv - s16x2{(short)p[-2 * kTileMax + 2], (short)p[2 * kTileMax - 2]}) * sg;
+      Pd[7] = (vv - s16x2{(short)p[-3 * kTileMax + 1], (short)p[3 * kTileMax - 1]}) * sg;
+      int best = fast_arc_extreme<true>(Pd);
+      if (__ballot((ent & 0xC000u) == 0xC000u)) {   // some pixel of this chunk needs the brighter arcs too
+        if ((ent & 0xC000u) == 0xC000u) best = max(best, -fast_arc_extreme<false>(Pd));
+      }
       keep = best > thr;
       sc = best - 1;                               // cornerScore<16>: max(t, arcs) - 1
       si = (by + 1) * sw + bx + 1;
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     unsigned ent = 0;
     if (j < n2) {
       ent = seg[j];
-      const uint8_t* q = &score[((ent >> 7) + 1) * sw + (ent & 127) + 1];
+      const uint8_t* q = &score[(((ent >> 7) & 127) + 1) * sw + (ent & 127) + 1];
       const int s = q[0];
       keep = s > q[-1] && s > q[1] && s > q[-sw - 1] && s > q[-sw] && s > q[-sw + 1] && s > q[sw - 1] && s > q[sw] && s > q[sw + 1];
     }
@@ -363,7 +374,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
   uint32_t* dst = cellCand + slot * P.cellCap;
   for (int j = lane; j < n3; j += 64) {
     const unsigned ent = seg[j];
-    const int by = ent >> 7, bx = ent & 127, pos = off + j;
+    const int by = (ent >> 7) & 127, bx = ent & 127, pos = off + j;
     if (pos < P.cellCap) dst[pos] = qt_pack(c.x0 + 3 + bx - kBorder, c.y0 + 3 + by - kBorder, score[(by + 1) * sw + bx + 1]);
   }
   if (threadIdx.x == 0) cellCount[slot] = (uint32_t)min(cntD[0] + cntD[1] + cntD[2] + cntD[3], P.cellCap);
@@ -900,23 +911,29 @@ __global__ __launch_bounds__(kQtFlatThreads) void k_quadtree_flat(PlanDev P, con
 // ------------------------------------------------------------------------------------------------
 // cv::GaussianBlur(level, 7x7, sigma 2, BORDER_REFLECT_101) in OpenCV's 8.8 fixed-point form
 // (orbExtractor.cpp:385-386).  The pyramid's own 19-px reflect-101 pad supplies the border.
-// 64x16 output tile per workgroup: LDS-staged source, separable: 16-bit horizontal sums (v_dot4_u32_u8), 32-bit vertical
+// 64x32 output tile per workgroup: LDS-staged source, separable: 16-bit horizontal sums (v_dot4_u32_u8), 32-bit vertical
 // (v_dot2_u32_u16) — the same integers as the scalar form, (sum + 32768) >> 16.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, size_t pyrFrameStride, uint8_t* __restrict__ blur,
                                               size_t blurFrameStride, PlanDev P) {
-  constexpr int TW = 64, TH = 16, SH = TH + 6, SWW = 18;  // source tile: 22 rows x 18 dwords (72 B: cols x0-3 .. x0+68)
+  constexpr int TW = kBlurTW, TH = kBlurTH, SH = TH + 6, SWW = 18;  // source tile: 38 rows x 18 dwords (72 B: cols x0-3 .. x0+68)
   __shared__ uint32_t src[SH * SWW];
   __shared__ __align__(16) uint32_t hb[(SH / 2) * TW];   // horizontal sums, rows paired: (row 2p | row 2p+1 << 16)
-  const int level = blockIdx.y;
-  int f = blockIdx.z, tileId = blockIdx.x;
-  if ((f | 7) < (int)gridDim.z) {   // XCD-aware (see k_fast_cells): XCD x handles every tile of frame 8*(f/8) + x
+  // grid.x runs over the tiles of ALL levels of a frame (a per-level grid launched 60 % empty workgroups: the kernel's waves
+  // are ~50 instructions long, so wave launch rate matters)
+  int f = blockIdx.y, tileId = blockIdx.x;
+  if ((f | 7) < (int)gridDim.y) {   // XCD-aware (see k_fast_cells): XCD x handles every tile of frame 8*(f/8) + x
     tileId = (f & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     f = (f & ~7) | (blockIdx.x & 7);
   }
+  if (tileId >= P.blurTileBegin[P.nLevels]) return;
+  int level = 0;
+#pragma unroll
+  for (int l = 1; l < kMaxLevels; l++)
+    if (l < P.nLevels && tileId >= P.blurTileBegin[l]) level = l;
+  tileId -= P.blurTileBegin[level];
   const LevelDev L = P.lv[level];
-  const int tilesX = (L.w + TW - 1) / TW, tilesY = (L.h + TH - 1) / TH;
-  if (tileId >= tilesX * tilesY) return;
+  const int tilesX = (L.w + TW - 1) / TW;
   const int ty = tileId / tilesX, tx = tileId - ty * tilesX;
   const int x0 = tx * TW, y0 = ty * TH;
   // padded-row coordinates: level x <-> x + 19, so the tile's first source column x0-3 sits at byte x0+16: dword aligned
@@ -931,8 +948,8 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, s
   // horizontal pass, two source rows per thread: the 7 taps of an output are two v_dot4_u32_u8 over the byte windows
   // [k, k+4) and [k+4, k+8) of the row (v_alignbyte), and the two rows' results share a dword, (row 2p | row 2p+1 << 16), so
   // that the vertical pass can take two taps per v_dot2_u32_u16.  (The kernel is VALU-issue bound; this halves its VALU count.)
-  if (threadIdx.x < (SH / 2) * (TW / 4)) {
-    const int rp = threadIdx.x >> 4, g = threadIdx.x & 15;
+  for (int task = threadIdx.x; task < (SH / 2) * (TW / 4); task += 256) {
+    const int rp = task >> 4, g = task & 15;
     uint32_t o[2][4];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -948,9 +965,12 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, s
         make_uint4(o[0][0] | (o[1][0] << 16), o[0][1] | (o[1][1] << 16), o[0][2] | (o[1][2] << 16), o[0][3] | (o[1][3] << 16));
   }
   __syncthreads();
-  const int r = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
-  const int gy = y0 + r;
-  if (gy < L.h && x0 + c4 < L.blurPitch) {
+  const int c4 = (threadIdx.x & 15) * 4;
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    const int r = (threadIdx.x >> 4) + 16 * half;
+    const int gy = y0 + r;
+    if (!(gy < L.h && x0 + c4 < L.blurPitch)) continue;
     // rows r .. r+6 live in row pairs r/2 .. r/2+3; an odd r starts in the upper half of its first pair
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     const bool odd = r & 1;

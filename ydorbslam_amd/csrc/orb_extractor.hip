@@ -209,6 +209,9 @@ int buildPlan(ydorb_extractor* e, int w, int h, HostPlan& P) {
     D.lv[l].candOff = candOff;
     candOff += D.lv[l].nCells * D.cellCap;
   }
+  D.blurTileBegin[0] = 0;
+  for (int l = 0; l < kMaxLevels; l++)
+    D.blurTileBegin[l + 1] = D.blurTileBegin[l] + (l < D.nLevels ? ((D.lv[l].w + kBlurTW - 1) / kBlurTW) * ((D.lv[l].h + kBlurTH - 1) / kBlurTH) : 0);
   P.pyrFrameStride = padOff;
   P.blurFrameStride = blurOff;
   P.qtFrameStride = (size_t)candOff;
@@ -348,12 +351,8 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   // fork: the blur (needs only the pyramid) goes first on `s` so that it heads its hardware queue; the quad-tree launches, one
   // per level on the side streams, wait for the FAST results only and overlap it
   HIPCHK(hipEventRecord(e->evFork, s));
-  {
-    int maxTiles = 0;
-    for (int l = 0; l < D.nLevels; l++) maxTiles = std::max(maxTiles, ((D.lv[l].w + 63) / 64) * ((D.lv[l].h + 15) / 16));
-    hipLaunchKernelGGL(k_blur, dim3((maxTiles + 7) / 8 * 8, D.nLevels, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
-                       P.blurFrameStride, D);
-  }
+  hipLaunchKernelGGL(k_blur, dim3((D.blurTileBegin[D.nLevels] + 7) / 8 * 8, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
+                     P.blurFrameStride, D);
   for (int l = 0; l < D.nLevels; l++) {
     HIPCHK(hipStreamWaitEvent(e->qtStream[l], e->evFork, 0));
     const HostPlan::QtLevel& Q = P.qt[l];
