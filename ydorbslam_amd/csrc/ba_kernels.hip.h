@@ -728,31 +728,42 @@ __global__ __launch_bounds__(256) void k_chol_step(R* __restrict__ S, R* __restr
 
 // Backward substitution L^T x = y (y comes out of the factorisation launches), single workgroup, blocked by 32 with the
 // diagonal blocks applied through their inverses:  x_k = Linv_kk^T y_k ;  y_j -= L(k,j)^T x_k  (j < k).
+// The chain over the 19 blocks is serial, so each step is kept short: the block inverse (exactly 1024 numbers, one per
+// thread) and the 32 L entries a thread needs for the update are fetched BEFORE the step's reduction (they do not depend on x),
+// and x_k is a 32-way shuffle reduction on all 1024 threads instead of a 32-term loop on 32 of them.
 __global__ __launch_bounds__(1024) void k_chol_solve(const R* __restrict__ L, const R* __restrict__ diagInv, int n, const R* __restrict__ yin,
                                                      R* __restrict__ x) {
   extern __shared__ R y[];  // [n]
+  __shared__ R inv[NB][NB + 1];
   __shared__ R yk[NB];
   const int tid = threadIdx.x, nb = n / NB;
   for (int i = tid; i < n; i += 1024) y[i] = yin[i];
-  __syncthreads();
   for (int kb = nb - 1; kb >= 0; kb--) {
-    if (tid < NB) {
-      const R* inv = diagInv + (size_t)kb * NB * NB;   // x_k[c] = sum_{r >= c} Linv[r][c] y_k[r]
-      R s = 0;
-      for (int r = tid; r < NB; r++) s += inv[r * NB + tid] * y[kb * NB + r];
-      yk[tid] = s;
+    const R invReg = diagInv[(size_t)kb * NB * NB + tid];          // element (r, c) = (tid / 32, tid % 32)
+    R lrow[NB];
+    const bool upd = tid < kb * NB;                                 // this thread's column of the update
+#pragma unroll
+    for (int r = 0; r < NB; r++) lrow[r] = upd ? L[(size_t)(kb * NB + r) * n + tid] : 0.0;
+    __syncthreads();                                                // previous step's y updates are visible; inv/yk are free
+    inv[tid >> 5][tid & 31] = invReg;
+    __syncthreads();
+    {  // x_k[c] = sum_{r >= c} Linv[r][c] y_k[r]: thread (c, r) = (tid / 32, tid % 32), reduced over the 32 lanes of a half wave
+      const int c = tid >> 5, r = tid & 31;
+      R p = r >= c ? inv[r][c] * y[kb * NB + r] : 0.0;
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) p += __shfl_xor(p, o, 64);
+      if (r == 0) yk[c] = p;
     }
     __syncthreads();
     if (tid < NB) y[kb * NB + tid] = yk[tid];
-    // y_j -= sum_r L(kb*NB + r, j) x_k[r] for j < kb*NB: row access, coalesced over j
-    for (int jcol = tid; jcol < kb * NB; jcol += 1024) {
-      R s = 0;
-#pragma unroll 8
-      for (int r = 0; r < NB; r++) s += L[(size_t)(kb * NB + r) * n + jcol] * yk[r];
-      y[jcol] -= s;
+    if (upd) {
+      R sres = 0;
+#pragma unroll
+      for (int r = 0; r < NB; r++) sres += lrow[r] * yk[r];
+      y[tid] -= sres;
     }
-    __syncthreads();
   }
+  __syncthreads();
   for (int i = tid; i < n; i += 1024) x[i] = y[i];
 }
 

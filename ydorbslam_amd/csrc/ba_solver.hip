@@ -57,6 +57,7 @@ struct Ctx {  // per-device scratch, reused across calls (localBundleAdjust runs
   DBuf err, partial, Hll, bl, Hpl, BD, Hpp, bp, S, diagL, diagInv, bs, Dinv, db, xp, xl, yv, scal, status, pairCnt, pairStart, pairCursor, pairA, pairB;
   hipEvent_t ev[2 * PH_COUNT + 2]{};
   bool evInit = false;
+  double* hPin = nullptr;   // pinned read-back area: scal[8] + status[2] (one stream sync per LM trial)
 };
 std::mutex g_mu;
 Ctx g_ctx[16];
@@ -211,10 +212,11 @@ int optimize(Run& R_, int iterations, int stage) {
     hipLaunchKernelGGL(k_pair_sort, dim3((nBuckets + 3) / 4), dim3(256), 0, s, c.pairStart.as<int>(), nBuckets, c.pairA.as<int2>(), c.pairB.as<int2>());
   }
   HIPCHK(hipMemsetAsync(dS, 0, sizeof(double) * ((size_t)n * n + n), s));
-  double hscal[8];
+  double* hscal = c.hPin;
+  int* hstatus = reinterpret_cast<int*>(c.hPin + 8);
   const bool multi = O.world > 1 && O.allreduce;
 
-  auto computeChi2 = [&](int buf, double* out) -> int {
+  auto computeChi2 = [&](int buf, double* out, bool withStatus) -> int {
     PhaseTimer t(R_, PH_ERR);
     hipLaunchKernelGGL(k_errors, dim3(nBlkE), dim3(256), 0, s, Ed, c.poses[buf].as<double>(), c.pts[buf].as<double>(), R_.cam, dM, dSt,
                        c.err.as<double>(), c.partial.as<double>());
@@ -222,15 +224,17 @@ int optimize(Run& R_, int iterations, int stage) {
     t.stop();
     if (multi) { int r2 = allreduce(R_, c.scal.p, 1, 0); if (r2) return r2; }
     HIPCHK(hipMemcpyAsync(hscal, c.scal.p, sizeof(double) * 8, hipMemcpyDeviceToHost, s));
+    if (withStatus) HIPCHK(hipMemcpyAsync(hstatus, c.status.p, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     *out = hscal[0];
     return YDORB_OK;
   };
 
-  double lambda = 0, ni = 2;
+  double lambda = 0, ni = 2, currentChi = 0;
   for (int it = 0; it < iterations && !R_.stopped(); it++) {
-    double currentChi;
-    if ((rc = computeChi2(R_.cur, &currentChi))) return rc;
+    // computeActiveErrors + activeRobustChi2 at the top of an iteration: after the first iteration the state is the trial
+    // that was just accepted, whose errors (c.err) and chi2 are already there — same kernel, same inputs, same bits.
+    if (it == 0 && (rc = computeChi2(R_.cur, &currentChi, false))) return rc;
     {  // buildSystem
       PhaseTimer t(R_, PH_BUILD);
       hipLaunchKernelGGL(k_build_points, dim3((nL + 127) / 128), dim3(128), 0, s, Ed, c.ptStart.as<int>(), nL, c.poses[R_.cur].as<double>(),
@@ -298,10 +302,8 @@ int optimize(Run& R_, int iterations, int stage) {
         if (multi) { if ((rc = allreduce(R_, c.scal.as<double>() + 2, 1, 0))) return rc; }
       }
       double tempChi;
-      if ((rc = computeChi2(nxt, &tempChi))) return rc;  // also brings back scal[2] and leaves err = errors of the trial state
+      if ((rc = computeChi2(nxt, &tempChi, true))) return rc;  // also brings back scal[2], the factorisation status, and leaves err = errors of the trial state
       const double scaleSum = hscal[2];
-      int hstatus[2];
-      HIPCHK(hipMemcpy(hstatus, c.status.p, sizeof(hstatus), hipMemcpyDeviceToHost));
       const bool ok2 = hstatus[0] == 0;
       if (!ok2) tempChi = std::numeric_limits<double>::max();
       rho = currentChi - tempChi;
@@ -397,6 +399,7 @@ int ydorb_ba_solve(const YdBaProblem* P, const YdBaOptions* optIn, YdBaResult* r
     c.device = O.device;
     HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     for (auto& e : c.ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipHostMalloc(&c.hPin, sizeof(double) * 16));
   }
   Run R_{&c, P, &O, res};
   R_.level.assign(E, 0);
