@@ -540,30 +540,61 @@ constexpr int NB = 32;
 constexpr int NBP = NB + 1;
 
 // LL^T of the lower part of D (LDS, [NB][NBP]) by ONE wave; returns false on a non-positive pivot.
-// Lane i (< 32) keeps row i in 32 registers (all loops fully unrolled, so every index is a compile-time constant); per pivot
-// step the scaled column goes through a 32-entry LDS vector that every lane reads back with independent (pipelined)
-// broadcast loads.  The first version updated the trailing block element-by-element in LDS: ~30 us per tile.
-__device__ __forceinline__ bool potrf_wave(R (*D)[NBP], R* col, R* rdiag, int lane) {
+// Lane i (< 32) keeps row i in 32 registers (all loops fully unrolled, so every index is a compile-time constant).  Per pivot
+// step the pivot is broadcast with v_readlane (constant lane -> scalar registers).  (History, CHOL_TIMING build: element-wise LDS
+// updates ~30 us per tile; register rows with an LDS column vector and two wave barriers per pivot 10 us; all-readlane 9.2 us.)
+__device__ __forceinline__ R bcast_lane(R v, int srcLane) {   // srcLane must be a compile-time constant after unrolling
+  const unsigned lo = __builtin_amdgcn_readlane((int)__double2loint(v), srcLane), hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
+  return __hiloint2double((int)hi, (int)lo);
+}
+__device__ __forceinline__ R rsqrt_nr(R d) {   // v_rsq_f64 seed + two Newton steps (relative error ~1e-16 for normal d > 0)
+  R y = __builtin_amdgcn_rsq(d);
+  const R h = 0.5 * d;
+  y = y * (1.5 - h * y * y);
+  y = y * (1.5 - h * y * y);
+  return y;
+}
+__device__ __forceinline__ bool potrf_wave(R (*D)[NBP], R (*Lp)[NB][4], R* rdiag, int lane) {
+  // Blocked by 4 columns: inside a block the pivots and the (at most 3) in-block multipliers go through v_readlane; the block's
+  // four finished columns then make ONE LDS round trip (row-major [row][4], double-buffered) and every later column takes its
+  // rank-4 update from two broadcast ds_read_b128 + 4 FMAs — 8 round trips instead of 32, and the 992 v_readlane of the
+  // all-readlane form (which made a single wave issue-bound: 9.2 us) shrink to 160.  Same operation order per element as the
+  // rank-1 form (k ascending).
   const int i = lane & 31;
   R a[NB];
 #pragma unroll
   for (int c = 0; c < NB; c++) a[c] = D[i][c];
   bool ok = true;
 #pragma unroll
-  for (int j = 0; j < NB; j++) {
-    const R d = __shfl(a[j], j, 64);   // pivot: element (j, j) lives in lane j
-    if (!(d > 0)) ok = false;
-    const R inv = rsqrt(d);                    // one reciprocal square root per pivot instead of a divide per row
-    const R lij = i == j ? d * inv : a[j] * inv;   // rows i < j hold stale values in a[j]; they are never used again
-    a[j] = lij;
-    if (lane < NB) col[i] = lij;
-    if (lane == j) rdiag[j] = inv;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+  for (int b = 0; b < NB / 4; b++) {
 #pragma unroll
-    for (int c = j + 1; c < NB; c++) a[c] -= lij * col[c];   // only c <= i matters; the rest is never read
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    for (int jj = 0; jj < 4; jj++) {
+      const int j = 4 * b + jj;
+      const R d = bcast_lane(a[j], j);           // pivot: element (j, j) lives in lane j
+      if (!(d > 0)) ok = false;
+      const R inv = rsqrt_nr(d);                 // one reciprocal square root per pivot instead of a divide per row
+      const R lij = a[j] * inv;                  // rows i < j hold stale values in a[j]; they are never used again
+      a[j] = lij;
+      if (lane == j) rdiag[j] = inv;
+#pragma unroll
+      for (int c = j + 1; c < 4 * b + 4; c++) a[c] -= lij * bcast_lane(lij, c);   // L(c, j) lives in lane c
+    }
+    if (b < NB / 4 - 1) {
+      R (*buf)[4] = Lp[b & 1];
+      if (lane < NB) {
+        *reinterpret_cast<double2*>(&buf[i][0]) = make_double2(a[4 * b], a[4 * b + 1]);
+        *reinterpret_cast<double2*>(&buf[i][2]) = make_double2(a[4 * b + 2], a[4 * b + 3]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 4 * b + 4; c < NB; c++) {
+        const double2 l01 = *reinterpret_cast<const double2*>(&buf[c][0]), l23 = *reinterpret_cast<const double2*>(&buf[c][2]);
+        R v = a[c];
+        v -= a[4 * b] * l01.x; v -= a[4 * b + 1] * l01.y; v -= a[4 * b + 2] * l23.x; v -= a[4 * b + 3] * l23.y;
+        a[c] = v;
+      }
+    }
   }
   if (lane < NB) {
 #pragma unroll
@@ -582,6 +613,12 @@ __device__ __forceinline__ int tri_index(int t, int* row) {  // t -> (row, col) 
   return t - r * (r + 1) / 2;
 }
 
+#ifdef CHOL_TIMING
+__device__ long long g_cholClk[2][32][12];
+#define CH_CLK(p) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 1)) g_cholClk[blockIdx.x][kb][p] = wall_clock64(); } while (0)
+#else
+#define CH_CLK(p) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void k_chol_step(R* __restrict__ S, R* __restrict__ diagL, R* __restrict__ diagInv, int n, int kb,
                                                    int* __restrict__ status, R* __restrict__ bvec, R* __restrict__ yv) {
   __shared__ R Ta[NB][NBP];   // this tile
@@ -589,35 +626,48 @@ __global__ __launch_bounds__(256) void k_chol_step(R* __restrict__ S, R* __restr
   __shared__ R La[NB][NBP];   // L(i, kb-1)
   __shared__ R Lb[NB][NBP];   // L(j, kb-1)
   __shared__ R Lk[NB][NBP];   // L(kb, kb-1)
-  __shared__ R colv[NB];
+  __shared__ __align__(16) R Lp[2][NB][4];   // potrf: the current 4-column block of L, double-buffered
   __shared__ R rdiag[NB];   // 1 / L_jj
   __shared__ int sOk;
+  CH_CLK(0);
   const int tid = threadIdx.x, tr = tid >> 3, tc4 = (tid & 7) * 4;
-  int ri;
-  const int cj = tri_index(blockIdx.x, &ri);
-  const int i = kb + ri, j = kb + cj;          // tile (i, j), i >= j >= kb
-  const bool panel = j == kb;
-  // The diagonal workgroup also carries the forward substitution L y = b along (b is touched by this workgroup only):
-  // b_r -= L(r, panel kb-1) y_{kb-1} for every remaining row, and after the panel is factored y_kb = L_kk^-1 b_kb.
-  if (i == kb && j == kb && kb > 0) {
+  if (blockIdx.x == (unsigned)((n / NB - kb) * (n / NB - kb + 1) / 2)) {
+    // Extra workgroup (launches kb >= 1): the forward substitution L y = b rides along, off the factorisation's critical path.
+    //   y_{kb-1} = Linv_{kb-1} b_{kb-1}   (block inverse stored by launch kb-1; b_{kb-1} already holds every earlier panel's update)
+    //   b_r -= L(r, panel kb-1) y_{kb-1}  for all remaining rows (panel kb-1 is final; this launch only touches tiles >= kb).
+    // The last block's y is computed by k_chol_solve.
     __shared__ R yprev[NB];
-    if (tid < NB) yprev[tid] = yv[(kb - 1) * NB + tid];
+    {
+      const int r = tid >> 3, part = tid & 7;   // 8 threads per row, 4 terms each
+      const R* inv = diagInv + (size_t)(kb - 1) * NB * NB + r * NB;
+      R p = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) p += inv[part * 4 + k] * bvec[(kb - 1) * NB + part * 4 + k];   // Linv is lower triangular (zeros above)
+      p += __shfl_xor(p, 1, 64); p += __shfl_xor(p, 2, 64); p += __shfl_xor(p, 4, 64);
+      if (part == 0) { yprev[r] = p; yv[(kb - 1) * NB + r] = p; }
+    }
     __syncthreads();
     for (int r = kb * NB + tid; r < n; r += 256) {
       const R* row = S + (size_t)r * n + (kb - 1) * NB;
       R sres = 0;
-#pragma unroll 8
+#pragma unroll
       for (int k = 0; k < NB; k++) sres += row[k] * yprev[k];
       bvec[r] -= sres;
     }
-    __syncthreads();
+    return;
   }
+  int ri;
+  const int cj = tri_index(blockIdx.x, &ri);
+  const int i = kb + ri, j = kb + cj;          // tile (i, j), i >= j >= kb
+  const bool panel = j == kb;
+  CH_CLK(1);
   R acc[4], accD[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     acc[c] = S[(size_t)(i * NB + tr) * n + j * NB + tc4 + c];
     if (panel) accD[c] = S[(size_t)(kb * NB + tr) * n + kb * NB + tc4 + c];
   }
+  CH_CLK(2);
   if (kb > 0) {
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -641,6 +691,7 @@ __global__ __launch_bounds__(256) void k_chol_step(R* __restrict__ S, R* __restr
       }
     }
   }
+  CH_CLK(3);
   if (!panel) {
 #pragma unroll
     for (int c = 0; c < 4; c++) S[(size_t)(i * NB + tr) * n + j * NB + tc4 + c] = acc[c];
@@ -649,9 +700,10 @@ __global__ __launch_bounds__(256) void k_chol_step(R* __restrict__ S, R* __restr
 #pragma unroll
   for (int c = 0; c < 4; c++) { Ta[tr][tc4 + c] = acc[c]; Dg[tr][tc4 + c] = accD[c]; }
   __syncthreads();
+  CH_CLK(4);
 #ifndef CHOL_SKIP_POTRF
   if (tid < 64) {
-    const bool ok = potrf_wave(Dg, colv, rdiag, tid);
+    const bool ok = potrf_wave(Dg, Lp, rdiag, tid);
     if (tid == 0) sOk = ok ? 1 : 0;
   }
 #else
@@ -659,6 +711,7 @@ __global__ __launch_bounds__(256) void k_chol_step(R* __restrict__ S, R* __restr
   if (tid < NB) rdiag[tid] = 1.0;
 #endif
   __syncthreads();
+  CH_CLK(5);
   if (!sOk) {
     if (tid == 0) atomicMax(status, 1);
     return;
@@ -681,6 +734,7 @@ __global__ __launch_bounds__(256) void k_chol_step(R* __restrict__ S, R* __restr
 #pragma unroll
     for (int r = 0; r < 16; r++) La[off + r][off + c] = z[r];   // La is free after the update: La = Linv
   }
+  CH_CLK(6);
   {
     const int r = tid >> 4, c = tid & 15;
     La[r][16 + c] = 0.0;   // upper-right block
@@ -702,17 +756,14 @@ __global__ __launch_bounds__(256) void k_chol_step(R* __restrict__ S, R* __restr
     La[16 + r][c] = m;
   }
   __syncthreads();
+  CH_CLK(7);
   if (i == kb) {
 #pragma unroll
     for (int c = 0; c < 4; c++) {
       diagL[(size_t)kb * NB * NB + tr * NB + tc4 + c] = tc4 + c <= tr ? Dg[tr][tc4 + c] : 0;
       diagInv[(size_t)kb * NB * NB + tr * NB + tc4 + c] = La[tr][tc4 + c];
     }
-    if (tid < NB) {
-      R sres = 0;
-      for (int k = 0; k <= tid; k++) sres += La[tid][k] * bvec[kb * NB + k];
-      yv[kb * NB + tid] = sres;
-    }
+    CH_CLK(8);
     return;
   }
   R xo[4] = {0, 0, 0, 0};
@@ -722,22 +773,31 @@ __global__ __launch_bounds__(256) void k_chol_step(R* __restrict__ S, R* __restr
 #pragma unroll
     for (int c = 0; c < 4; c++) xo[c] += t * La[tc4 + c][k];
   }
+  CH_CLK(9);
 #pragma unroll
   for (int c = 0; c < 4; c++) S[(size_t)(i * NB + tr) * n + kb * NB + tc4 + c] = xo[c];
+  CH_CLK(10);
 }
 
 // Backward substitution L^T x = y (y comes out of the factorisation launches), single workgroup, blocked by 32 with the
-// diagonal blocks applied through their inverses:  x_k = Linv_kk^T y_k ;  y_j -= L(k,j)^T x_k  (j < k).
-// The chain over the 19 blocks is serial, so each step is kept short: the block inverse (exactly 1024 numbers, one per
+// diagonal blocks applied through their inverses:  x_k = Linv_kk^T y_k ;  y_j -= L(k,j)^T x_k  (j < k).  It first finishes the
+// forward substitution (last block of y).  The chain over the 19 blocks is serial, so each step is kept short: the block inverse (exactly 1024 numbers, one per
 // thread) and the 32 L entries a thread needs for the update are fetched BEFORE the step's reduction (they do not depend on x),
 // and x_k is a 32-way shuffle reduction on all 1024 threads instead of a 32-term loop on 32 of them.
 __global__ __launch_bounds__(1024) void k_chol_solve(const R* __restrict__ L, const R* __restrict__ diagInv, int n, const R* __restrict__ yin,
-                                                     R* __restrict__ x) {
+                                                     const R* __restrict__ bvec, R* __restrict__ x) {
   extern __shared__ R y[];  // [n]
   __shared__ R inv[NB][NB + 1];
   __shared__ R yk[NB];
   const int tid = threadIdx.x, nb = n / NB;
-  for (int i = tid; i < n; i += 1024) y[i] = yin[i];
+  for (int i = tid; i < n - NB; i += 1024) y[i] = yin[i];
+  {  // forward substitution's last block: y_last = Linv_last b_last (thread (r, k) = (tid / 32, tid % 32); zeros above the diagonal)
+    const int r = tid >> 5, k = tid & 31;
+    R p = diagInv[(size_t)(nb - 1) * NB * NB + tid] * bvec[(nb - 1) * NB + k];
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) p += __shfl_xor(p, o, 64);
+    if (k == 0) y[(nb - 1) * NB + r] = p;
+  }
   for (int kb = nb - 1; kb >= 0; kb--) {
     const R invReg = diagInv[(size_t)kb * NB * NB + tid];          // element (r, c) = (tid / 32, tid % 32)
     R lrow[NB];

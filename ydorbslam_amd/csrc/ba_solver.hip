@@ -5,6 +5,7 @@
 // (core/optimization_algorithm_levenberg.cpp:57-173).  All arithmetic on the graph runs in ba_kernels.hip.h;
 // the host only sorts the edge list, keeps lambda / nu, and reads three scalars per trial.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <algorithm>
 #include <cmath>
@@ -87,6 +88,14 @@ int allreduce(Run& R_, void* d_buf, int64_t count, int op) {
   return YDORB_OK;
 }
 
+// YDORB_BA_TRACE=1: host wall-clock marks of the solve on stderr (where the time between device phases goes)
+static bool g_trace = getenv("YDORB_BA_TRACE") != nullptr;
+static std::chrono::steady_clock::time_point g_t0;
+static void trace(const char* what) {
+  if (!g_trace) return;
+  fprintf(stderr, "[ba %8.3f ms] %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_t0).count(), what);
+}
+
 struct PhaseTimer {
   Run& r; int ph; hipEvent_t a, b; bool on;
   PhaseTimer(Run& r_, int ph_) : r(r_), ph(ph_), a(r_.c->ev[2 * ph_]), b(r_.c->ev[2 * ph_ + 1]), on(true) {
@@ -110,6 +119,7 @@ int optimize(Run& R_, int iterations, int stage) {
   const YdBaOptions& O = *R_.O;
   hipStream_t s = c.stream;
   const int K = P.n_poses, NP = P.n_points, E = P.n_edges;
+  trace("optimize: begin");
   std::vector<int> act;
   for (int e = 0; e < E; e++) if (!R_.level[e]) act.push_back(e);
   if (act.empty()) return YDORB_OK;
@@ -183,12 +193,14 @@ int optimize(Run& R_, int iterations, int stage) {
   double* dbp = dHpp + (size_t)36 * nPf;
   double* dS = c.S.as<double>();
   double* dbs = dS + (size_t)n * n;
+  trace("optimize: host ordering done");
 #define UP(buf, vec, T) HIPCHK(hipMemcpyAsync(c.buf.p, vec.data(), sizeof(T) * vec.size(), hipMemcpyHostToDevice, s))
   UP(ePose, hPose, int); UP(ePidx, hPidx, int); UP(ePt, hPt, int); UP(eLm, hLm, int); UP(eMeas, hMeas, double); UP(eInfo, hInfo, double);
   UP(eRobust, hRobust, uint8_t); UP(ptStart, hPtStart, int); UP(poseStart, hPoseStart, int); UP(ptOf, ptOf, int);
   if (!hPoseEdges.empty()) UP(poseEdges, hPoseEdges, int);
   if (nPf) UP(poseOf, poseOf, int);
 #undef UP
+  trace("optimize: uploads enqueued");
   EdgeSoA Ed{c.ePose.as<int>(), c.ePidx.as<int>(), c.ePt.as<int>(), c.eMeas.as<double>(), c.eInfo.as<double>(), c.eRobust.as<uint8_t>(), Ea};
   const double dM = O.delta_mono, dSt = O.delta_stereo;
   // pose-pair buckets of the Schur complement (structure is fixed for this optimize() call)
@@ -230,6 +242,7 @@ int optimize(Run& R_, int iterations, int stage) {
     return YDORB_OK;
   };
 
+  trace("optimize: pair buckets enqueued");
   double lambda = 0, ni = 2, currentChi = 0;
   for (int it = 0; it < iterations && !R_.stopped(); it++) {
     // computeActiveErrors + activeRobustChi2 at the top of an iteration: after the first iteration the state is the trial
@@ -276,9 +289,9 @@ int optimize(Run& R_, int iterations, int stage) {
       {
         PhaseTimer t(R_, PH_SOLVE);
         for (int kb = 0; kb < nb; kb++)
-          hipLaunchKernelGGL(k_chol_step, dim3((nb - kb) * (nb - kb + 1) / 2), dim3(256), 0, s, dS, c.diagL.as<double>(), c.diagInv.as<double>(), n, kb,
+          hipLaunchKernelGGL(k_chol_step, dim3((nb - kb) * (nb - kb + 1) / 2 + (kb > 0)), dim3(256), 0, s, dS, c.diagL.as<double>(), c.diagInv.as<double>(), n, kb,
                              c.status.as<int>(), dbs, c.yv.as<double>());
-        hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), sizeof(double) * n, s, dS, c.diagInv.as<double>(), n, c.yv.as<double>(), c.xp.as<double>());
+        hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), sizeof(double) * n, s, dS, c.diagInv.as<double>(), n, c.yv.as<double>(), dbs, c.xp.as<double>());
         hipLaunchKernelGGL(k_backsub, dim3((nL + 127) / 128), dim3(128), 0, s, Ed, c.ptStart.as<int>(), nL, c.Hpl.as<double>(), c.Dinv.as<double>(),
                            c.bl.as<double>(), c.xp.as<double>(), c.xl.as<double>());
         t.stop();
@@ -332,6 +345,7 @@ int optimize(Run& R_, int iterations, int stage) {
     res->n_iterations++;
     if (qmax == O.max_trials || rho == 0 || !std::isfinite(lambda)) break;  // SolverResult::Terminate
   }
+  trace("optimize: LM loop done");
   // errors as g2o leaves them in the edges: those of the last evaluated state (possibly a rejected trial)
   std::vector<double> herr((size_t)3 * Ea);
   HIPCHK(hipMemcpyAsync(herr.data(), c.err.p, sizeof(double) * 3 * Ea, hipMemcpyDeviceToHost, s));
@@ -339,6 +353,7 @@ int optimize(Run& R_, int iterations, int stage) {
   for (int i = 0; i < Ea; i++)
     for (int d = 0; d < 3; d++) R_.err[(size_t)3 * act[i] + d] = herr[(size_t)3 * i + d];
   for (int ph = 0; ph < PH_COUNT; ph++) PhaseTimer::collect(R_, ph);
+  trace("optimize: errors read back");
   return YDORB_OK;
 }
 
@@ -393,6 +408,8 @@ int ydorb_ba_solve(const YdBaProblem* P, const YdBaOptions* optIn, YdBaResult* r
   if (E == 0 || K == 0 || NP == 0) return YDORB_OK;
   int rc = require_device(O.device);
   if (rc) return rc;
+  g_t0 = std::chrono::steady_clock::now();
+  trace("solve: begin");
   std::lock_guard<std::mutex> lock(g_mu);
   Ctx& c = g_ctx[O.device];
   if (!c.stream) {
@@ -422,6 +439,7 @@ int ydorb_ba_solve(const YdBaProblem* P, const YdBaOptions* optIn, YdBaResult* r
   HIPCHK(hipMemcpy(c.pts[0].p, P->points, sizeof(double) * 3 * NP, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c.ePoseAll.p, P->edge_pose, sizeof(int) * E, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c.ePtAll.p, P->edge_point, sizeof(int) * E, hipMemcpyHostToDevice));
+  trace("solve: state uploaded");
   hipEvent_t t0 = c.ev[2 * PH_COUNT], t1 = c.ev[2 * PH_COUNT + 1];
   HIPCHK(hipEventRecord(t0, c.stream));
 
@@ -433,6 +451,7 @@ int ydorb_ba_solve(const YdBaProblem* P, const YdBaOptions* optIn, YdBaResult* r
   std::vector<double> depth;
   if (!R_.stopped()) {  // optimizer.cpp:290-314
     if ((rc = edgeDepths(R_, depth))) return rc;
+    trace("solve: depths read");
     for (int e = 0; e < E; e++) {
       const double th = P->edge_meas[3 * e + 2] >= 0 ? O.chi2_stereo : O.chi2_mono;
       if (chi2Of(e) > th || !(depth[e] > 0.0)) R_.level[e] = 1;
@@ -452,6 +471,7 @@ int ydorb_ba_solve(const YdBaProblem* P, const YdBaOptions* optIn, YdBaResult* r
   HIPCHK(hipMemcpy(P->poses, c.poses[R_.cur].p, sizeof(double) * 7 * K, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(P->points, c.pts[R_.cur].p, sizeof(double) * 3 * NP, hipMemcpyDeviceToHost));
   (void)hipEventElapsedTime(&res->ms_total, t0, t1);
+  trace("solve: results read back");
   res->ms_errors = (float)R_.phaseMs[PH_ERR]; res->ms_build = (float)R_.phaseMs[PH_BUILD]; res->ms_schur = (float)R_.phaseMs[PH_SCHUR];
   res->ms_solve = (float)R_.phaseMs[PH_SOLVE]; res->ms_update = (float)R_.phaseMs[PH_UPDATE];
   if (R_.stopped()) res->stopped = 1;
@@ -480,8 +500,8 @@ int ydorb_ba_dense_solve(int32_t device, const double* A, int32_t n0, const doub
   HIPCHK(hipMemcpy(dA, hA.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(db, hb.data(), sizeof(double) * n, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(dst, 0, sizeof(int) * 2));
-  for (int kb = 0; kb < nb; kb++) hipLaunchKernelGGL(k_chol_step, dim3((nb - kb) * (nb - kb + 1) / 2), dim3(256), 0, 0, dA, dD, dI, n, kb, dst, db, dy);
-  hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), sizeof(double) * n, 0, dA, dI, n, dy, dx);
+  for (int kb = 0; kb < nb; kb++) hipLaunchKernelGGL(k_chol_step, dim3((nb - kb) * (nb - kb + 1) / 2 + (kb > 0)), dim3(256), 0, 0, dA, dD, dI, n, kb, dst, db, dy);
+  hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), sizeof(double) * n, 0, dA, dI, n, dy, db, dx);
   HIPCHK(hipGetLastError());
   std::vector<double> hx(n);
   int hst[2];
@@ -489,6 +509,20 @@ int ydorb_ba_dense_solve(int32_t device, const double* A, int32_t n0, const doub
   HIPCHK(hipMemcpy(hst, dst, sizeof(hst), hipMemcpyDeviceToHost));
   *ok = hst[0] == 0;
   for (int i = 0; i < n0; i++) x[i] = hx[i];
+#ifdef CHOL_TIMING
+  {
+    static long long clk[2][32][12];
+    HIPCHK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_cholClk), sizeof(clk)));
+    for (int w = 0; w < 2; w++)
+      for (int kb = 0; kb < nb && kb < 32; kb += 6) {
+        fprintf(stderr, "chol wg%d kb=%d:", w, kb);
+        for (int p2 = 1; p2 < 11; p2++) fprintf(stderr, " %.2f", clk[w][kb][p2] ? (clk[w][kb][p2] - clk[w][kb][0]) / 100.0 : -1.0);
+        fprintf(stderr, " us\n");
+      }
+    for (int kb = 1; kb < nb && kb < 32; kb++) fprintf(stderr, "%.1f ", (clk[0][kb][0] - clk[0][kb - 1][0]) / 100.0);
+    fprintf(stderr, "us between step starts\n");
+  }
+#endif
   (void)hipFree(dA); (void)hipFree(dD); (void)hipFree(dI); (void)hipFree(db); (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dst);
   return YDORB_OK;
 }
