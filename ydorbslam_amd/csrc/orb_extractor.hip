@@ -34,6 +34,7 @@ struct HostPlan {
   // quad-tree launch geometry per level: node table for 4*quota nodes, LDS-resident candidates up to candCap (HBM beyond)
   struct QtLevel { int nodeCap, candCap; size_t lds; int flatItems; size_t flatLds; } qt[kMaxLevels]{};
   size_t qtLdsMax = 0;
+  size_t qtPassLds = 0;   // the all-levels hand-over launch: largest node table + cell bases, candidates in HBM
   std::vector<int> tabInt;      // xofs|yofs per level
   std::vector<short> tabShort;  // alpha|beta per level
   struct TabOff { int xofs, yofs, alpha, beta; } tab[kMaxLevels]{};
@@ -235,6 +236,7 @@ int buildPlan(ydorb_extractor* e, int w, int h, HostPlan& P) {
       return YDORB_ERR_UNSUPPORTED;
     }
     P.qtLdsMax = std::max(P.qtLdsMax, Q.lds);
+    P.qtPassLds = std::max(P.qtPassLds, (size_t)Q.nodeCap * 48 + (size_t)(L.nCells + 1) * 4);
     // flat kernel: 512*items candidate slots.  First guess from the densities above (L0 1/45 .. L7 1/20 of the band); enqueue()
     // re-sizes it from the candidate counts the device actually saw.  A unit with more candidates goes to the pass kernel.
     Q.flatItems = flatItemsFor((long)((double)band / (45.0 - 3.5 * l)) + 64);
@@ -264,6 +266,7 @@ int ensurePlan(ydorb_extractor* e, int w, int h, int nFrames) {
   HIPCHK(hipMalloc(&e->d_qtCand, sizeof(uint32_t) * 2 * P.qtFrameStride * B));
   HIPCHK(hipMalloc(&e->d_qtNode, sizeof(uint16_t) * 2 * P.qtFrameStride * B));
   HIPCHK(hipMalloc(&e->d_needPass, (size_t)kMaxLevels * B));
+  HIPCHK(hipMemsetAsync(e->d_needPass, 0, (size_t)kMaxLevels * B, e->stream));
 
   HIPCHK(hipMalloc(&e->d_lvlKp, sizeof(uint32_t) * (size_t)D.sumQuota * B));
   HIPCHK(hipMalloc(&e->d_lvlAngle, sizeof(float) * (size_t)D.sumQuota * B));
@@ -289,8 +292,8 @@ int ensurePlan(ydorb_extractor* e, int w, int h, int nFrames) {
   if (!P.tabShort.empty()) HIPCHK(hipMemcpyAsync(e->d_tabShort, P.tabShort.data(), sizeof(short) * P.tabShort.size(), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipMemsetAsync(e->d_status, 0, sizeof(int), e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
-  if (P.qtLdsMax > 48 * 1024)
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.qtLdsMax));
+  if (std::max(P.qtLdsMax, P.qtPassLds) > 48 * 1024)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(P.qtLdsMax, P.qtPassLds)));
   {
     size_t ldsFlat = 0;   // any level may later be re-sized up to 16 items (retuneQuadtree)
     for (int l = 0; l < D.nLevels; l++)
@@ -353,6 +356,7 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   HIPCHK(hipEventRecord(e->evFork, s));
   hipLaunchKernelGGL(k_blur, dim3((D.blurTileBegin[D.nLevels] + 7) / 8 * 8, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
                      P.blurFrameStride, D);
+  bool anyFlat = false;
   for (int l = 0; l < D.nLevels; l++) {
     HIPCHK(hipStreamWaitEvent(e->qtStream[l], e->evFork, 0));
     const HostPlan::QtLevel& Q = P.qt[l];
@@ -371,13 +375,20 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
       }
 #undef YD_QT_FLAT
     }
-    // pass algorithm: every unit when the flat kernel is off, otherwise only the units it flagged (the others exit at once)
-    hipLaunchKernelGGL(k_quadtree, dim3(1, nFrames), dim3(kQtThreads), Q.lds, e->qtStream[l], D, e->d_cellCount, e->d_cellCand,
-                       e->d_qtCand, e->d_qtNode, P.qtFrameStride, Q.nodeCap, Q.candCap, l, e->d_lvlKp, e->d_lvlCount, e->d_status, needPass);
+    // pass algorithm on this level's stream only when the flat kernel is off for the level; otherwise the units the flat kernel
+    // hands over (rare) are picked up by ONE launch over all levels after the join (below)
+    if (!needPass)
+      hipLaunchKernelGGL(k_quadtree, dim3(1, nFrames), dim3(kQtThreads), Q.lds, e->qtStream[l], D, e->d_cellCount, e->d_cellCand,
+                         e->d_qtCand, e->d_qtNode, P.qtFrameStride, Q.nodeCap, Q.candCap, l, e->d_lvlKp, e->d_lvlCount, e->d_status, needPass);
+    else
+      anyFlat = true;
     HIPCHK(hipEventRecord(e->evJoin[l], e->qtStream[l]));
   }
   if (prof) HIPCHK(hipEventRecord(e->ev[3], s));   // end of the blur; the quad-tree stage is the interval up to the join below
   for (int l = 0; l < D.nLevels; l++) HIPCHK(hipStreamWaitEvent(s, e->evJoin[l], 0));
+  if (anyFlat)   // hand-over units of every level: node table in LDS, candidates in HBM scratch (candCap 0); others exit at once
+    hipLaunchKernelGGL(k_quadtree, dim3(D.nLevels, nFrames), dim3(kQtThreads), P.qtPassLds, s, D, e->d_cellCount, e->d_cellCand, e->d_qtCand,
+                       e->d_qtNode, P.qtFrameStride, 0, 0, 0, e->d_lvlKp, e->d_lvlCount, e->d_status, e->d_needPass);
   if (prof) HIPCHK(hipEventRecord(e->ev[4], s));
   hipLaunchKernelGGL(k_orient_describe, dim3(((D.sumQuota + 3) / 4 + 7) / 8 * 8, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
                      P.blurFrameStride, D, e->d_lvlKp, e->d_lvlCount, d_kps, d_desc, cap, d_nOut, e->d_lvlAngle);
