@@ -69,76 +69,72 @@ typedef unsigned long long __attribute__((aligned(1))) u64_unaligned;
 #define PYR_ROWS 4
 #endif
 constexpr int kPyrRows = PYR_ROWS;
-// Both kernels issue every load of a thread's kPyrRows rows before the first use (rows past the bottom are clamped and their
-// store masked), so a thread keeps 2*kPyrRows independent loads in flight instead of one row at a time.
+// The level kernels write INTERIOR rows only, one dword per thread and row, every lane on the same (fast) path: a dword that
+// straddles the left/right edge is computed from clamped columns and its pad bytes are rewritten by k_pyr_borders afterwards.
+// (Computing the reflect-101 pad inside these kernels sent two thirds of the waves through a byte-gather slow path for the sake
+// of a few lanes.)  All loads of a thread's kPyrRows rows are issued before the first use.
 __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ img, int stride, size_t frameStride,
                                                     uint8_t* __restrict__ pyr, size_t pyrFrameStride, LevelDev L) {
   const int wx = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int yb = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * kPyrRows;
-  if (wx * 4 >= L.pitch) return;
+  const int yb = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * kPyrRows;   // interior row
+  const int x0 = wx * 4 - kPad;                              // level column of this dword's first byte
+  if (x0 + 3 < 0 || x0 >= L.w) return;                       // pure pad dword: k_pyr_borders
   const uint8_t* src = img + (size_t)blockIdx.z * frameStride;
-  uint8_t* dst = pyr + (size_t)blockIdx.z * pyrFrameStride + L.padOff + wx * 4;
-  const int x0 = wx * 4 - kPad, hp = L.h + 2 * kPad;
-  const bool interior = x0 >= 0 && x0 + 3 < L.w;
-  int rx[4];
-#pragma unroll
-  for (int b = 0; b < 4; b++) rx[b] = x0 + b < L.w + kPad ? reflect101(x0 + b, L.w) : -1;
+  uint8_t* dst = pyr + (size_t)blockIdx.z * pyrFrameStride + L.padOff + (size_t)kPad * L.pitch + wx * 4;
+  // 4 source bytes from a clamped address; an edge dword is shifted so that its interior bytes land where they belong
+  const int xa = L.w >= 4 ? min(max(x0, 0), L.w - 4) : 0, sh = 8 * (x0 - xa);
   uint32_t v[kPyrRows];
 #pragma unroll
   for (int r = 0; r < kPyrRows; r++) {
-    const uint8_t* row = src + (size_t)reflect101(min(yb + r, hp - 1) - kPad, L.h) * stride;
-    v[r] = 0;
-    if (interior) {
-      v[r] = *reinterpret_cast<const u32_unaligned*>(row + x0);
+    const uint8_t* row = src + (size_t)min(yb + r, L.h - 1) * stride;
+    if (L.w >= 4) {
+      v[r] = *reinterpret_cast<const u32_unaligned*>(row + xa);
     } else {
-#pragma unroll
-      for (int b = 0; b < 4; b++)
-        if (rx[b] >= 0) v[r] |= (uint32_t)row[rx[b]] << (8 * b);
+      v[r] = 0;
+      for (int b = 0; b < L.w; b++) v[r] |= (uint32_t)row[b] << (8 * b);
     }
+    v[r] = sh < 0 ? v[r] << (-sh) : v[r] >> sh;
   }
 #pragma unroll
   for (int r = 0; r < kPyrRows; r++)
-    if (yb + r < hp) *reinterpret_cast<uint32_t*>(dst + (size_t)(yb + r) * L.pitch) = v[r];
+    if (yb + r < L.h) *reinterpret_cast<uint32_t*>(dst + (size_t)(yb + r) * L.pitch) = v[r];
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pyramid level l>=1: cv::resize(level l-1, INTER_LINEAR) + reflect-101 border (orbExtractor.cpp:614-615).
-// Border pixels are recomputed from the reflected interior coordinate instead of re-read, so the level
-// is written exactly once.  Coefficient tables (11-bit fixed point) are built on the host.
-// Interior fast path: the 4 outputs of a thread read source columns sx[0] .. sx[3]+1, at most 8 consecutive bytes for
-// scale factors <= 2, fetched as one unaligned 8-byte load per source row.  The row tables are indexed by a wave-uniform
-// row number (scalar loads); the source column is computed in the kernel, only the weights come from the column table.
+// Pyramid level l>=1: cv::resize(level l-1, INTER_LINEAR) (orbExtractor.cpp:614-615), interior only.
+// Coefficient tables (11-bit fixed point) are built on the host.  The 4 outputs of a thread read source columns
+// sx[0] .. sx[3]+1, at most 8 consecutive bytes for scale factors <= 2, fetched as one unaligned 8-byte load per source row.
+// The row tables are indexed by a wave-uniform row number (scalar loads); the source column is computed in the kernel, only
+// the weights come from the column table.  A tap that falls outside the source interior has weight 0, so the (not yet
+// written) pad bytes of the source level never reach a result.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, size_t pyrFrameStride, LevelDev Lp, LevelDev L,
                                                     double scaleX, const short* __restrict__ alpha,
                                                     const int* __restrict__ yofs, const short* __restrict__ beta) {
   const int wx = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int yb = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * kPyrRows;
-  if (wx * 4 >= L.pitch) return;
+  const int yb = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * kPyrRows;   // interior row
+  const int x0 = wx * 4 - kPad;
+  if (x0 + 3 < 0 || x0 >= L.w) return;                       // pure pad dword: k_pyr_borders
   uint8_t* frame = pyr + (size_t)blockIdx.z * pyrFrameStride;
   const uint8_t* S = frame + Lp.padOff + (size_t)kPad * Lp.pitch + kPad;  // ROI origin of the source level
-  uint8_t* dst = frame + L.padOff + wx * 4;
-  const int x0 = wx * 4 - kPad, hp = L.h + 2 * kPad;
+  uint8_t* dst = frame + L.padOff + (size_t)kPad * L.pitch + wx * 4;
   int sx[4], sx1[4], a0[4], a1[4];
 #pragma unroll
   for (int b = 0; b < 4; b++) {
-    sx[b] = -1; sx1[b] = 0; a0[b] = 0; a1[b] = 0;
-    if (x0 + b < L.w + kPad) {
-      const int dx = reflect101(x0 + b, L.w);
-      // source column computed here (the same IEEE sequence as the host's coefficient table): the pixel loads then wait for
-      // no table load, only the weights do
-      const float fx = (float)__dsub_rn(__dmul_rn((double)dx + 0.5, scaleX), 0.5);
-      sx[b] = min(max((int)floorf(fx), 0), Lp.w - 1);
-      a0[b] = alpha[2 * dx]; a1[b] = alpha[2 * dx + 1];
-      sx1[b] = min(sx[b] + 1, Lp.w - 1);   // a1 == 0 whenever sx+1 is outside
-    }
+    const int dx = min(max(x0 + b, 0), L.w - 1);             // edge dwords: pad bytes repeat the edge column (rewritten later)
+    // source column computed here (the same IEEE sequence as the host's coefficient table): the pixel loads then wait for
+    // no table load, only the weights do
+    const float fx = (float)__dsub_rn(__dmul_rn((double)dx + 0.5, scaleX), 0.5);
+    sx[b] = min(max((int)floorf(fx), 0), Lp.w - 1);
+    a0[b] = alpha[2 * dx]; a1[b] = alpha[2 * dx + 1];
+    sx1[b] = min(sx[b] + 1, Lp.w - 1);   // a1 == 0 whenever sx+1 is outside
   }
-  const bool fast = x0 >= 0 && x0 + 3 < L.w && sx[3] - sx[0] <= 6 && sx[0] + 7 < Lp.w + kPad;
+  const bool fast = sx[3] - sx[0] <= 6;   // always, for scale factors <= 2
   const uint8_t *r0p[kPyrRows], *r1p[kPyrRows];
   int b0[kPyrRows], b1[kPyrRows];
 #pragma unroll
   for (int r = 0; r < kPyrRows; r++) {
-    const int dy = reflect101(min(yb + r, hp - 1) - kPad, L.h);
+    const int dy = min(yb + r, L.h - 1);
     const int sy = yofs[dy];
     b0[r] = beta[2 * dy]; b1[r] = beta[2 * dy + 1];
     r0p[r] = S + (size_t)min(max(sy, 0), Lp.h - 1) * Lp.pitch;
@@ -147,7 +143,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, s
   uint32_t v[kPyrRows];
   if (fast) {
     // Both taps of an output as one u16 pair picked out of the 8 loaded bytes (v_perm_b32, selector fixed per column) and
-    // weighted by (alpha0, alpha1) in one v_dot2_u32_u16: the kernel is VALU-bound and this is a third of the scalar form.
+    // weighted by (alpha0, alpha1) in one v_dot2_u32_u16.
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     uint32_t sel[4];
     u16x2 ab[4];
@@ -176,23 +172,62 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, s
         v[r] |= (uint32_t)(o & 0xFF) << (8 * b);
       }
     }
-  } else {
+  } else {   // scale factor > 2: byte taps
 #pragma unroll
     for (int r = 0; r < kPyrRows; r++) {
       v[r] = 0;
 #pragma unroll
-      for (int b = 0; b < 4; b++)
-        if (sx[b] >= 0) {
-          const int h0 = r0p[r][sx[b]] * a0[b] + r0p[r][sx1[b]] * a1[b];
-          const int h1 = r1p[r][sx[b]] * a0[b] + r1p[r][sx1[b]] * a1[b];
-          const int o = (((b0[r] * (h0 >> 4)) >> 16) + ((b1[r] * (h1 >> 4)) >> 16) + 2) >> 2;
-          v[r] |= (uint32_t)(o & 0xFF) << (8 * b);
-        }
+      for (int b = 0; b < 4; b++) {
+        const int h0 = r0p[r][sx[b]] * a0[b] + r0p[r][sx1[b]] * a1[b];
+        const int h1 = r1p[r][sx[b]] * a0[b] + r1p[r][sx1[b]] * a1[b];
+        const int o = (((b0[r] * (h0 >> 4)) >> 16) + ((b1[r] * (h1 >> 4)) >> 16) + 2) >> 2;
+        v[r] |= (uint32_t)(o & 0xFF) << (8 * b);
+      }
     }
   }
 #pragma unroll
   for (int r = 0; r < kPyrRows; r++)
-    if (yb + r < hp) *reinterpret_cast<uint32_t*>(dst + (size_t)(yb + r) * L.pitch) = v[r];
+    if (yb + r < L.h) *reinterpret_cast<uint32_t*>(dst + (size_t)(yb + r) * L.pitch) = v[r];
+}
+
+// ------------------------------------------------------------------------------------------------
+// copyMakeBorder(BORDER_REFLECT_101) of every level (orbExtractor.cpp:612-621), one launch for all levels and frames after the
+// level kernels: a thread owns one dword of the padded level that holds at least one pad byte — the 19 full rows above and
+// below, and up to 6 dwords at either end of an interior row — keeps the interior bytes it finds there and fills each pad byte
+// from the reflected interior pixel.  Bytes beyond w + 38 (pitch slack) are zeroed.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyr_borders(uint8_t* __restrict__ pyr, size_t pyrFrameStride, PlanDev P) {
+  const int level = blockIdx.y, f = blockIdx.z;
+  const LevelDev L = P.lv[level];
+  const int wd = L.pitch >> 2, rightStart = (kPad + L.w) >> 2;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  int y, xd;
+  if (t < 2 * kPad * wd) {
+    const int r = t / wd;
+    xd = t - r * wd;
+    y = r < kPad ? r : L.h + r;                  // rows 0..18 and h+19 .. h+37
+  } else {
+    const int u = t - 2 * kPad * wd, row = u / 12, j = u - row * 12;
+    if (row >= L.h) return;
+    y = kPad + row;
+    xd = j < 6 ? j : rightStart + j - 6;
+    if (xd >= wd || (j < 6 && (4 * xd >= kPad || xd >= rightStart))) return;   // left: dwords 0..4; tiny levels: the right end wins
+  }
+  uint8_t* base = pyr + (size_t)f * pyrFrameStride + L.padOff;
+  uint32_t* dw = reinterpret_cast<uint32_t*>(base + (size_t)y * L.pitch) + xd;
+  const int Y = y - kPad, ry = reflect101(Y, L.h);
+  const bool rowInside = Y >= 0 && Y < L.h;
+  const uint32_t old = rowInside ? *dw : 0u;
+  const uint8_t* srow = base + (size_t)(ry + kPad) * L.pitch + kPad;
+  uint32_t v = 0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const int X = 4 * xd + b - kPad;
+    uint32_t px = 0;
+    if (X < L.w + kPad) px = (rowInside && X >= 0 && X < L.w) ? (old >> (8 * b)) & 255u : srow[reflect101(X, L.w)];
+    v |= px << (8 * b);
+  }
+  *dw = v;
 }
 
 // ------------------------------------------------------------------------------------------------

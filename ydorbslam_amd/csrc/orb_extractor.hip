@@ -260,6 +260,7 @@ int ensurePlan(ydorb_extractor* e, int w, int h, int nFrames) {
   const PlanDev& D = P.dev;
   HIPCHK(hipMalloc(&e->d_img, e->imgBytes * B));
   HIPCHK(hipMalloc(&e->d_pyr, P.pyrFrameStride * B));
+  HIPCHK(hipMemsetAsync(e->d_pyr, 0, P.pyrFrameStride * B, e->stream));   // pitch slack beyond w + 38 is never written: keep it zero
   HIPCHK(hipMalloc(&e->d_blur, P.blurFrameStride * B));
   HIPCHK(hipMalloc(&e->d_cellCount, sizeof(uint32_t) * D.nCellsTotal * B));
   HIPCHK(hipMalloc(&e->d_cellCand, sizeof(uint32_t) * (size_t)D.nCellsTotal * D.cellCap * B));
@@ -336,15 +337,19 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   if (prof) HIPCHK(hipEventRecord(e->ev[0], s));
   {
     const LevelDev& L0 = D.lv[0];
-    dim3 g((L0.pitch / 4 + 63) / 64, (L0.h + 2 * kPad + 4 * kPyrRows - 1) / (4 * kPyrRows), nFrames);
+    dim3 g((L0.pitch / 4 + 63) / 64, (L0.h + 4 * kPyrRows - 1) / (4 * kPyrRows), nFrames);
     hipLaunchKernelGGL(k_pyr_level0, g, dim3(256), 0, s, d_img, stride, frameStride, e->d_pyr, P.pyrFrameStride, L0);
-    for (int l = 1; l < D.nLevels; l++) {
+    int maxBorder = 0;
+    for (int l = 0; l < D.nLevels; l++) {
       const LevelDev& L = D.lv[l];
-      dim3 gl((L.pitch / 4 + 63) / 64, (L.h + 2 * kPad + 4 * kPyrRows - 1) / (4 * kPyrRows), nFrames);
+      maxBorder = std::max(maxBorder, 2 * kPad * (L.pitch / 4) + 12 * L.h);
+      if (l == 0) continue;
+      dim3 gl((L.pitch / 4 + 63) / 64, (L.h + 4 * kPyrRows - 1) / (4 * kPyrRows), nFrames);
       hipLaunchKernelGGL(k_pyr_resize, gl, dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, D.lv[l - 1], L,
                          1. / ((double)L.w / D.lv[l - 1].w), e->d_tabShort + P.tab[l].alpha, e->d_tabInt + P.tab[l].yofs,
                          e->d_tabShort + P.tab[l].beta);
     }
+    hipLaunchKernelGGL(k_pyr_borders, dim3((maxBorder + 255) / 256, D.nLevels, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, D);
   }
   if (prof) HIPCHK(hipEventRecord(e->ev[1], s));
   if (D.nCellsTotal > 0)
