@@ -43,11 +43,13 @@ struct PlanDev {
   int nLevels, nCellsTotal, cellCap, sumQuota;
   int maxX[16];             // m_v_maxXcords[0..15]
   int blurTileBegin[kMaxLevels + 1];   // first 64x32 blur tile of each level in the flat per-frame tile list
+  int borderBegin[kMaxLevels + 1];     // first border thread of each level in k_pyr_borders' flat per-frame list (multiples of 256)
   LevelDev lv[kMaxLevels];
 };
 constexpr int kBlurTW = 64, kBlurTH = 32;
 struct CellDev {            // FAST sub-image [x0,x1) x [y0,y1) in level coordinates (orbExtractor.cpp:562-581)
-  short level, x0, y0, x1, y1, pad0, pad1, pad2;
+  short level, x0, y0, x1, y1, pad0;
+  int srcOff;               // byte offset of the sub-image's first pixel inside a frame's pyramid block (host-computed)
 };
 
 __device__ __forceinline__ int reflect101(int i, int n) {
@@ -197,10 +199,14 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, s
 // from the reflected interior pixel.  Bytes beyond w + 38 (pitch slack) are zeroed.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pyr_borders(uint8_t* __restrict__ pyr, size_t pyrFrameStride, PlanDev P) {
-  const int level = blockIdx.y, f = blockIdx.z;
+  const int f = blockIdx.y;
+  int t = blockIdx.x * 256 + threadIdx.x, level = 0;
+#pragma unroll
+  for (int l = 1; l < kMaxLevels; l++)
+    if (l < P.nLevels && (int)(blockIdx.x * 256) >= P.borderBegin[l]) level = l;   // level starts are workgroup-aligned
+  t -= P.borderBegin[level];
   const LevelDev L = P.lv[level];
   const int wd = L.pitch >> 2, rightStart = (kPad + L.w) >> 2;
-  const int t = blockIdx.x * 256 + threadIdx.x;
   int y, xd;
   if (t < 2 * kPad * wd) {
     const int r = t / wd;
@@ -301,14 +307,13 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     if (threadIdx.x == 0) cellCount[slot] = 0;
     return;
   }
-  const uint8_t* roi = pyr + (size_t)f * pyrFrameStride + L.padOff + (size_t)kPad * L.pitch + kPad;
-  {  // tile load: (unaligned) dwords, 18 per row cover up to 72 px (reads past tw stay inside the level's 19-px padding)
-    const int wpr = (tw + 3) >> 2;
-    const float rw = 1.0f / (float)wpr;
-    for (int i = threadIdx.x; i < wpr * th; i += 256) {
-      const int ty = (int)(((float)i + 0.5f) * rw), wd = i - ty * wpr;
-      *reinterpret_cast<uint32_t*>(&tile[ty * kTileMax + 4 * wd]) =
-          *reinterpret_cast<const u32_unaligned*>(roi + (size_t)(c.y0 + ty) * L.pitch + c.x0 + 4 * wd);
+  {  // tile load: (unaligned) dwords, up to 18 per row (reads past tw stay inside the level's 19-px padding); thread = (row mod 16,
+     // dword column): no index arithmetic beyond one multiply-add per pass
+    const uint8_t* sub = pyr + (size_t)f * pyrFrameStride + c.srcOff;
+    const int wpr = (tw + 3) >> 2, ty0 = threadIdx.x >> 4, wd = threadIdx.x & 15;
+    for (int ty = ty0; ty < th; ty += 16) {
+      if (wd < wpr) *reinterpret_cast<uint32_t*>(&tile[ty * kTileMax + 4 * wd]) = *reinterpret_cast<const u32_unaligned*>(sub + ty * L.pitch + 4 * wd);
+      if (wd + 16 < wpr) *reinterpret_cast<uint32_t*>(&tile[ty * kTileMax + 4 * wd + 64]) = *reinterpret_cast<const u32_unaligned*>(sub + ty * L.pitch + 4 * wd + 64);
     }
   }
   const int sw = bw + 2, sh = bh + 2;  // score map with a zero ring

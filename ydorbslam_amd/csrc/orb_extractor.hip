@@ -165,6 +165,7 @@ int buildPlan(ydorb_extractor* e, int w, int h, HostPlan& P) {
           CellDev c{};
           c.level = (short)l;
           c.x0 = (short)iniX; c.y0 = (short)iniY; c.x1 = (short)maxX; c.y1 = (short)maxY;
+          c.srcOff = L.padOff + (kPad + c.y0) * L.pitch + kPad + c.x0;
           P.cells.push_back(c);
         }
       }
@@ -210,6 +211,9 @@ int buildPlan(ydorb_extractor* e, int w, int h, HostPlan& P) {
     D.lv[l].candOff = candOff;
     candOff += D.lv[l].nCells * D.cellCap;
   }
+  D.borderBegin[0] = 0;
+  for (int l = 0; l < kMaxLevels; l++)
+    D.borderBegin[l + 1] = D.borderBegin[l] + (l < D.nLevels ? alignUp(2 * kPad * (D.lv[l].pitch / 4) + 12 * D.lv[l].h, 256) : 0);
   D.blurTileBegin[0] = 0;
   for (int l = 0; l < kMaxLevels; l++)
     D.blurTileBegin[l + 1] = D.blurTileBegin[l] + (l < D.nLevels ? ((D.lv[l].w + kBlurTW - 1) / kBlurTW) * ((D.lv[l].h + kBlurTH - 1) / kBlurTH) : 0);
@@ -339,17 +343,14 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
     const LevelDev& L0 = D.lv[0];
     dim3 g((L0.pitch / 4 + 63) / 64, (L0.h + 4 * kPyrRows - 1) / (4 * kPyrRows), nFrames);
     hipLaunchKernelGGL(k_pyr_level0, g, dim3(256), 0, s, d_img, stride, frameStride, e->d_pyr, P.pyrFrameStride, L0);
-    int maxBorder = 0;
-    for (int l = 0; l < D.nLevels; l++) {
+    for (int l = 1; l < D.nLevels; l++) {
       const LevelDev& L = D.lv[l];
-      maxBorder = std::max(maxBorder, 2 * kPad * (L.pitch / 4) + 12 * L.h);
-      if (l == 0) continue;
       dim3 gl((L.pitch / 4 + 63) / 64, (L.h + 4 * kPyrRows - 1) / (4 * kPyrRows), nFrames);
       hipLaunchKernelGGL(k_pyr_resize, gl, dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, D.lv[l - 1], L,
                          1. / ((double)L.w / D.lv[l - 1].w), e->d_tabShort + P.tab[l].alpha, e->d_tabInt + P.tab[l].yofs,
                          e->d_tabShort + P.tab[l].beta);
     }
-    hipLaunchKernelGGL(k_pyr_borders, dim3((maxBorder + 255) / 256, D.nLevels, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, D);
+    hipLaunchKernelGGL(k_pyr_borders, dim3(D.borderBegin[D.nLevels] / 256, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, D);
   }
   if (prof) HIPCHK(hipEventRecord(e->ev[1], s));
   if (D.nCellsTotal > 0)
