@@ -1119,19 +1119,31 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
   }
   const int slot = bx * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (slot >= P.sumQuota) return;
-  int level = 0, before = 0, tot = 0;
-  for (int l = 0; l < P.nLevels; l++) {
-    const int c = lvlCount[f * kMaxLevels + l];
-    if (slot >= P.lv[l].kpOff) { level = l; before = tot; }
+  // the lane's four test point pairs do not depend on the keypoint: fetch them first, under the keypoint look-up
+  float4 pat[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) pat[t] = reinterpret_cast<const float4*>(kPatternDev)[t * 64 + lane];
+  // slot -> level needs no memory (kpOff is plan data); the packed keypoint is fetched together with the level counts instead of
+  // after them (one dependent round trip less; the slot is inside the array whether or not it holds a keypoint)
+  int level = 0;
+#pragma unroll
+  for (int l = 1; l < kMaxLevels; l++)
+    if (l < P.nLevels && slot >= P.lv[l].kpOff) level = l;
+  const uint32_t pk = __builtin_amdgcn_readfirstlane(lvlKp[(size_t)f * P.sumQuota + slot]);
+  int before = 0, tot = 0, mine = 0;
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; l++) {
+    const int c = l < P.nLevels ? lvlCount[f * kMaxLevels + l] : 0;
+    if (l < level) before += c;
+    if (l == level) mine = c;
     tot += c;
   }
   if (slot == 0 && lane == 0) nOut[f] = min(tot, cap);
   const LevelDev L = P.lv[level];
   const int k = slot - L.kpOff;
-  if (k >= lvlCount[f * kMaxLevels + level]) return;
+  if (k >= mine) return;
   const int outIdx = before + k;
   if (outIdx >= cap) return;
-  const uint32_t pk = __builtin_amdgcn_readfirstlane(lvlKp[(size_t)f * P.sumQuota + slot]);
   const int kx = qt_x(pk) + kBorder, ky = qt_y(pk) + kBorder;
   const uint8_t* roi = pyr + (size_t)f * pyrFrameStride + L.padOff + (size_t)kPad * L.pitch + kPad;
   // --- orientation.  The reference's m_v_maxXcords is 0 for most rows (only the centre column counts there) and up to 26 for
@@ -1171,7 +1183,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
   unsigned long long words[4];
 #pragma unroll
   for (int t = 0; t < 4; t++) {
-    const float4 pt = reinterpret_cast<const float4*>(kPatternDev)[t * 64 + lane];
+    const float4 pt = pat[t];
     const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(pt.x, sinB), __fmul_rn(pt.y, cosA)));
     const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(pt.x, cosA), __fmul_rn(pt.y, sinB)));
     const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(pt.z, sinB), __fmul_rn(pt.w, cosA)));
