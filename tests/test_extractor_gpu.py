@@ -130,3 +130,26 @@ def test_quadtree_flat_and_pass_kernels_agree(oracle_lib, monkeypatch):
         for l in range(8):
             assert flat.debug_read(3, l, f) == 0      # the flat kernel itself finished every one of these units
             assert passk.debug_read(3, l, f) == 1
+
+
+@pytest.mark.parametrize("w,h,nf,sf,nl,thr", [
+    (640, 480, 1500, 2.5, 3, 20),     # scale factor > 2: the resize kernel's byte-tap path
+    (640, 480, 800, 2.0, 4, 12),      # exactly 2: still the 8-byte window path
+    (752, 480, 1200, 1.5, 5, 30),
+    (97, 61, 200, 1.2, 8, 20),        # smallest levels have no FAST cells and borders wider than the interior
+    (1280, 720, 3000, 1.2, 8, 20),    # bigger than any BASELINE config: quotas above 600 per level, candidates beyond the LDS slots
+])
+def test_other_pyramid_configurations(oracle_lib, w, h, nf, sf, nl, thr):
+    """Constructor arguments other than the TUM/KITTI/EuRoC settings (orbExtractor.cpp:315-354 takes them freely)."""
+    import ydorbslam_amd as y
+    from oracle.orb_oracle import OrbExtractorOracle
+    gpu, cpu = y.OrbExtractor(nf, sf, nl, thr, 7), OrbExtractorOracle(nf, sf, nl, thr, 7)
+    for idx in (0, 1):                # the second call re-sizes the quad-tree launches from the first call's candidate counts
+        img = synth_frame(w, h, 20 + idx)
+        gk, gd = gpu.extract(img)
+        ck, cd = cpu.extract(img)
+        for l in range(nl):
+            cw, _, _ = cpu.level_dims(l)
+            assert np.array_equal(gpu.read_level(l), cpu.level_padded(l)[:, :cw + 38]), "pyramid level %d" % l
+        _same_kps(gk, ck)
+        assert np.array_equal(gd, cd)

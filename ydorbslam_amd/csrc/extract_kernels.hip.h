@@ -548,7 +548,14 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(PlanDev P, const uint32
   const int level = levelBase + blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
   if (needPass && !needPass[f * kMaxLevels + level]) return;   // k_quadtree_flat already produced this unit
   const LevelDev L = P.lv[level];
-  if (nodeCap <= 0) nodeCap = 4 * max(L.quota, 1);             // one launch over all levels: each derives its own table size
+  if (nodeCap <= 0) {   // one launch over all levels (-nodeCap = nodes the launch's LDS holds): each level derives its own table size
+    const int have = -nodeCap;
+    nodeCap = 4 * max(L.quota, 1);
+    if (nodeCap > have) {   // quota too large for an LDS node table: this unit cannot be handed over
+      if (lane == 0) { atomicMax(status, 3); lvlCount[f * kMaxLevels + level] = 0; }
+      return;
+    }
+  }
   uint8_t* sp = smem;
   QtShared S;
   S.cc = (QT_LDS unsigned long long*)(sp); sp += sizeof(unsigned long long) * nodeCap;

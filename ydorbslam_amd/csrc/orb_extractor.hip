@@ -32,9 +32,10 @@ struct HostPlan {
   std::vector<CellDev> cells;
   size_t pyrFrameStride = 0, blurFrameStride = 0, qtFrameStride = 0;
   // quad-tree launch geometry per level: node table for 4*quota nodes, LDS-resident candidates up to candCap (HBM beyond)
-  struct QtLevel { int nodeCap, candCap; size_t lds; int flatItems; size_t flatLds; } qt[kMaxLevels]{};
+  struct QtLevel { int nodeCap, candCap; size_t lds; int flatItems; size_t flatLds; bool passOk; } qt[kMaxLevels]{};
   size_t qtLdsMax = 0;
   size_t qtPassLds = 0;   // the all-levels hand-over launch: largest node table + cell bases, candidates in HBM
+  int qtPassNodes = 0;    // ... and how many nodes that table holds (a level that needs more cannot be handed over)
   std::vector<int> tabInt;      // xofs|yofs per level
   std::vector<short> tabShort;  // alpha|beta per level
   struct TabOff { int xofs, yofs, alpha, beta; } tab[kMaxLevels]{};
@@ -235,18 +236,26 @@ int buildPlan(ydorb_extractor* e, int w, int h, HostPlan& P) {
       Q.candCap = 0;
       Q.lds = (size_t)Q.nodeCap * 48 + (size_t)(L.nCells + 1) * 4;
     }
-    if (Q.lds > 150 * 1024) {
-      set_error("n_features=%d needs %zu B of LDS for the level-%d quad-tree (max 150 KiB)", e->cfg.n_features, Q.lds, l);
-      return YDORB_ERR_UNSUPPORTED;
+    // very large quotas (few levels x many features): the pass kernel's node table (48 B x 4 x quota) no longer fits LDS.  The flat
+    // kernel has no node table, so the level still works; only a unit that the flat kernel would hand over cannot be taken
+    // (reported as YDORB_ERR_CAPACITY by the call's status check — never silently wrong).
+    Q.passOk = Q.lds <= 150 * 1024;
+    if (Q.passOk) {
+      P.qtLdsMax = std::max(P.qtLdsMax, Q.lds);
+      P.qtPassLds = std::max(P.qtPassLds, (size_t)Q.nodeCap * 48 + (size_t)(L.nCells + 1) * 4);
+      P.qtPassNodes = std::max(P.qtPassNodes, Q.nodeCap);
     }
-    P.qtLdsMax = std::max(P.qtLdsMax, Q.lds);
-    P.qtPassLds = std::max(P.qtPassLds, (size_t)Q.nodeCap * 48 + (size_t)(L.nCells + 1) * 4);
     // flat kernel: 512*items candidate slots.  First guess from the densities above (L0 1/45 .. L7 1/20 of the band); enqueue()
     // re-sizes it from the candidate counts the device actually saw.  A unit with more candidates goes to the pass kernel.
     Q.flatItems = flatItemsFor((long)((double)band / (45.0 - 3.5 * l)) + 64);
     Q.flatLds = qt_flat_lds_bytes(Q.flatItems, L.quota);
     if (Q.flatLds > 150 * 1024) { Q.flatItems = 0; Q.flatLds = 0; }   // huge quotas: pass kernel only
+    if (!Q.passOk && (!Q.flatItems || e->forcePassQuadtree)) {
+      set_error("n_features=%d needs %zu B of LDS for the level-%d quad-tree (max 150 KiB)", e->cfg.n_features, Q.lds, l);
+      return YDORB_ERR_UNSUPPORTED;
+    }
   }
+  P.qtPassLds = std::max<size_t>(P.qtPassLds, 1024);
   return YDORB_OK;
 }
 
@@ -394,7 +403,7 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   for (int l = 0; l < D.nLevels; l++) HIPCHK(hipStreamWaitEvent(s, e->evJoin[l], 0));
   if (anyFlat)   // hand-over units of every level: node table in LDS, candidates in HBM scratch (candCap 0); others exit at once
     hipLaunchKernelGGL(k_quadtree, dim3(D.nLevels, nFrames), dim3(kQtThreads), P.qtPassLds, s, D, e->d_cellCount, e->d_cellCand, e->d_qtCand,
-                       e->d_qtNode, P.qtFrameStride, 0, 0, 0, e->d_lvlKp, e->d_lvlCount, e->d_status, e->d_needPass);
+                       e->d_qtNode, P.qtFrameStride, -P.qtPassNodes, 0, 0, e->d_lvlKp, e->d_lvlCount, e->d_status, e->d_needPass);
   if (prof) HIPCHK(hipEventRecord(e->ev[4], s));
   hipLaunchKernelGGL(k_orient_describe, dim3(((D.sumQuota + 3) / 4 + 7) / 8 * 8, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
                      P.blurFrameStride, D, e->d_lvlKp, e->d_lvlCount, d_kps, d_desc, cap, d_nOut, e->d_lvlAngle);
@@ -407,6 +416,7 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
 
 int checkStatus(ydorb_extractor* e) {
   if (*e->h_status == 1) { set_error("more than 65535 FAST candidates in one pyramid level"); return YDORB_ERR_CAPACITY; }
+  if (*e->h_status == 3) { set_error("a pyramid level needs the pass quad-tree kernel (more candidates than LDS slots, or a very deep tree) but its quota is too large for that kernel's LDS node table"); return YDORB_ERR_CAPACITY; }
   if (*e->h_status) { set_error("quad-tree node table overflow (status %d)", *e->h_status); return YDORB_ERR_CAPACITY; }
   return YDORB_OK;
 }
