@@ -184,21 +184,27 @@ __global__ __launch_bounds__(256) void k_errors(EdgeSoA Ed, const R* __restrict_
     const bool st = z[2] >= 0;
     R r[3], d;
     residual(t, q, V3{X[0], X[1], X[2]}, z, st, cam, r, &d);
-    err[3 * e] = r[0]; err[3 * e + 1] = r[1]; err[3 * e + 2] = r[2];
-    const R c2 = Ed.info[e] * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-    if (Ed.robust[e]) { R r0, r1; huber(c2, st ? deltaStereo : deltaMono, &r0, &r1); chi = r0; }
-    else chi = c2;
+    if (Ed.info[e] != 0) {   // information 0 = culled after stage 1: not in the active set (no chi2, error not refreshed)
+      err[3 * e] = r[0]; err[3 * e + 1] = r[1]; err[3 * e + 2] = r[2];
+      const R c2 = Ed.info[e] * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+      if (Ed.robust[e]) { R r0, r1; huber(c2, st ? deltaStereo : deltaMono, &r0, &r1); chi = r0; }
+      else chi = c2;
+    }
   }
   const R s = block_sum(chi, lds);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 // final ordered sum of the partials: out[slot] = sum(partial[0..n))
-__global__ __launch_bounds__(256) void k_sum_partials(const R* __restrict__ partial, int n, R* __restrict__ out, int slot) {
+__global__ __launch_bounds__(256) void k_sum_partials(const R* __restrict__ partial, int n, R* __restrict__ out, int slot,
+                                                      const int* __restrict__ status) {
   __shared__ R lds[4];
   R v = 0;
   for (int i = threadIdx.x; i < n; i += 256) v += partial[i];
   const R s = block_sum(v, lds);
-  if (threadIdx.x == 0) out[slot] = s;
+  if (threadIdx.x == 0) {
+    out[slot] = s;
+    if (status) { out[6] = (R)status[0]; out[7] = (R)status[1]; }   // the factorisation status rides along in the same read-back
+  }
 }
 
 // buildSystem, landmark side (constructQuadraticForm for `from` = point): one thread per active landmark.
@@ -211,13 +217,18 @@ __global__ __launch_bounds__(128) void k_build_points(EdgeSoA Ed, const int* __r
   if (l >= nL) return;
   R h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
   for (int e = ptStart[l]; e < ptStart[l + 1]; e++) {
+    const R w = Ed.info[e];
+    if (w == 0) {   // culled edge: no contribution; its Hpl block must read as zero for the Schur and back-substitution kernels
+      if (Ed.pidx[e] >= 0)
+        for (int k = 0; k < 18; k++) Hpl[(size_t)18 * e + k] = 0;
+      continue;
+    }
     V3 t; Q4 q;
     load_pose(poses, Ed.pose[e], t, q);
     const R* X = pts + 3 * Ed.pt[e];
     const bool st = Ed.meas[3 * e + 2] >= 0;
     R A[3][3], B[3][6];
     jacobians(t, q, V3{X[0], X[1], X[2]}, st, cam, A, B);
-    const R w = Ed.info[e];
     const R r0 = err[3 * e], r1 = err[3 * e + 1], r2 = err[3 * e + 2];
     R rho1 = 1;
     if (Ed.robust[e]) { R rr; huber(w * (r0 * r0 + r1 * r1 + r2 * r2), st ? deltaStereo : deltaMono, &rr, &rho1); }
@@ -257,13 +268,14 @@ __global__ __launch_bounds__(256) void k_build_poses(EdgeSoA Ed, const int* __re
   for (int k = 0; k < 6; k++) b[k] = 0;
   for (int j = poseStart[i] + threadIdx.x; j < poseStart[i + 1]; j += 256) {
     const int e = poseEdges[j];
+    const R w = Ed.info[e];
+    if (w == 0) continue;   // culled edge
     V3 t; Q4 q;
     load_pose(poses, Ed.pose[e], t, q);
     const R* X = pts + 3 * Ed.pt[e];
     const bool st = Ed.meas[3 * e + 2] >= 0;
     R A[3][3], B[3][6];
     jacobians(t, q, V3{X[0], X[1], X[2]}, st, cam, A, B);
-    const R w = Ed.info[e];
     const R r0 = err[3 * e], r1 = err[3 * e + 1], r2 = err[3 * e + 2];
     R rho1 = 1;
     if (Ed.robust[e]) { R rr; huber(w * (r0 * r0 + r1 * r1 + r2 * r2), st ? deltaStereo : deltaMono, &rr, &rho1); }
@@ -328,8 +340,9 @@ __global__ __launch_bounds__(256) void k_max_diag(const R* __restrict__ Hpp, int
 
 // D^-1 = (Hll + lambda I)^-1 (Eigen cofactor inverse, block_solver.hpp:350) and db = D^-1 b_l, per landmark
 __global__ __launch_bounds__(256) void k_dinv(const R* __restrict__ Hll, const R* __restrict__ bl, int nL, R lambda, R* __restrict__ Dinv,
-                                              R* __restrict__ db) {
+                                              R* __restrict__ db, int* __restrict__ status) {
   const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l == 0) { status[0] = 0; status[1] = 0; }   // first kernel of a trial: clears the factorisation status
   if (l >= nL) return;
   const R* d = Hll + (size_t)6 * l;
   const R a = d[0] + lambda, b = d[1], c = d[2], e = d[3] + lambda, f = d[4], i = d[5] + lambda;

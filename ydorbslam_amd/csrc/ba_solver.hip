@@ -74,6 +74,7 @@ struct Run {
   Cam cam;
   double phaseMs[PH_COUNT] = {0, 0, 0, 0, 0};
   bool pending[PH_COUNT] = {false, false, false, false, false};
+  struct Sys { std::vector<int> act; int nL = 0, nPf = 0, Ea = 0, n = 0, nb = 0, nBlkE = 0, nBuckets = 0; } sys;   // stage 1's system, re-used by stage 2
   bool stopped() const { return P->stop && *P->stop; }
 };
 
@@ -113,116 +114,144 @@ struct PhaseTimer {
 };
 
 // one SparseOptimizer::optimize(iterations) on the level-0 edges
-int optimize(Run& R_, int iterations, int stage) {
+int optimize(Run& R_, int iterations, int stage, bool reuse) {
   Ctx& c = *R_.c;
   const YdBaProblem& P = *R_.P;
   const YdBaOptions& O = *R_.O;
   hipStream_t s = c.stream;
   const int K = P.n_poses, NP = P.n_points, E = P.n_edges;
   trace("optimize: begin");
-  std::vector<int> act;
-  for (int e = 0; e < E; e++) if (!R_.level[e]) act.push_back(e);
-  if (act.empty()) return YDORB_OK;
-  // index mapping (buildIndexMapping, sparse_optimizer.cpp:168-192): free poses first, then landmarks, active ones only
-  std::vector<int> poseIdx(K, -1), ptIdx(NP, -1), poseOf, ptOf;
-  {
-    std::vector<uint8_t> pu(K, 0), qu(NP, 0);
-    for (int e : act) { pu[P.edge_pose[e]] = 1; qu[P.edge_point[e]] = 1; }
-    for (int k = 0; k < K; k++) if (pu[k] && !P.pose_fixed[k]) { poseIdx[k] = (int)poseOf.size(); poseOf.push_back(k); }
-    for (int p = 0; p < NP; p++) if (qu[p]) { ptIdx[p] = (int)ptOf.size(); ptOf.push_back(p); }
-  }
-  const int nP = (int)poseOf.size(), nL = (int)ptOf.size(), Ea = (int)act.size();
-  if (O.world > 1) {
-    // every rank must factorise the same reduced system: the free-pose set comes from the caller's fixed mask only
-    poseOf.clear();
-    for (int k = 0; k < K; k++) { poseIdx[k] = -1; if (!P.pose_fixed[k]) { poseIdx[k] = (int)poseOf.size(); poseOf.push_back(k); } }
-  }
-  const int nPf = (int)poseOf.size();
-  (void)nP;
-  {  // order by (landmark index, pose index, edge index): counting sort by landmark, then a tiny insertion sort per landmark
-    std::vector<int> start(nL + 1, 0), sorted(Ea);
-    for (int e : act) start[ptIdx[P.edge_point[e]] + 1]++;
-    for (int l = 0; l < nL; l++) start[l + 1] += start[l];
-    std::vector<int> fill(start.begin(), start.end() - 1);
-    for (int e : act) sorted[fill[ptIdx[P.edge_point[e]]]++] = e;   // act is ascending: stable
-    for (int l = 0; l < nL; l++)
-      for (int a = start[l] + 1; a < start[l + 1]; a++) {
-        const int e = sorted[a], pe = poseIdx[P.edge_pose[e]];
-        int b = a - 1;
-        while (b >= start[l] && (poseIdx[P.edge_pose[sorted[b]]] > pe || (poseIdx[P.edge_pose[sorted[b]]] == pe && sorted[b] > e))) { sorted[b + 1] = sorted[b]; b--; }
-        sorted[b + 1] = e;
-      }
-    act.swap(sorted);
-  }
-  std::vector<int> hPose(Ea), hPidx(Ea), hPt(Ea), hLm(Ea), hPtStart(nL + 1, 0), hPoseStart(nPf + 1, 0), hPoseEdges;
-  std::vector<double> hMeas((size_t)3 * Ea), hInfo(Ea);
-  std::vector<uint8_t> hRobust(Ea);
-  for (int i = 0; i < Ea; i++) {
-    const int e = act[i];
-    hPose[i] = P.edge_pose[e]; hPidx[i] = poseIdx[P.edge_pose[e]]; hPt[i] = P.edge_point[e]; hLm[i] = ptIdx[P.edge_point[e]];
-    for (int d = 0; d < 3; d++) hMeas[3 * i + d] = P.edge_meas[3 * e + d];
-    hInfo[i] = P.edge_inv_sigma2[e];
-    hRobust[i] = R_.robust[e];
-    hPtStart[hLm[i] + 1]++;
-    if (hPidx[i] >= 0) hPoseStart[hPidx[i] + 1]++;
-  }
-  for (int l = 0; l < nL; l++) hPtStart[l + 1] += hPtStart[l];
-  for (int i = 0; i < nPf; i++) hPoseStart[i + 1] += hPoseStart[i];
-  hPoseEdges.resize(hPoseStart[nPf]);
-  {
-    std::vector<int> fill(hPoseStart.begin(), hPoseStart.end() - 1);
-    for (int i = 0; i < Ea; i++) if (hPidx[i] >= 0) hPoseEdges[fill[hPidx[i]]++] = i;
-  }
-  const int n = std::max(NB, (6 * nPf + NB - 1) / NB * NB), nb = n / NB;
-  const int nBlkE = (Ea + 255) / 256;
+  Run::Sys& Y = R_.sys;
+  // Stage 2 (after the chi2 cull) re-uses stage 1's device structures: a culled edge keeps its slot with information 0, which
+  // every kernel treats as "skip" — no second host ordering, upload or pair-bucket build.  Landmarks / poses that lose all their
+  // edges stay in the system with H = lambda*I, b = 0, i.e. dx = 0: the same estimate g2o keeps by leaving them out.
+  auto prepare = [&]() -> int {
+    std::vector<int> act;
+    for (int e = 0; e < E; e++) if (!R_.level[e]) act.push_back(e);
+    if (act.empty()) { Y.Ea = 0; return YDORB_OK; }
+    // index mapping (buildIndexMapping, sparse_optimizer.cpp:168-192): free poses first, then landmarks, active ones only
+    std::vector<int> poseIdx(K, -1), ptIdx(NP, -1), poseOf, ptOf;
+    {
+      std::vector<uint8_t> pu(K, 0), qu(NP, 0);
+      for (int e : act) { pu[P.edge_pose[e]] = 1; qu[P.edge_point[e]] = 1; }
+      for (int k = 0; k < K; k++) if (pu[k] && !P.pose_fixed[k]) { poseIdx[k] = (int)poseOf.size(); poseOf.push_back(k); }
+      for (int p = 0; p < NP; p++) if (qu[p]) { ptIdx[p] = (int)ptOf.size(); ptOf.push_back(p); }
+    }
+    const int nP = (int)poseOf.size(), nL = (int)ptOf.size(), Ea = (int)act.size();
+    if (O.world > 1) {
+      // every rank must factorise the same reduced system: the free-pose set comes from the caller's fixed mask only
+      poseOf.clear();
+      for (int k = 0; k < K; k++) { poseIdx[k] = -1; if (!P.pose_fixed[k]) { poseIdx[k] = (int)poseOf.size(); poseOf.push_back(k); } }
+    }
+    const int nPf = (int)poseOf.size();
+    (void)nP;
+    {  // order by (landmark index, pose index, edge index): counting sort by landmark, then a tiny insertion sort per landmark
+      std::vector<int> start(nL + 1, 0), sorted(Ea);
+      for (int e : act) start[ptIdx[P.edge_point[e]] + 1]++;
+      for (int l = 0; l < nL; l++) start[l + 1] += start[l];
+      std::vector<int> fill(start.begin(), start.end() - 1);
+      for (int e : act) sorted[fill[ptIdx[P.edge_point[e]]]++] = e;   // act is ascending: stable
+      for (int l = 0; l < nL; l++)
+        for (int a = start[l] + 1; a < start[l + 1]; a++) {
+          const int e = sorted[a], pe = poseIdx[P.edge_pose[e]];
+          int b = a - 1;
+          while (b >= start[l] && (poseIdx[P.edge_pose[sorted[b]]] > pe || (poseIdx[P.edge_pose[sorted[b]]] == pe && sorted[b] > e))) { sorted[b + 1] = sorted[b]; b--; }
+          sorted[b + 1] = e;
+        }
+      act.swap(sorted);
+    }
+    std::vector<int> hPose(Ea), hPidx(Ea), hPt(Ea), hLm(Ea), hPtStart(nL + 1, 0), hPoseStart(nPf + 1, 0), hPoseEdges;
+    std::vector<double> hMeas((size_t)3 * Ea), hInfo(Ea);
+    std::vector<uint8_t> hRobust(Ea);
+    for (int i = 0; i < Ea; i++) {
+      const int e = act[i];
+      hPose[i] = P.edge_pose[e]; hPidx[i] = poseIdx[P.edge_pose[e]]; hPt[i] = P.edge_point[e]; hLm[i] = ptIdx[P.edge_point[e]];
+      for (int d = 0; d < 3; d++) hMeas[3 * i + d] = P.edge_meas[3 * e + d];
+      hInfo[i] = P.edge_inv_sigma2[e];
+      hRobust[i] = R_.robust[e];
+      hPtStart[hLm[i] + 1]++;
+      if (hPidx[i] >= 0) hPoseStart[hPidx[i] + 1]++;
+    }
+    for (int l = 0; l < nL; l++) hPtStart[l + 1] += hPtStart[l];
+    for (int i = 0; i < nPf; i++) hPoseStart[i + 1] += hPoseStart[i];
+    hPoseEdges.resize(hPoseStart[nPf]);
+    {
+      std::vector<int> fill(hPoseStart.begin(), hPoseStart.end() - 1);
+      for (int i = 0; i < Ea; i++) if (hPidx[i] >= 0) hPoseEdges[fill[hPidx[i]]++] = i;
+    }
+    const int n = std::max(NB, (6 * nPf + NB - 1) / NB * NB), nb = n / NB;
+    const int nBlkE = (Ea + 255) / 256;
+    int rc;
+    if ((rc = c.ePose.ensure(sizeof(int) * Ea)) || (rc = c.ePidx.ensure(sizeof(int) * Ea)) || (rc = c.ePt.ensure(sizeof(int) * Ea)) ||
+        (rc = c.eLm.ensure(sizeof(int) * Ea)) || (rc = c.eMeas.ensure(sizeof(double) * 3 * Ea)) || (rc = c.eInfo.ensure(sizeof(double) * Ea)) ||
+        (rc = c.eRobust.ensure(Ea)) || (rc = c.ptStart.ensure(sizeof(int) * (nL + 1))) || (rc = c.poseStart.ensure(sizeof(int) * (nPf + 1))) ||
+        (rc = c.poseEdges.ensure(sizeof(int) * std::max<size_t>(hPoseEdges.size(), 1))) || (rc = c.poseOf.ensure(sizeof(int) * std::max(nPf, 1))) ||
+        (rc = c.ptOf.ensure(sizeof(int) * nL)) || (rc = c.err.ensure(sizeof(double) * 3 * Ea)) || (rc = c.partial.ensure(sizeof(double) * (nBlkE + (6 * nPf + 3 * nL + 255) / 256 + 1))) ||
+        (rc = c.Hll.ensure(sizeof(double) * 6 * nL)) || (rc = c.bl.ensure(sizeof(double) * 3 * nL)) || (rc = c.Hpl.ensure(sizeof(double) * 18 * (size_t)Ea)) ||
+        (rc = c.BD.ensure(sizeof(double) * 18 * (size_t)Ea)) ||
+        (rc = c.Hpp.ensure(sizeof(double) * 42 * std::max(nPf, 1))) || (rc = c.S.ensure(sizeof(double) * ((size_t)n * n + n))) ||
+        (rc = c.diagL.ensure(sizeof(double) * (size_t)nb * NB * NB)) || (rc = c.diagInv.ensure(sizeof(double) * (size_t)nb * NB * NB)) || (rc = c.Dinv.ensure(sizeof(double) * 6 * nL)) || (rc = c.db.ensure(sizeof(double) * 3 * nL)) ||
+        (rc = c.xp.ensure(sizeof(double) * n)) || (rc = c.yv.ensure(sizeof(double) * n)) || (rc = c.xl.ensure(sizeof(double) * 3 * nL)) || (rc = c.scal.ensure(sizeof(double) * 8)) ||
+        (rc = c.status.ensure(sizeof(int) * 2)))
+      return rc;
+    // Hpp and bp are contiguous ([36 nPf | 6 nPf]) so one all-reduce covers both; bs follows S for the same reason
+    trace("optimize: host ordering done");
+  #define UP(buf, vec, T) HIPCHK(hipMemcpyAsync(c.buf.p, vec.data(), sizeof(T) * vec.size(), hipMemcpyHostToDevice, s))
+    UP(ePose, hPose, int); UP(ePidx, hPidx, int); UP(ePt, hPt, int); UP(eLm, hLm, int); UP(eMeas, hMeas, double); UP(eInfo, hInfo, double);
+    UP(eRobust, hRobust, uint8_t); UP(ptStart, hPtStart, int); UP(poseStart, hPoseStart, int); UP(ptOf, ptOf, int);
+    if (!hPoseEdges.empty()) UP(poseEdges, hPoseEdges, int);
+    if (nPf) UP(poseOf, poseOf, int);
+  #undef UP
+    trace("optimize: uploads enqueued");
+    // pose-pair buckets of the Schur complement (structure is fixed for this optimize() call)
+    const int nBuckets = nPf * (nPf + 1) / 2;
+    size_t nItems = 0;
+    for (int l = 0; l < nL; l++) {
+      size_t m = 0;
+      for (int i = hPtStart[l]; i < hPtStart[l + 1]; i++) m += hPidx[i] >= 0;
+      nItems += m * (m + 1) / 2;
+    }
+    if ((rc = c.pairCnt.ensure(sizeof(int) * (nBuckets + 1))) || (rc = c.pairStart.ensure(sizeof(int) * (nBuckets + 1))) ||
+        (rc = c.pairCursor.ensure(sizeof(int) * (nBuckets + 1))) || (rc = c.pairA.ensure(sizeof(int2) * std::max<size_t>(nItems, 1))) ||
+        (rc = c.pairB.ensure(sizeof(int2) * std::max<size_t>(nItems, 1))))
+      return rc;
+    if (nBuckets > 0) {
+      EdgeSoA Ed{c.ePose.as<int>(), c.ePidx.as<int>(), c.ePt.as<int>(), c.eMeas.as<double>(), c.eInfo.as<double>(), c.eRobust.as<uint8_t>(), Ea};
+      HIPCHK(hipMemsetAsync(c.pairCnt.p, 0, sizeof(int) * (nBuckets + 1), s));
+      hipLaunchKernelGGL(k_pair_count, dim3((nL + 255) / 256), dim3(256), 0, s, Ed, c.ptStart.as<int>(), nL, c.pairCnt.as<int>());
+      hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(256), 0, s, c.pairCnt.as<int>(), nBuckets, c.pairStart.as<int>());
+      HIPCHK(hipMemcpyAsync(c.pairCursor.p, c.pairStart.p, sizeof(int) * (nBuckets + 1), hipMemcpyDeviceToDevice, s));
+      hipLaunchKernelGGL(k_pair_fill, dim3((nL + 255) / 256), dim3(256), 0, s, Ed, c.ptStart.as<int>(), nL, c.pairCursor.as<int>(), c.pairA.as<int2>());
+      hipLaunchKernelGGL(k_pair_sort, dim3((nBuckets + 3) / 4), dim3(256), 0, s, c.pairStart.as<int>(), nBuckets, c.pairA.as<int2>(), c.pairB.as<int2>());
+    }
+    HIPCHK(hipStreamSynchronize(s));   // the host staging vectors above die with this scope
+    Y.act.swap(act); Y.nL = nL; Y.nPf = nPf; Y.Ea = Ea; Y.n = n; Y.nb = nb; Y.nBlkE = nBlkE; Y.nBuckets = nBuckets;
+    return YDORB_OK;
+  };
   int rc;
-  if ((rc = c.ePose.ensure(sizeof(int) * Ea)) || (rc = c.ePidx.ensure(sizeof(int) * Ea)) || (rc = c.ePt.ensure(sizeof(int) * Ea)) ||
-      (rc = c.eLm.ensure(sizeof(int) * Ea)) || (rc = c.eMeas.ensure(sizeof(double) * 3 * Ea)) || (rc = c.eInfo.ensure(sizeof(double) * Ea)) ||
-      (rc = c.eRobust.ensure(Ea)) || (rc = c.ptStart.ensure(sizeof(int) * (nL + 1))) || (rc = c.poseStart.ensure(sizeof(int) * (nPf + 1))) ||
-      (rc = c.poseEdges.ensure(sizeof(int) * std::max<size_t>(hPoseEdges.size(), 1))) || (rc = c.poseOf.ensure(sizeof(int) * std::max(nPf, 1))) ||
-      (rc = c.ptOf.ensure(sizeof(int) * nL)) || (rc = c.err.ensure(sizeof(double) * 3 * Ea)) || (rc = c.partial.ensure(sizeof(double) * (nBlkE + (6 * nPf + 3 * nL + 255) / 256 + 1))) ||
-      (rc = c.Hll.ensure(sizeof(double) * 6 * nL)) || (rc = c.bl.ensure(sizeof(double) * 3 * nL)) || (rc = c.Hpl.ensure(sizeof(double) * 18 * (size_t)Ea)) ||
-      (rc = c.BD.ensure(sizeof(double) * 18 * (size_t)Ea)) ||
-      (rc = c.Hpp.ensure(sizeof(double) * 42 * std::max(nPf, 1))) || (rc = c.S.ensure(sizeof(double) * ((size_t)n * n + n))) ||
-      (rc = c.diagL.ensure(sizeof(double) * (size_t)nb * NB * NB)) || (rc = c.diagInv.ensure(sizeof(double) * (size_t)nb * NB * NB)) || (rc = c.Dinv.ensure(sizeof(double) * 6 * nL)) || (rc = c.db.ensure(sizeof(double) * 3 * nL)) ||
-      (rc = c.xp.ensure(sizeof(double) * n)) || (rc = c.yv.ensure(sizeof(double) * n)) || (rc = c.xl.ensure(sizeof(double) * 3 * nL)) || (rc = c.scal.ensure(sizeof(double) * 8)) ||
-      (rc = c.status.ensure(sizeof(int) * 2)))
-    return rc;
+  if (!reuse || Y.Ea == 0) {
+    if ((rc = prepare())) return rc;
+  } else {
+    std::vector<double> hInfo(Y.Ea);
+    std::vector<uint8_t> hRobust(Y.Ea);
+    for (int i = 0; i < Y.Ea; i++) { const int e = Y.act[i]; hInfo[i] = R_.level[e] ? 0.0 : P.edge_inv_sigma2[e]; hRobust[i] = R_.robust[e]; }
+    HIPCHK(hipMemcpyAsync(c.eInfo.p, hInfo.data(), sizeof(double) * Y.Ea, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c.eRobust.p, hRobust.data(), Y.Ea, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));   // the staging vectors die here
+  }
+  if (Y.Ea == 0) return YDORB_OK;
+  const std::vector<int>& act = Y.act;
+  const int nL = Y.nL, nPf = Y.nPf, Ea = Y.Ea, n = Y.n, nb = Y.nb, nBlkE = Y.nBlkE, nBuckets = Y.nBuckets;
   // Hpp and bp are contiguous ([36 nPf | 6 nPf]) so one all-reduce covers both; bs follows S for the same reason
   double* dHpp = c.Hpp.as<double>();
   double* dbp = dHpp + (size_t)36 * nPf;
   double* dS = c.S.as<double>();
   double* dbs = dS + (size_t)n * n;
-  trace("optimize: host ordering done");
-#define UP(buf, vec, T) HIPCHK(hipMemcpyAsync(c.buf.p, vec.data(), sizeof(T) * vec.size(), hipMemcpyHostToDevice, s))
-  UP(ePose, hPose, int); UP(ePidx, hPidx, int); UP(ePt, hPt, int); UP(eLm, hLm, int); UP(eMeas, hMeas, double); UP(eInfo, hInfo, double);
-  UP(eRobust, hRobust, uint8_t); UP(ptStart, hPtStart, int); UP(poseStart, hPoseStart, int); UP(ptOf, ptOf, int);
-  if (!hPoseEdges.empty()) UP(poseEdges, hPoseEdges, int);
-  if (nPf) UP(poseOf, poseOf, int);
-#undef UP
-  trace("optimize: uploads enqueued");
   EdgeSoA Ed{c.ePose.as<int>(), c.ePidx.as<int>(), c.ePt.as<int>(), c.eMeas.as<double>(), c.eInfo.as<double>(), c.eRobust.as<uint8_t>(), Ea};
   const double dM = O.delta_mono, dSt = O.delta_stereo;
-  // pose-pair buckets of the Schur complement (structure is fixed for this optimize() call)
-  const int nBuckets = nPf * (nPf + 1) / 2;
-  size_t nItems = 0;
-  for (int l = 0; l < nL; l++) {
-    size_t m = 0;
-    for (int i = hPtStart[l]; i < hPtStart[l + 1]; i++) m += hPidx[i] >= 0;
-    nItems += m * (m + 1) / 2;
-  }
-  if ((rc = c.pairCnt.ensure(sizeof(int) * (nBuckets + 1))) || (rc = c.pairStart.ensure(sizeof(int) * (nBuckets + 1))) ||
-      (rc = c.pairCursor.ensure(sizeof(int) * (nBuckets + 1))) || (rc = c.pairA.ensure(sizeof(int2) * std::max<size_t>(nItems, 1))) ||
-      (rc = c.pairB.ensure(sizeof(int2) * std::max<size_t>(nItems, 1))))
-    return rc;
-  if (nBuckets > 0) {
-    HIPCHK(hipMemsetAsync(c.pairCnt.p, 0, sizeof(int) * (nBuckets + 1), s));
-    hipLaunchKernelGGL(k_pair_count, dim3((nL + 255) / 256), dim3(256), 0, s, Ed, c.ptStart.as<int>(), nL, c.pairCnt.as<int>());
-    hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(256), 0, s, c.pairCnt.as<int>(), nBuckets, c.pairStart.as<int>());
-    HIPCHK(hipMemcpyAsync(c.pairCursor.p, c.pairStart.p, sizeof(int) * (nBuckets + 1), hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_pair_fill, dim3((nL + 255) / 256), dim3(256), 0, s, Ed, c.ptStart.as<int>(), nL, c.pairCursor.as<int>(), c.pairA.as<int2>());
-    hipLaunchKernelGGL(k_pair_sort, dim3((nBuckets + 3) / 4), dim3(256), 0, s, c.pairStart.as<int>(), nBuckets, c.pairA.as<int2>(), c.pairB.as<int2>());
-  }
+  // the two estimate buffers must agree on everything the update kernel does not write (fixed poses, points without edges)
+  HIPCHK(hipMemcpyAsync(c.poses[R_.cur ^ 1].p, c.poses[R_.cur].p, sizeof(double) * 7 * K, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(c.pts[R_.cur ^ 1].p, c.pts[R_.cur].p, sizeof(double) * 3 * NP, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemsetAsync(dS, 0, sizeof(double) * ((size_t)n * n + n), s));
   double* hscal = c.hPin;
   int* hstatus = reinterpret_cast<int*>(c.hPin + 8);
@@ -232,12 +261,12 @@ int optimize(Run& R_, int iterations, int stage) {
     PhaseTimer t(R_, PH_ERR);
     hipLaunchKernelGGL(k_errors, dim3(nBlkE), dim3(256), 0, s, Ed, c.poses[buf].as<double>(), c.pts[buf].as<double>(), R_.cam, dM, dSt,
                        c.err.as<double>(), c.partial.as<double>());
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, c.partial.as<double>(), nBlkE, c.scal.as<double>(), 0);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, c.partial.as<double>(), nBlkE, c.scal.as<double>(), 0, withStatus ? c.status.as<int>() : nullptr);
     t.stop();
     if (multi) { int r2 = allreduce(R_, c.scal.p, 1, 0); if (r2) return r2; }
     HIPCHK(hipMemcpyAsync(hscal, c.scal.p, sizeof(double) * 8, hipMemcpyDeviceToHost, s));
-    if (withStatus) HIPCHK(hipMemcpyAsync(hstatus, c.status.p, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    if (withStatus) { hstatus[0] = (int)hscal[6]; hstatus[1] = (int)hscal[7]; }
     *out = hscal[0];
     return YDORB_OK;
   };
@@ -270,11 +299,10 @@ int optimize(Run& R_, int iterations, int stage) {
     int qmax = 0;
     do {
       const int nxt = R_.cur ^ 1;
-      HIPCHK(hipMemsetAsync(c.status.p, 0, sizeof(int) * 2, s));
       {
         PhaseTimer t(R_, PH_SCHUR);
         const double contrib = (!multi || O.rank == 0) ? 1.0 : 0.0;
-        hipLaunchKernelGGL(k_dinv, dim3((nL + 255) / 256), dim3(256), 0, s, c.Hll.as<double>(), c.bl.as<double>(), nL, lambda, c.Dinv.as<double>(), c.db.as<double>());
+        hipLaunchKernelGGL(k_dinv, dim3((nL + 255) / 256), dim3(256), 0, s, c.Hll.as<double>(), c.bl.as<double>(), nL, lambda, c.Dinv.as<double>(), c.db.as<double>(), c.status.as<int>());
         hipLaunchKernelGGL(k_bd, dim3(nBlkE), dim3(256), 0, s, Ed, c.eLm.as<int>(), c.Hpl.as<double>(), c.Dinv.as<double>(), c.BD.as<double>());
         if (nPf)
           hipLaunchKernelGGL(k_bs, dim3(nPf), dim3(256), 0, s, Ed, c.poseStart.as<int>(), c.poseEdges.as<int>(), c.eLm.as<int>(), c.Hpl.as<double>(),
@@ -298,8 +326,6 @@ int optimize(Run& R_, int iterations, int stage) {
       }
       {
         PhaseTimer t(R_, PH_UPDATE);
-        HIPCHK(hipMemcpyAsync(c.poses[nxt].p, c.poses[R_.cur].p, sizeof(double) * 7 * K, hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipMemcpyAsync(c.pts[nxt].p, c.pts[R_.cur].p, sizeof(double) * 3 * NP, hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(k_update, dim3((std::max(nPf, nL) + 255) / 256), dim3(256), 0, s, c.poses[R_.cur].as<double>(), c.pts[R_.cur].as<double>(),
                            c.poses[nxt].as<double>(), c.pts[nxt].as<double>(), c.poseOf.as<int>(), nPf, c.ptOf.as<int>(), nL, c.xp.as<double>(),
                            c.xl.as<double>());
@@ -309,7 +335,7 @@ int optimize(Run& R_, int iterations, int stage) {
           const int nb2 = (np6 + 3 * nL + 255) / 256;
           hipLaunchKernelGGL(k_scale, dim3(nb2), dim3(256), 0, s, c.xp.as<double>(), dbp, np6, c.xl.as<double>(), c.bl.as<double>(), 3 * nL, lambda,
                              c.partial.as<double>() + nBlkE);
-          hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, c.partial.as<double>() + nBlkE, nb2, c.scal.as<double>(), 2);
+          hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, c.partial.as<double>() + nBlkE, nb2, c.scal.as<double>(), 2, nullptr);
         }
         t.stop();
         if (multi) { if ((rc = allreduce(R_, c.scal.as<double>() + 2, 1, 0))) return rc; }
@@ -351,7 +377,8 @@ int optimize(Run& R_, int iterations, int stage) {
   HIPCHK(hipMemcpyAsync(herr.data(), c.err.p, sizeof(double) * 3 * Ea, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   for (int i = 0; i < Ea; i++)
-    for (int d = 0; d < 3; d++) R_.err[(size_t)3 * act[i] + d] = herr[(size_t)3 * i + d];
+    if (!R_.level[act[i]])   // a culled edge keeps the error of its last evaluation (it is not in g2o's active set any more)
+      for (int d = 0; d < 3; d++) R_.err[(size_t)3 * act[i] + d] = herr[(size_t)3 * i + d];
   for (int ph = 0; ph < PH_COUNT; ph++) PhaseTimer::collect(R_, ph);
   trace("optimize: errors read back");
   return YDORB_OK;
@@ -443,7 +470,7 @@ int ydorb_ba_solve(const YdBaProblem* P, const YdBaOptions* optIn, YdBaResult* r
   hipEvent_t t0 = c.ev[2 * PH_COUNT], t1 = c.ev[2 * PH_COUNT + 1];
   HIPCHK(hipEventRecord(t0, c.stream));
 
-  if ((rc = optimize(R_, O.iters1, 1))) return rc;
+  if ((rc = optimize(R_, O.iters1, 1, false))) return rc;
   auto chi2Of = [&](int e) {
     const double* r = &R_.err[(size_t)3 * e];
     return P->edge_inv_sigma2[e] * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
@@ -457,7 +484,7 @@ int ydorb_ba_solve(const YdBaProblem* P, const YdBaOptions* optIn, YdBaResult* r
       if (chi2Of(e) > th || !(depth[e] > 0.0)) R_.level[e] = 1;
       R_.robust[e] = 0;
     }
-    if ((rc = optimize(R_, O.iters2, 2))) return rc;
+    if ((rc = optimize(R_, O.iters2, 2, true))) return rc;
   } else {
     res->stopped = 1;
   }
