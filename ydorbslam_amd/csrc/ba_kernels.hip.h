@@ -475,23 +475,27 @@ __global__ __launch_bounds__(256) void k_bs(EdgeSoA Ed, const int* __restrict__ 
   __syncthreads();
   if (threadIdx.x < 6) bs[6 * i + threadIdx.x] = contrib * bp[6 * i + threadIdx.x] - (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
-// One wave per lower 6x6 block (i2 >= i1); the last workgroup also writes the identity padding of S and bs.
+// One workgroup per lower 6x6 block (i2 >= i1); the last workgroup also writes the identity padding of S and bs.
 // The block is the contraction  [Hpl_b rows q | 3m columns] x [BD_a rows r | 3m columns]^T  over the m landmarks the two poses
 // share: it runs on the FP64 matrix core, v_mfma_f64_16x16x4_f64 (A[i = lane&15][k = lane>>4], B[k][j = lane&15],
-// D col = lane&15, row = (lane>>4) + 4*reg; rows/cols >= 6 are fed zeros), four k-columns per instruction, items of a
-// 64-item chunk handed to the lanes by ds_bpermute so no load depends on another load.
+// D col = lane&15, row = (lane>>4) + 4*reg; rows/cols >= 6 are fed zeros), four k-columns per instruction.
 typedef double double4_t __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_schur_pairs(const int* __restrict__ start, const int2* __restrict__ items, int nP, int nBuckets,
+constexpr int kSchurWaves = 4;   // waves per bucket
+__global__ __launch_bounds__(64 * kSchurWaves) void k_schur_pairs(const int* __restrict__ start, const int2* __restrict__ items, int nP, int nBuckets,
                                                      const R* __restrict__ BD, const R* __restrict__ Hpl, const R* __restrict__ Hpp, R lambda,
                                                      R contrib, int n, R* __restrict__ S, R* __restrict__ bs) {
-  const int bkt = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // One workgroup per bucket, its items split over the workgroup's waves (the buckets of poses that see the same landmarks hold hundreds of
+  // items while most others are empty: with one wave per bucket ~700 waves carried the whole launch); the partial blocks
+  // are added in wave order, so the result does not depend on timing.
+  __shared__ R part[kSchurWaves][36];
+  const int bkt = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (bkt >= nBuckets) {
     if (blockIdx.x == gridDim.x - 1) {  // padding rows/cols 6 nP .. n-1: identity (scaled like the rest for the all-reduce)
-      for (int idx = threadIdx.x; idx < (n - 6 * nP) * n; idx += 256) {
+      for (int idx = threadIdx.x; idx < (n - 6 * nP) * n; idx += 64 * kSchurWaves) {
         const int r = 6 * nP + idx / n, c = idx % n;
         if (c <= r) S[(size_t)r * n + c] = r == c ? contrib : 0.0;
       }
-      for (int r = 6 * nP + threadIdx.x; r < n; r += 256) bs[r] = 0;
+      for (int r = 6 * nP + threadIdx.x; r < n; r += 64 * kSchurWaves) bs[r] = 0;
     }
     return;
   }
@@ -502,40 +506,47 @@ __global__ __launch_bounds__(256) void k_schur_pairs(const int* __restrict__ sta
   const int i16 = lane & 15, kq = lane >> 4;
   const bool live = i16 < 6;
   double4_t acc = {0.0, 0.0, 0.0, 0.0};
-  const int s0 = start[bkt], s1 = start[bkt + 1];
-  for (int chunk = s0; chunk < s1; chunk += 64) {
-    const int cnt = min(64, s1 - chunk);
-    const int2 it = lane < cnt ? items[chunk + lane] : make_int2(0, 0);
-    const int nk = 3 * cnt;
-    // 16 MFMA steps per group: all 32 operand loads of a group are issued before the first MFMA waits on one of them
-    for (int kg = 0; kg < nk; kg += 64) {
-      R av[16], bv[16];
+  const int b0 = start[bkt], b1 = start[bkt + 1];
+  const int per = (((b1 - b0) + kSchurWaves - 1) / kSchurWaves + 3) & ~3;   // items per wave, a multiple of the 4 MFMA k-slots
+  const int s0 = min(b0 + wv * per, b1), s1 = min(s0 + per, b1);
+  // K ordering chosen for the loads, not for the landmarks: MFMA k-slot kq takes item 4g + kq and the three instructions of a
+  // group take that item's columns c = 0, 1, 2 — so lane (row i16, slot kq) reads ITS row of ITS item as three consecutive
+  // doubles from each operand (the 16 lanes of a slot cover one contiguous 144-byte block), no index shuffles, and 8 groups
+  // (32 items) of loads are in flight before the first MFMA waits.
+  for (int base = s0; base < s1; base += 32) {
+    R av[8][3], bv[8][3];
 #pragma unroll
-      for (int u = 0; u < 16; u++) {
-        const int kk = kg + 4 * u + kq;
-        const int t = kk / 3, c = kk - 3 * t;
-        const int ea = __shfl(it.x, t & 63, 64), eb = __shfl(it.y, t & 63, 64);
-        av[u] = 0.0; bv[u] = 0.0;
-        if (live && kk < nk) {
-          av[u] = Hpl[(size_t)18 * eb + i16 * 3 + c];
-          bv[u] = BD[(size_t)18 * ea + i16 * 3 + c];
-        }
-      }
+    for (int g = 0; g < 8; g++) {
+      const int idx = base + 4 * g + kq;
+      const bool on = live && idx < s1;
+      const int2 it = on ? items[idx] : make_int2(0, 0);
+      const R* pa = Hpl + (size_t)18 * it.y + i16 * 3;
+      const R* pb = BD + (size_t)18 * it.x + i16 * 3;
 #pragma unroll
-      for (int u = 0; u < 16; u++)
-        if (kg + 4 * u < nk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+      for (int c = 0; c < 3; c++) { av[g][c] = on ? pa[c] : 0.0; bv[g][c] = on ? pb[c] : 0.0; }
     }
+#pragma unroll
+    for (int g = 0; g < 8; g++)
+      if (base + 4 * g < s1) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g][c], bv[g][c], acc, 0, 0, 0);
+      }
   }
   if (live) {
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) {
-      const int q = kq + 4 * reg, r = i16;
-      if (q < 6) {
-        R v = -acc[reg];
-        if (i1 == i2) v += contrib * (Hpp[(size_t)36 * i1 + q * 6 + r] + (q == r ? lambda : 0.0));
-        S[(size_t)(6 * i2 + q) * n + 6 * i1 + r] = v;
-      }
+      const int q = kq + 4 * reg;
+      if (q < 6) part[wv][q * 6 + i16] = acc[reg];
     }
+  }
+  __syncthreads();
+  if (threadIdx.x < 36) {
+    const int q = threadIdx.x / 6, r = threadIdx.x - 6 * q;
+    R v = 0;
+#pragma unroll
+    for (int w = 0; w < kSchurWaves; w++) v -= part[w][threadIdx.x];
+    if (i1 == i2) v += contrib * (Hpp[(size_t)36 * i1 + q * 6 + r] + (q == r ? lambda : 0.0));
+    S[(size_t)(6 * i2 + q) * n + 6 * i1 + r] = v;
   }
 }
 

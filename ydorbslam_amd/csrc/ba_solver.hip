@@ -307,7 +307,7 @@ int optimize(Run& R_, int iterations, int stage, bool reuse) {
         if (nPf)
           hipLaunchKernelGGL(k_bs, dim3(nPf), dim3(256), 0, s, Ed, c.poseStart.as<int>(), c.poseEdges.as<int>(), c.eLm.as<int>(), c.Hpl.as<double>(),
                              c.db.as<double>(), dbp, contrib, dbs);
-        hipLaunchKernelGGL(k_schur_pairs, dim3((nBuckets + 3) / 4 + 1), dim3(256), 0, s, c.pairStart.as<int>(), c.pairB.as<int2>(), nPf, nBuckets,
+        hipLaunchKernelGGL(k_schur_pairs, dim3(nBuckets + 1), dim3(64 * kSchurWaves), 0, s, c.pairStart.as<int>(), c.pairB.as<int2>(), nPf, nBuckets,
                            c.BD.as<double>(), c.Hpl.as<double>(), dHpp, lambda, contrib, n, dS, dbs);
         t.stop();
       }
