@@ -258,6 +258,9 @@ typedef struct YdBaResult {
 
 /* default options as the reference uses them */
 void ydorb_ba_default_options(YdBaOptions* opt);
+/* Re-entrant: every call takes one of 8 per-device contexts (own stream and scratch), so several host threads — several maps or
+ * sessions — may solve at once; a ninth concurrent caller waits.  Results do not depend on what else runs (fixed summation
+ * orders).  The reference itself calls localBundleAdjust from one thread (localMapping.cpp:29). */
 int ydorb_ba_solve(const YdBaProblem* prob, const YdBaOptions* opt, YdBaResult* res);
 /* dense SPD solve with the BA's blocked Cholesky (known-answer tests; A is n x n row-major, host pointers) */
 int ydorb_ba_dense_solve(int32_t device, const double* A, int32_t n, const double* b, double* x, int32_t* ok);

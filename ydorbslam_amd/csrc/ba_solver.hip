@@ -60,8 +60,13 @@ struct Ctx {  // per-device scratch, reused across calls (localBundleAdjust runs
   bool evInit = false;
   double* hPin = nullptr;   // pinned read-back area: scal[8] + status[2] (one stream sync per LM trial)
 };
-std::mutex g_mu;
-Ctx g_ctx[16];
+// A small pool of contexts per device: one localBundleAdjust at a time is the reference's use (LocalMapping thread), but the solve
+// is a latency chain that leaves most of the GPU idle, so several host threads (several maps / sessions) may solve concurrently,
+// each on its own stream and scratch.
+constexpr int kCtxPool = 8;
+std::mutex g_mu[16][kCtxPool];
+Ctx g_ctx[16][kCtxPool];
+std::mutex g_pick;
 
 struct Run {
   Ctx* c;
@@ -437,8 +442,15 @@ int ydorb_ba_solve(const YdBaProblem* P, const YdBaOptions* optIn, YdBaResult* r
   if (rc) return rc;
   g_t0 = std::chrono::steady_clock::now();
   trace("solve: begin");
-  std::lock_guard<std::mutex> lock(g_mu);
-  Ctx& c = g_ctx[O.device];
+  int slot = -1;
+  {
+    std::lock_guard<std::mutex> pick(g_pick);
+    for (int i = 0; i < kCtxPool && slot < 0; i++)
+      if (g_mu[O.device][i].try_lock()) slot = i;
+  }
+  if (slot < 0) { slot = 0; g_mu[O.device][0].lock(); }   // all busy: queue behind slot 0
+  std::lock_guard<std::mutex> lock(g_mu[O.device][slot], std::adopt_lock);
+  Ctx& c = g_ctx[O.device][slot];
   if (!c.stream) {
     c.device = O.device;
     HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
