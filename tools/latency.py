@@ -15,3 +15,23 @@ print("ydorb_extract 640x480 N=1000: %.3f ms per frame (H2D + kernels + D2H, hos
 ex.set_profiling(True)
 for i in range(50): ex.extract(img)
 print({k: round(v, 4) for k, v in ex.stage_times().items()})
+
+# one searchByProjectionInLastAndCurrentFrame-style call (mode 1): queries = the previous frame's keypoints
+from ydorbslam_amd.matcher import FrameView, OrbMatcher, QUERY_DTYPE
+k0, d0 = ex.extract(img); k1, d1 = ex.extract(img2)
+sf = 1.2 ** np.arange(8, dtype=np.float32)
+q = np.zeros(len(k0), QUERY_DTYPE)
+q["u"], q["v"] = k0["x"], k0["y"]
+q["r"] = (np.float32(15.0) * sf[k0["octave"]]).astype(np.float32)
+q["min_level"], q["max_level"] = k0["octave"] - 1, k0["octave"] + 1
+q["angle"], q["level"], q["flags"] = k0["angle"], k0["octave"], 3
+m = OrbMatcher(0.9, True)
+fv = FrameView(k1, d1, (0.0, 640.0, 0.0, 480.0))
+for _ in range(10): m.search_by_projection(1, fv, q, d0)
+t = time.perf_counter()
+for _ in range(N): nm, asg, tk = m.search_by_projection(1, fv, q, d0)
+dt = (time.perf_counter() - t) / N
+print("ydorb_search_by_projection mode 1, %d queries x %d keypoints: %.3f ms per call (%d matches)" % (len(q), len(k1), dt * 1e3, nm))
+m.set_profiling(True)
+for _ in range(20): m.search_by_projection(1, fv, q, d0)
+print({k: round(v, 4) for k, v in m.stage_times().items()})

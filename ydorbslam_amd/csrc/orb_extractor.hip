@@ -81,6 +81,7 @@ struct ydorb_extractor {
   int lastFrames = 0;
   // profiling
   bool profiling = false;
+  bool profPending = false;       // the stage events of the last launch have not been read yet
   bool forcePassQuadtree = false;  // YDORB_QT_PASS=1 at create: run every unit through the pass kernel (tests compare both)
   hipEvent_t ev[ST_COUNT + 1]{};
   double stageMs[ST_COUNT]{};
@@ -324,6 +325,8 @@ int ensurePlan(ydorb_extractor* e, int w, int h, int nFrames) {
   return YDORB_OK;
 }
 
+void collectProfile(ydorb_extractor* e);
+
 // Adapt the flat quad-tree kernel's LDS footprint to the scene: the device keeps the largest candidate count per level, the
 // copy-back at the end of every call brings it here (a call behind, which is fine — both kernels give the same keypoints).
 static void retuneQuadtree(ydorb_extractor* e) {
@@ -346,8 +349,14 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   retuneQuadtree(e);
   const HostPlan& P = e->plan;
   const PlanDev& D = P.dev;
-  const bool prof = e->profiling && s == e->stream;
-  if (prof) HIPCHK(hipEventRecord(e->ev[0], s));
+  // stage events go on whatever stream the work is launched on (so a pipelined caller gets the durations as they really are,
+  // other streams' kernels included); the previous launch's events are read first if they have completed — never waited for
+  const bool prof = e->profiling;
+  if (prof) {
+    if (e->profPending && hipEventQuery(e->ev[ST_COUNT]) == hipSuccess) collectProfile(e);
+    e->profPending = false;   // a launch whose events were not ready in time is dropped from the average
+    HIPCHK(hipEventRecord(e->ev[0], s));
+  }
   {
     const LevelDev& L0 = D.lv[0];
     dim3 g((L0.pitch / 4 + 63) / 64, (L0.h + 4 * kPyrRows - 1) / (4 * kPyrRows), nFrames);
@@ -407,7 +416,7 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   if (prof) HIPCHK(hipEventRecord(e->ev[4], s));
   hipLaunchKernelGGL(k_orient_describe, dim3(((D.sumQuota + 3) / 4 + 7) / 8 * 8, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
                      P.blurFrameStride, D, e->d_lvlKp, e->d_lvlCount, d_kps, d_desc, cap, d_nOut, e->d_lvlAngle);
-  if (prof) HIPCHK(hipEventRecord(e->ev[5], s));
+  if (prof) { HIPCHK(hipEventRecord(e->ev[5], s)); e->profPending = true; }
   HIPCHK(hipMemcpyAsync(e->h_lvlMaxN, e->d_lvlMaxN, sizeof(int) * kMaxLevels, hipMemcpyDeviceToHost, s));
   HIPCHK(hipGetLastError());
   e->lastFrames = nFrames;
@@ -422,7 +431,8 @@ int checkStatus(ydorb_extractor* e) {
 }
 
 void collectProfile(ydorb_extractor* e) {
-  if (!e->profiling) return;
+  if (!e->profiling || !e->profPending) return;
+  e->profPending = false;
   for (int i = 0; i < ST_COUNT; i++) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]) == hipSuccess) e->stageMs[i] += ms;
@@ -696,8 +706,8 @@ int ydorb_extractor_set_profiling(ydorb_extractor_t* e, int32_t on) {
 
 int ydorb_extractor_stage_times(ydorb_extractor_t* e, int32_t max_stages, const char** names, float* ms, int32_t* n_stages) {
   if (!e || !n_stages) return YDORB_ERR_INVALID_ARG;
-  if (e->profiling && e->stageCalls == 0 && e->lastFrames > 0) {  // device-resident path: collect after the caller synchronised
-    if (hipStreamSynchronize(e->stream) == hipSuccess) collectProfile(e);
+  if (e->profiling && e->profPending) {  // device-resident path: the last launch's events (may be on a caller's stream)
+    if (hipEventSynchronize(e->ev[ST_COUNT]) == hipSuccess) collectProfile(e);
   }
   const int n = std::min<int>(max_stages, ST_COUNT);
   for (int i = 0; i < n; i++) {

@@ -74,12 +74,13 @@ namespace {
 
 void collect(ydorb_matcher* m) {
   if (!m->profiling || !m->evPending) return;
+  m->evPending = false;
+  if (hipEventQuery(m->ev[MS_COUNT]) != hipSuccess) return;   // a pipelined caller launched again before the events completed: sample dropped, never waited for
   for (int i = 0; i < MS_COUNT; i++) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, m->ev[i], m->ev[i + 1]) == hipSuccess) m->stageMs[i] += ms;
   }
   m->stageCalls++;
-  m->evPending = false;
 }
 
 // misc layout: [0] poolHead (unsigned), [1] status (int), [2] count (int)
