@@ -241,7 +241,14 @@ typedef struct YdBaOptions {
   void* d_comm_buf;              /* device workspace the callback can address (e.g. a torch tensor), >= comm_doubles doubles */
   int64_t comm_doubles;
   int32_t rank, world;
+  int32_t flags;                 /* YDORB_BA_* bits below; 0 = localBundleAdjust's two-stage schedule */
+  int32_t reserved;
 } YdBaOptions;
+/* Optimizer::bundleAdjust / globalBundleAdjust (optimizer.cpp:7-137, :353-357) use the same graph and solver with ONE
+ * optimize(iters1) call: no chi2 cull, no second stage (edge_outlier is still filled with the chi2/depth test for the caller's
+ * information), Huber kernels optional (_bIsRobust) and delta_mono = (double)(float)sqrt(5.99) — note 5.99, :37. */
+#define YDORB_BA_SINGLE_STAGE 1
+#define YDORB_BA_NO_ROBUST 2
 
 typedef struct YdBaResult {
   int32_t n_trials;              /* LM trials executed (each = linearise/Schur/solve/update/chi2) */

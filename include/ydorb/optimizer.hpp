@@ -7,6 +7,7 @@
 #ifndef YDORB_ADAPTER_OPTIMIZER_HPP
 #define YDORB_ADAPTER_OPTIMIZER_HPP
 
+#include <cmath>
 #include <list>
 #include <map>
 #include <memory>
@@ -131,6 +132,92 @@ void localBundleAdjustImpl(KeyFramePtr kf0, MapPtr map, const volatile bool* sto
     pointMP[p]->setPosInWorld(X);
     pointMP[p]->updateNormalAndDepth();
   }
+}
+
+// Optimizer::bundleAdjust (optimizer.cpp:7-137): every given keyframe (id 0 fixed) and map point, ONE optimize(iterNum) call, Huber
+// optional; results go to the vertices' GBA fields when loopKeyFrameID != 0 (:113-136).  Same C ABI call with
+// YDORB_BA_SINGLE_STAGE; the body of
+//   void Optimizer::bundleAdjust(kfs, mps, iterNum, stop, loopKFid, robust)
+// becomes  ydorb::adapter::bundleAdjustImpl<Frame>(kfs, mps, iterNum, &stop == nullptr ? nullptr : &stop, loopKFid, robust);
+template <class FrameT, class KeyFramePtr, class MapPointPtr>
+void bundleAdjustImpl(const std::vector<KeyFramePtr>& kfs, const std::vector<MapPointPtr>& mps, int iterNum, const volatile bool* stop,
+                      long int loopKeyFrameID, bool robust) {
+  std::vector<KeyFramePtr> poseKF;
+  std::map<long int, int> poseIndex;
+  std::vector<double> poses;
+  std::vector<uint8_t> fixed;
+  long int maxKFid = 0;
+  for (const KeyFramePtr& k : kfs) {
+    if (k->isBad()) continue;
+    poseIndex[k->m_int_keyFrameID] = (int)poseKF.size();
+    poseKF.push_back(k);
+    poses.resize(poses.size() + 7);
+    poseToSE3Quat(k->getCameraPoseByTransform_c2w(), &poses[poses.size() - 7]);
+    fixed.push_back(k->m_int_keyFrameID == 0 ? 1 : 0);
+    if (k->m_int_keyFrameID > maxKFid) maxKFid = k->m_int_keyFrameID;
+  }
+  std::vector<double> points(3 * mps.size(), 0.0);
+  std::vector<uint8_t> excluded(mps.size(), 1);   // bad points and points without a usable observation stay untouched (:103-110)
+  std::vector<int32_t> ePose, ePoint;
+  std::vector<double> eMeas, eInfo;
+  for (size_t p = 0; p < mps.size(); p++) {
+    if (!mps[p] || mps[p]->isBad()) continue;
+    const cv::Mat X = mps[p]->getPosInWorld();
+    for (int d = 0; d < 3; d++) points[3 * p + d] = X.at<float>(d);
+    for (const auto& ob : mps[p]->getObservations()) {
+      if (ob.first->isBad() || ob.first->m_int_keyFrameID > maxKFid) continue;
+      const auto it = poseIndex.find(ob.first->m_int_keyFrameID);
+      if (it == poseIndex.end()) continue;   // g2o: optimizer.vertex(id) == nullptr -> the edge cannot be added
+      const cv::KeyPoint& kp = ob.first->m_v_keyPoints[ob.second];
+      const float ur = ob.first->m_v_rightXcords[ob.second];
+      ePose.push_back(it->second); ePoint.push_back((int32_t)p);
+      eMeas.push_back(kp.pt.x); eMeas.push_back(kp.pt.y); eMeas.push_back(ur < 0 ? -1.0 : (double)ur);
+      eInfo.push_back(ob.first->m_v_invScaleFactorSquares[kp.octave]);
+      excluded[p] = 0;
+    }
+  }
+  YdBaProblem P{};
+  P.n_poses = (int32_t)poseKF.size(); P.n_points = (int32_t)mps.size(); P.n_edges = (int32_t)ePose.size();
+  P.poses = poses.data(); P.pose_fixed = fixed.data(); P.points = points.data();
+  P.edge_pose = ePose.data(); P.edge_point = ePoint.data(); P.edge_meas = eMeas.data(); P.edge_inv_sigma2 = eInfo.data();
+  P.fx = FrameT::m_flt_fx; P.fy = FrameT::m_flt_fy; P.cx = FrameT::m_flt_cx; P.cy = FrameT::m_flt_cy; P.bf = FrameT::m_flt_baseLineTimesFx;
+  P.stop = reinterpret_cast<const volatile uint8_t*>(stop);
+  YdBaOptions O;
+  ydorb_ba_default_options(&O);
+  O.iters1 = iterNum; O.iters2 = 0;
+  O.delta_mono = (double)(float)std::sqrt(5.99);   // `const float monoDelta = sqrt(5.99)`, :37
+  O.flags = YDORB_BA_SINGLE_STAGE | (robust ? 0 : YDORB_BA_NO_ROBUST);
+  YdBaResult res{};
+  if (ydorb_ba_solve(&P, &O, &res) != YDORB_OK) throw std::runtime_error(std::string("ydorb: ") + ydorb_last_error());
+  for (size_t k = 0; k < poseKF.size(); k++) {   // :113-124
+    const cv::Mat T = se3QuatToPose(&poses[7 * k]);
+    if (loopKeyFrameID == 0) {
+      poseKF[k]->setCameraPoseByTransform_c2w(T);
+    } else {
+      poseKF[k]->m_cvMat_T_c2w_GlobalBA.create(4, 4, CV_32F);
+      T.copyTo(poseKF[k]->m_cvMat_T_c2w_GlobalBA);
+      poseKF[k]->m_int_globalBAForKeyFrameID = loopKeyFrameID;
+    }
+  }
+  for (size_t p = 0; p < mps.size(); p++) {     // :126-136
+    if (!mps[p] || mps[p]->isBad() || excluded[p]) continue;
+    cv::Mat X(3, 1, CV_32F);
+    for (int d = 0; d < 3; d++) X.at<float>(d) = (float)points[3 * p + d];
+    if (loopKeyFrameID == 0) {
+      mps[p]->setPosInWorld(X);
+      mps[p]->updateNormalAndDepth();
+    } else {
+      mps[p]->m_cvMat_posGlobalBA.create(3, 1, CV_32F);
+      X.copyTo(mps[p]->m_cvMat_posGlobalBA);
+      mps[p]->m_int_globalBAforKeyFrameID = loopKeyFrameID;
+    }
+  }
+}
+
+// Optimizer::globalBundleAdjust (optimizer.cpp:353-357)
+template <class FrameT, class MapPtr>
+void globalBundleAdjustImpl(MapPtr map, int iterNum, const volatile bool* stop, long int loopKeyFrameID, bool robust) {
+  bundleAdjustImpl<FrameT>(map->getAllKeyFrames(), map->getAllMapPoints(), iterNum, stop, loopKeyFrameID, robust);
 }
 
 }  // namespace adapter

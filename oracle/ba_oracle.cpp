@@ -237,7 +237,7 @@ void cholSolve(const std::vector<R>& l, int n, const R* b, R* x) {
 struct Options {
   int32_t iters1, iters2;
   double chi2Mono, chi2Stereo, deltaMono, deltaStereo;
-  int32_t maxTrials, reserved;
+  int32_t maxTrials, flags;   // flags: 1 = single stage (Optimizer::bundleAdjust, optimizer.cpp:7-137), 2 = no Huber kernels (_bIsRobust false)
 };
 struct IterLog { double chi2, lambda; int32_t trials, stage; };
 
@@ -457,12 +457,12 @@ int yo_ba_solve(int K, int P, int E, double* poses, const uint8_t* poseFixed, do
   S.cam = {camera5[0], camera5[1], camera5[2], camera5[3], camera5[4]};
   S.stop = stop;
   S.opt = *(const Options*)options;
-  S.level.assign(E, 0); S.robust.assign(E, 1); S.err.assign((size_t)3 * E, 0.0);
+  S.level.assign(E, 0); S.robust.assign(E, (S.opt.flags & 2) ? 0 : 1); S.err.assign((size_t)3 * E, 0.0);
   if (nLog) *nLog = 0;
   if (S.stopped()) return 0;  // optimizer.cpp:284-286
   S.optimize(S.opt.iters1, 1);
   auto depthPositive = [&](int e) { return add(qrot(S.poses[ePose[e]].q, S.pts[ePoint[e]]), S.poses[ePose[e]].t).z > 0.0; };
-  if (!S.stopped()) {  // optimizer.cpp:290-314
+  if (!(S.opt.flags & 1) && !S.stopped()) {  // optimizer.cpp:290-314 (bundleAdjust, :7-137, has no cull and no second stage)
     for (int e = 0; e < E; e++) {
       const double th = S.isStereo(e) ? S.opt.chi2Stereo : S.opt.chi2Mono;
       if (S.chi2Of(e) > th || !depthPositive(e)) S.level[e] = 1;

@@ -258,7 +258,7 @@ def search_by_bow(mode, kps_a, desc_a, valid_a, fv_a, kps_b, desc_b, valid_b, fv
 # local-BA oracle (oracle/ba_oracle.cpp)
 # ---------------------------------------------------------------------------------------------
 BA_OPTIONS_DTYPE = np.dtype([("iters1", "<i4"), ("iters2", "<i4"), ("chi2_mono", "<f8"), ("chi2_stereo", "<f8"),
-                             ("delta_mono", "<f8"), ("delta_stereo", "<f8"), ("max_trials", "<i4"), ("reserved", "<i4")])
+                             ("delta_mono", "<f8"), ("delta_stereo", "<f8"), ("max_trials", "<i4"), ("flags", "<i4")])   # flags: 1 single stage (bundleAdjust), 2 no Huber
 
 
 def ba_default_options(iters1=5, iters2=10):
@@ -268,6 +268,14 @@ def ba_default_options(iters1=5, iters2=10):
     o["delta_mono"] = float(np.float32(np.sqrt(5.991)))                  # `const float monoDelta = sqrt(5.991)`, :223
     o["delta_stereo"] = float(np.float32(np.sqrt(7.815)))
     o["max_trials"] = 10                                                 # levenberg.cpp:50
+    return o
+
+
+def ba_global_options(iters=5, robust=True):
+    """Optimizer::bundleAdjust / globalBundleAdjust (optimizer.cpp:7-137): one optimize(iters), Huber deltas sqrt(5.99) / sqrt(7.815)."""
+    o = ba_default_options(iters, 0)
+    o["delta_mono"] = float(np.float32(np.sqrt(5.99)))                   # `const float monoDelta = sqrt(5.99)`, :37
+    o["flags"] = 1 | (0 if robust else 2)
     return o
 
 

@@ -16,7 +16,7 @@ struct KeyFrame;
 struct Frame;
 struct MapPoint {
   bool m_b_isTrackInView; int m_int_trackScaleLevel; float m_flt_trackViewCos, m_flt_trackProjX, m_flt_trackProjY, m_flt_trackProjRightX;
-  long int m_int_localBAForKeyFrameID;
+  long int m_int_localBAForKeyFrameID, m_int_globalBAforKeyFrameID; cv::Mat m_cvMat_posGlobalBA;
   bool isBad(); int getObservationsNum(); cv::Mat getDescriptor(); cv::Mat getPosInWorld();
   float getMaxDistanceInvariance(); float getMinDistanceInvariance(); int predictScaleLevel(const float&, const Frame&);
   std::map<std::shared_ptr<KeyFrame>, int> getObservations(); void eraseObservation(std::shared_ptr<KeyFrame>);
@@ -32,11 +32,14 @@ struct Frame {
 };
 struct KeyFrame {
   std::vector<cv::KeyPoint> m_v_keyPoints; cv::Mat m_cvMat_descriptors; FeatureVector m_bow_keyPointsVec; std::vector<float> m_v_rightXcords, m_v_invScaleFactorSquares;
-  long int m_int_keyFrameID, m_int_localBAForKeyFrameID, m_int_fixedBAForKeyFrameID;
+  long int m_int_keyFrameID, m_int_localBAForKeyFrameID, m_int_fixedBAForKeyFrameID, m_int_globalBAForKeyFrameID; cv::Mat m_cvMat_T_c2w_GlobalBA;
   std::vector<std::shared_ptr<MapPoint>> getMatchedMapPointsVec(); std::vector<std::shared_ptr<KeyFrame>> getOrderedConnectedKeyFrames();
   bool isBad(); cv::Mat getCameraPoseByTransform_c2w(); void setCameraPoseByTransform_c2w(cv::Mat); void eraseMatchedMapPoint(std::shared_ptr<MapPoint>);
 };
-struct Map { std::mutex m_mutex_updateMap; };
+struct Map {
+  std::mutex m_mutex_updateMap;
+  std::vector<std::shared_ptr<KeyFrame>> getAllKeyFrames(); std::vector<std::shared_ptr<MapPoint>> getAllMapPoints();
+};
 
 namespace ya = ydorb::adapter;
 int check(Frame& a, Frame& b, std::shared_ptr<KeyFrame> kf, std::shared_ptr<KeyFrame> kf2, std::vector<std::shared_ptr<MapPoint>>& mps,
@@ -50,6 +53,8 @@ int check(Frame& a, Frame& b, std::shared_ptr<KeyFrame> kf, std::shared_ptr<KeyF
 #ifdef YDORB_CHECK_OPTIMIZER
   bool stop = false;
   ya::localBundleAdjustImpl<std::shared_ptr<KeyFrame>, std::shared_ptr<Map>, Frame>(kf, std::make_shared<Map>(), &stop);
+  ya::bundleAdjustImpl<Frame>(std::vector<std::shared_ptr<KeyFrame>>{kf, kf2}, mps, 10, &stop, 0L, true);
+  ya::globalBundleAdjustImpl<Frame>(std::make_shared<Map>(), 10, nullptr, 7L, false);
 #endif
   return n;
 }

@@ -24,6 +24,7 @@ struct Mat {
   template <class T> T& at(int, int); template <class T> const T& at(int, int) const;
   template <class T> T* ptr(); template <class T> const T* ptr() const;
   void copyTo(Mat) const;
+  void create(int, int, int);
   void copyTo(const _OutputArray&) const;
   static MatExpr eye(int, int, int);
 };

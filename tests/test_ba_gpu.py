@@ -100,3 +100,22 @@ def test_concurrent_solves_use_separate_contexts(oracle_lib):
         assert np.array_equal(g["outlier"], r["outlier"])
         assert g["poses"].tobytes() == r["poses"].tobytes() and g["points"].tobytes() == r["points"].tobytes()
         assert g["log"].tobytes() == r["log"].tobytes()
+
+
+@pytest.mark.parametrize("robust", [True, False])
+def test_global_bundle_adjust_single_stage(oracle_lib, robust):
+    """Optimizer::bundleAdjust / globalBundleAdjust (optimizer.cpp:7-137, :353-357): same graph, ONE optimize(iterNum) call, no chi2
+    cull, Huber optional with delta sqrt(5.99) — the §8(f) row that re-uses the local-BA kernels unchanged."""
+    import ydorbslam_amd as y
+    prob = synth_ba_problem(30, 2500, 6, seed=11, outlier_frac=0.03, mono_frac=0.3, n_fixed=1)
+    ref = oracle_lib.ba_solve(prob, oracle_lib.ba_global_options(10, robust))
+    got = y.Optimizer.local_bundle_adjust(prob, y.Optimizer.global_options(10, robust))
+    assert got["trials"] == ref["trials"] and len(got["log"]) == len(ref["log"])
+    assert set(got["log"][:, 3]) == {1.0}                                           # one stage only
+    assert np.allclose(got["log"][:, :2], ref["log"][:, :2], rtol=1e-6, atol=0)
+    assert np.array_equal(got["log"][:, 2:], ref["log"][:, 2:])
+    assert np.array_equal(got["outlier"], ref["outlier"])
+    assert np.allclose(got["poses"].astype(np.float32), ref["poses"].astype(np.float32), rtol=1e-4, atol=1e-6)
+    assert np.allclose(got["points"].astype(np.float32), ref["points"].astype(np.float32), rtol=1e-4, atol=1e-6)
+    two = y.Optimizer.local_bundle_adjust(prob)                                     # the two-stage schedule is a different run
+    assert len(two["log"]) != len(got["log"]) or not np.allclose(two["log"][:, 0], got["log"][:, 0])

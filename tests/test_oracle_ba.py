@@ -118,3 +118,16 @@ def test_outliers_are_culled_and_stop_flag(oracle_lib):
     stop = np.ones(1, np.uint8)
     r2 = oracle_lib.ba_solve(prob, stop=stop)
     assert r2["trials"] == 0 and np.array_equal(r2["poses"], prob["poses"])              # optimizer.cpp:284-286
+
+
+def test_single_stage_global_ba_options(oracle_lib):
+    """bundleAdjust (optimizer.cpp:7-137): one optimize(iters) call — every log row is stage 1, at most `iters` outer iterations,
+    the robust chi2 never increases, and switching the Huber kernels off changes the cost that is minimised."""
+    prob = synth_ba_problem(10, 300, 5, seed=21, outlier_frac=0.05)
+    r = oracle_lib.ba_solve(prob, oracle_lib.ba_global_options(7, True))
+    assert 1 <= len(r["log"]) <= 7 and set(r["log"][:, 3]) == {1.0}
+    assert np.all(np.diff(r["log"][:, 0]) <= 1e-9 * r["log"][0, 0])
+    n = oracle_lib.ba_solve(prob, oracle_lib.ba_global_options(7, False))
+    assert n["log"][0, 0] > r["log"][0, 0]            # plain chi2 of the outliers exceeds their Huber cost
+    two = oracle_lib.ba_solve(prob)
+    assert set(two["log"][:, 3]) == {1.0, 2.0}

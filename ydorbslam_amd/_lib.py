@@ -81,7 +81,10 @@ class YdBaOptions(C.Structure):
     _fields_ = [("iters1", _I), ("iters2", _I), ("chi2_mono", C.c_double), ("chi2_stereo", C.c_double),
                 ("delta_mono", C.c_double), ("delta_stereo", C.c_double), ("max_trials", _I), ("device", _I),
                 ("allreduce", BA_ALLREDUCE_FN), ("allreduce_user", _VP), ("d_comm_buf", _VP), ("comm_doubles", C.c_int64),
-                ("rank", _I), ("world", _I)]
+                ("rank", _I), ("world", _I), ("flags", _I), ("reserved", _I)]
+
+
+BA_SINGLE_STAGE, BA_NO_ROBUST = 1, 2
 
 
 class YdBaResult(C.Structure):

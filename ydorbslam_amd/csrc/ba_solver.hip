@@ -459,7 +459,7 @@ int ydorb_ba_solve(const YdBaProblem* P, const YdBaOptions* optIn, YdBaResult* r
   }
   Run R_{&c, P, &O, res};
   R_.level.assign(E, 0);
-  R_.robust.assign(E, 1);
+  R_.robust.assign(E, (O.flags & YDORB_BA_NO_ROBUST) ? 0 : 1);
   R_.err.assign((size_t)3 * E, 0.0);
   R_.cam = Cam{P->fx, P->fy, P->cx, P->cy, P->bf};
   for (int i = 0; i < 2; i++)
@@ -488,7 +488,9 @@ int ydorb_ba_solve(const YdBaProblem* P, const YdBaOptions* optIn, YdBaResult* r
     return P->edge_inv_sigma2[e] * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
   };
   std::vector<double> depth;
-  if (!R_.stopped()) {  // optimizer.cpp:290-314
+  if (O.flags & YDORB_BA_SINGLE_STAGE) {
+    // bundleAdjust: one optimize() call, nothing culled
+  } else if (!R_.stopped()) {  // optimizer.cpp:290-314
     if ((rc = edgeDepths(R_, depth))) return rc;
     trace("solve: depths read");
     for (int e = 0; e < E; e++) {

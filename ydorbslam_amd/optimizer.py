@@ -21,6 +21,16 @@ class Optimizer:
         return o
 
     @staticmethod
+    def global_options(iters=5, robust=True, device=0):
+        """Options of Optimizer::bundleAdjust / globalBundleAdjust (optimizer.cpp:7-137, :353-357): one optimize(iters) call."""
+        from ._lib import BA_NO_ROBUST, BA_SINGLE_STAGE
+        o = Optimizer.default_options(device)
+        o.iters1, o.iters2 = iters, 0
+        o.delta_mono = float(np.float32(np.sqrt(5.99)))    # `const float monoDelta = sqrt(5.99)`, :37
+        o.flags = BA_SINGLE_STAGE | (0 if robust else BA_NO_ROBUST)
+        return o
+
+    @staticmethod
     def local_bundle_adjust(prob, options=None, stop=None, allreduce=None, comm_tensor_ptr=None, comm_doubles=0, rank=0, world=1):
         """prob: dict(poses[K,7], fixed[K], points[P,3], edge_pose, edge_point, meas[E,3], info[E], camera[5]).
         Returns dict(poses, points, outlier, log (chi2, lambda, trials, stage), trials, iterations, ms)."""
