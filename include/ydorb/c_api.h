@@ -269,6 +269,28 @@ void ydorb_ba_default_options(YdBaOptions* opt);
  * sessions — may solve at once; a ninth concurrent caller waits.  Results do not depend on what else runs (fixed summation
  * orders).  The reference itself calls localBundleAdjust from one thread (localMapping.cpp:29). */
 int ydorb_ba_solve(const YdBaProblem* prob, const YdBaOptions* opt, YdBaResult* res);
+
+/* ------------------------------------------------------------------------------------------
+ * Pose-only optimisation.  Replaces YDORBSLAM::Optimizer::optimizePose (src/optimizer.cpp:358-501) — the
+ * Tracking thread calls it 1-3x per frame right after a match (tracking.cpp:386,466,611).  A batch of frames is solved in one
+ * launch, one workgroup per frame running all four episodes.  Frame f owns edges [edge_start[f], edge_start[f+1]): one per
+ * keypoint that has a map point; points = MapPoint::getPosInWorld() (world), meas = (kp.x, kp.y, rightX or < 0 for monocular),
+ * inv_sigma2 = m_v_invScaleFactorSquares[kp.octave].  poses [n][7] = (t, unit q) of T_c2w, in/out.
+ * Outputs: outlier[e] = Frame::m_v_isOutliers of the edge's keypoint, n_inliers[f] = the function's return value
+ * (initialCorrespondenceNum - badNum; 0 and an untouched pose when a frame has < 3 edges), optional chi2_log [n][4] (robust chi2
+ * after each episode, NaN where an episode did not run) and trials [n] (LM trials executed). */
+typedef struct YdPoseBatch {
+  int32_t n_frames;
+  int32_t device;
+  const int32_t* edge_start;     /* [n_frames + 1] */
+  double* poses;                 /* [n_frames][7] in/out */
+  const double* points;          /* [n_edges][3] */
+  const double* meas;            /* [n_edges][3] */
+  const double* inv_sigma2;      /* [n_edges] */
+  double fx, fy, cx, cy, bf;
+} YdPoseBatch;
+int ydorb_pose_optimize(const YdPoseBatch* batch, uint8_t* outlier, int32_t* n_inliers, double* chi2_log, int32_t* trials);
+
 /* dense SPD solve with the BA's blocked Cholesky (known-answer tests; A is n x n row-major, host pointers) */
 int ydorb_ba_dense_solve(int32_t device, const double* A, int32_t n, const double* b, double* x, int32_t* ok);
 

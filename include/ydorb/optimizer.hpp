@@ -214,6 +214,41 @@ void bundleAdjustImpl(const std::vector<KeyFramePtr>& kfs, const std::vector<Map
   }
 }
 
+// Optimizer::optimizePose (optimizer.cpp:358-501): pose-only refinement of one frame against its matched map points; returns the
+// number of inliers and updates Frame::m_v_isOutliers and the frame pose exactly where the reference does.  The body of
+//   int Optimizer::optimizePose(Frame& frame)   becomes   return ydorb::adapter::optimizePoseImpl(frame);
+// (A tracker that refines several frames at once — replay, multi-camera rigs — can hand them to ydorb_pose_optimize as one batch:
+// one workgroup per frame, 64 frames cost about as much as one.)
+template <class FrameT>
+int optimizePoseImpl(FrameT& frame) {
+  std::vector<int> idx;
+  std::vector<double> X, z, w;
+  for (int i = 0; i < frame.m_int_keyPointsNum; i++) {
+    if (!frame.m_v_sptrMapPoints[i]) continue;
+    frame.m_v_isOutliers[i] = false;                       // :392
+    const cv::KeyPoint& kp = frame.m_v_keyPoints[i];
+    const cv::Mat Xw = frame.m_v_sptrMapPoints[i]->getPosInWorld();
+    for (int d = 0; d < 3; d++) X.push_back(Xw.at<float>(d));
+    const float ur = frame.m_v_rightXcords[i];
+    z.push_back(kp.pt.x); z.push_back(kp.pt.y); z.push_back(ur < 0 ? -1.0 : (double)ur);
+    w.push_back(frame.m_v_invScaleFactorSquares[kp.octave]);
+    idx.push_back(i);
+  }
+  if (idx.size() < 3) return 0;                            // :443-445
+  double pose[7];
+  poseToSE3Quat(frame.getCameraPoseByTransform_c2w(), pose);
+  const int32_t start[2] = {0, (int32_t)idx.size()};
+  YdPoseBatch B{};
+  B.n_frames = 1; B.device = 0; B.edge_start = start; B.poses = pose; B.points = X.data(); B.meas = z.data(); B.inv_sigma2 = w.data();
+  B.fx = FrameT::m_flt_fx; B.fy = FrameT::m_flt_fy; B.cx = FrameT::m_flt_cx; B.cy = FrameT::m_flt_cy; B.bf = FrameT::m_flt_baseLineTimesFx;
+  std::vector<uint8_t> outlier(idx.size());
+  int32_t inliers = 0;
+  if (ydorb_pose_optimize(&B, outlier.data(), &inliers, nullptr, nullptr) != YDORB_OK) throw std::runtime_error(std::string("ydorb: ") + ydorb_last_error());
+  for (size_t k = 0; k < idx.size(); k++) frame.m_v_isOutliers[idx[k]] = outlier[k] != 0;
+  frame.setCameraPoseByTransform_c2w(se3QuatToPose(pose));  // :498-499
+  return inliers;
+}
+
 // Optimizer::globalBundleAdjust (optimizer.cpp:353-357)
 template <class FrameT, class MapPtr>
 void globalBundleAdjustImpl(MapPtr map, int iterNum, const volatile bool* stop, long int loopKeyFrameID, bool robust) {

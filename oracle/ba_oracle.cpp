@@ -513,4 +513,119 @@ int yo_ba_chol_solve(const double* A, int n, const double* b, double* x) {
   return 1;
 }
 void yo_ba_huber(double e, double delta, double* rho2) { huber(e, delta, rho2, rho2 + 1); }
+
+// ---- Optimizer::optimizePose (reference src/optimizer.cpp:358-501): pose-only LM on unary edges --------------------------------
+// g2o pieces: EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose (types_six_dof_expmap.h:230-320, .cpp:415-494: the
+// Jacobians use invz products, unlike the binary edges), BaseUnaryEdge::constructQuadraticForm, LinearSolverDense
+// (solvers/dense/linear_solver_dense.h:66-109: dense 6x6 Cholesky, failure when not positive), the same Levenberg loop.
+// pose7 in/out (tx,ty,tz,qx,qy,qz,qw); Xw [E][3]; meas [E][3] (ur < 0: monocular); info [E]; outlier [E] out.
+// Returns initialCorrespondenceNum - badNum (:500), or 0 without touching anything when E < 3 (:443-445).
+// chi2Log: [4] robust chi2 after each episode's optimize (NaN when the episode did not run).
+int yo_pose_optimize(double* pose7, int E, const double* Xw, const double* meas, const double* info, const double* camera5,
+                     uint8_t* outlier, double* chi2Log, int* trialsOut) {
+  if (trialsOut) *trialsOut = 0;
+  for (int k = 0; k < 4; k++) if (chi2Log) chi2Log[k] = std::numeric_limits<double>::quiet_NaN();
+  if (E < 3) return 0;
+  const Cam cam{camera5[0], camera5[1], camera5[2], camera5[3], camera5[4]};
+  const R deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);   // :381-382
+  Pose init{{pose7[0], pose7[1], pose7[2]}, {pose7[3], pose7[4], pose7[5], pose7[6]}};
+  qnormalize(init.q);
+  Pose T = init;
+  std::vector<uint8_t> level(E, 0), robust(E, 1);
+  std::vector<R> err((size_t)3 * E, 0.0);
+  for (int e = 0; e < E; e++) outlier[e] = 0;
+  auto stereoOf = [&](int e) { return meas[3 * e + 2] >= 0; };
+  auto errOf = [&](int e) { R d; residual(T, {Xw[3 * e], Xw[3 * e + 1], Xw[3 * e + 2]}, &meas[3 * e], stereoOf(e), cam, &err[3 * e], &d); };
+  auto chi2Of = [&](int e) { const R* r = &err[3 * e]; return info[e] * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]); };
+  int bad = 0, trials = 0;
+  for (int epi = 0; epi < 4; epi++) {
+    T = init;                                   // setEstimate(frame pose) at the top of every episode (:455)
+    std::vector<int> act;
+    for (int e = 0; e < E; e++) if (!level[e]) act.push_back(e);
+    auto robustChi2 = [&]() {
+      R chi = 0;
+      for (int e : act) {
+        const R c = chi2Of(e);
+        if (robust[e]) { R r0, r1; huber(c, stereoOf(e) ? deltaStereo : deltaMono, &r0, &r1); chi += r0; } else chi += c;
+      }
+      return chi;
+    };
+    if (!act.empty()) {                          // optimize(10), :457
+      R lambda = 0, ni = 2, currentChi = 0;
+      for (int it = 0; it < 10; it++) {
+        for (int e : act) errOf(e);
+        currentChi = robustChi2();
+        R H[6][6] = {{0}}, b[6] = {0};
+        for (int e : act) {
+          const bool st = stereoOf(e);
+          const int D = st ? 3 : 2;
+          const V3 p = add(qrot(T.q, V3{Xw[3 * e], Xw[3 * e + 1], Xw[3 * e + 2]}), T.t);
+          const R x = p.x, y = p.y, invz = 1.0 / p.z, invz2 = invz * invz;
+          R J[3][6];
+          J[0][0] = x * y * invz2 * cam.fx; J[0][1] = -(1 + (x * x * invz2)) * cam.fx; J[0][2] = y * invz * cam.fx;
+          J[0][3] = -invz * cam.fx; J[0][4] = 0; J[0][5] = x * invz2 * cam.fx;
+          J[1][0] = (1 + y * y * invz2) * cam.fy; J[1][1] = -x * y * invz2 * cam.fy; J[1][2] = -x * invz * cam.fy;
+          J[1][3] = 0; J[1][4] = -invz * cam.fy; J[1][5] = y * invz2 * cam.fy;
+          if (st) {
+            J[2][0] = J[0][0] - cam.bf * y * invz2; J[2][1] = J[0][1] + cam.bf * x * invz2; J[2][2] = J[0][2];
+            J[2][3] = J[0][3]; J[2][4] = 0; J[2][5] = J[0][5] - cam.bf * invz2;
+          }
+          R rho1 = 1;
+          if (robust[e]) { R r0; huber(chi2Of(e), st ? deltaStereo : deltaMono, &r0, &rho1); }
+          const R w = info[e], W = rho1 * w;
+          for (int r = 0; r < 6; r++) {
+            for (int c = 0; c < 6; c++) { R s2 = 0; for (int d = 0; d < D; d++) s2 += J[d][r] * W * J[d][c]; H[r][c] += s2; }
+            R s1 = 0;
+            for (int d = 0; d < D; d++) s1 += J[d][r] * (-w * err[3 * e + d] * rho1);
+            b[r] += s1;
+          }
+        }
+        if (it == 0) { R mx = 0; for (int i = 0; i < 6; i++) mx = std::max(fabs(H[i][i]), mx); lambda = 1e-5 * mx; ni = 2; }
+        R rho = 0, x6[6] = {0, 0, 0, 0, 0, 0};
+        int qmax = 0;
+        do {
+          const Pose bak = T;
+          std::vector<R> A(36);
+          for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) A[r * 6 + c] = H[r][c] + (r == c ? lambda : 0.0);
+          const bool ok = cholesky(A, 6);
+          if (ok) cholSolve(A, 6, b, x6);
+          T = poseOplus(T, x6);
+          for (int e : act) errOf(e);
+          R tempChi = robustChi2();
+          if (!ok) tempChi = std::numeric_limits<R>::max();
+          rho = currentChi - tempChi;
+          R sc = 1e-3;
+          for (int j = 0; j < 6; j++) sc += x6[j] * (lambda * x6[j] + b[j]);
+          rho /= sc;
+          if (rho > 0 && std::isfinite(tempChi)) {
+            R alpha = 1. - pow((2 * rho - 1), 3);
+            alpha = std::min(alpha, 2. / 3.);
+            lambda *= std::max(1. / 3., alpha);
+            ni = 2;
+            currentChi = tempChi;
+          } else {
+            lambda *= ni; ni *= 2;
+            T = bak;
+            if (!std::isfinite(lambda)) { qmax++; trials++; break; }
+          }
+          qmax++; trials++;
+        } while (rho < 0 && qmax < 10);
+        if (qmax == 10 || rho == 0 || !std::isfinite(lambda)) break;
+      }
+      if (chi2Log) chi2Log[epi] = currentChi;
+    }
+    bad = 0;                                     // classification, :458-493
+    for (int e = 0; e < E; e++) {
+      if (outlier[e]) errOf(e);                  // inactive edges carry a stale error: refreshed with the episode's final pose
+      const float c2 = (float)chi2Of(e);
+      const float th = stereoOf(e) ? 7.815f : 5.991f;
+      if (c2 > th) { outlier[e] = 1; level[e] = 1; bad++; } else { outlier[e] = 0; level[e] = 0; }
+      if (epi == 2) robust[e] = 0;
+    }
+    if (E < 10) break;                           // optimizer.edges().size() < 10, :494
+  }
+  pose7[0] = T.t.x; pose7[1] = T.t.y; pose7[2] = T.t.z; pose7[3] = T.q.x; pose7[4] = T.q.y; pose7[5] = T.q.z; pose7[6] = T.q.w;
+  if (trialsOut) *trialsOut = trials;
+  return E - bad;
+}
 }

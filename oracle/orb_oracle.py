@@ -296,3 +296,19 @@ def ba_solve(prob, options=None, stop=None):
     trials = lib().yo_ba_solve(len(poses), len(points), E, _p(poses), _p(fixed), _p(points), _p(ep), _p(eq), _p(meas), _p(info), _p(cam),
                                stop_p, _p(o), _p(outlier), _p(log), 64, C.byref(nlog))
     return dict(poses=poses, points=points, outlier=outlier, log=log[:nlog.value].copy(), trials=trials)
+
+
+def pose_optimize(prob):
+    """Optimizer::optimizePose restated (oracle/ba_oracle.cpp::yo_pose_optimize).  prob: ydorbslam_amd.synth.synth_pose_problem dict.
+    Returns dict(pose, outlier, inliers, chi2 (per episode), trials)."""
+    pose = np.ascontiguousarray(prob["pose"], np.float64).copy()
+    X = np.ascontiguousarray(prob["points"], np.float64); z = np.ascontiguousarray(prob["meas"], np.float64)
+    w = np.ascontiguousarray(prob["info"], np.float64); cam = np.ascontiguousarray(prob["camera"], np.float64)
+    E = len(w)
+    outlier = np.zeros(max(E, 1), np.uint8)
+    chi = np.zeros(4, np.float64)
+    trials = C.c_int(0)
+    L = lib()
+    L.yo_pose_optimize.restype = C.c_int
+    n = L.yo_pose_optimize(_p(pose), E, _p(X), _p(z), _p(w), _p(cam), _p(outlier), _p(chi), C.byref(trials))
+    return dict(pose=pose, outlier=outlier[:E], inliers=n, chi2=chi, trials=trials.value)

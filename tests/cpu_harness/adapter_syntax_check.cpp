@@ -26,7 +26,8 @@ typedef std::map<unsigned, std::vector<unsigned>> FeatureVector;
 struct Frame {
   std::vector<cv::KeyPoint> m_v_keyPoints; cv::Mat m_cvMat_descriptors; std::vector<float> m_v_rightXcords, m_v_scaleFactors;
   std::vector<std::shared_ptr<MapPoint>> m_v_sptrMapPoints; std::vector<bool> m_v_isOutliers; cv::Mat m_cvMat_T_c2w;
-  int m_int_keyPointsNum; FeatureVector m_bow_keyPointsVec;
+  int m_int_keyPointsNum; FeatureVector m_bow_keyPointsVec; std::vector<float> m_v_invScaleFactorSquares;
+  cv::Mat getCameraPoseByTransform_c2w(); void setCameraPoseByTransform_c2w(cv::Mat);
   static float m_flt_minX, m_flt_maxX, m_flt_minY, m_flt_maxY, m_flt_fx, m_flt_fy, m_flt_cx, m_flt_cy, m_flt_baseLine, m_flt_baseLineTimesFx;
   bool isInImage(const float&, const float&) const;
 };
@@ -55,6 +56,7 @@ int check(Frame& a, Frame& b, std::shared_ptr<KeyFrame> kf, std::shared_ptr<KeyF
   ya::localBundleAdjustImpl<std::shared_ptr<KeyFrame>, std::shared_ptr<Map>, Frame>(kf, std::make_shared<Map>(), &stop);
   ya::bundleAdjustImpl<Frame>(std::vector<std::shared_ptr<KeyFrame>>{kf, kf2}, mps, 10, &stop, 0L, true);
   ya::globalBundleAdjustImpl<Frame>(std::make_shared<Map>(), 10, nullptr, 7L, false);
+  n += ya::optimizePoseImpl(a);
 #endif
   return n;
 }

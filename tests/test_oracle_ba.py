@@ -131,3 +131,25 @@ def test_single_stage_global_ba_options(oracle_lib):
     assert n["log"][0, 0] > r["log"][0, 0]            # plain chi2 of the outliers exceeds their Huber cost
     two = oracle_lib.ba_solve(prob)
     assert set(two["log"][:, 3]) == {1.0, 2.0}
+
+
+def test_pose_only_optimisation_oracle(oracle_lib):
+    """Optimizer::optimizePose (optimizer.cpp:358-501), SURVEY 8(f) rank 2: four episodes from the same start pose, outliers
+    re-classified after each; the oracle must recover the pose, flag the gross outliers, and honour the < 3 / < 10 edge rules."""
+    from ydorbslam_amd.synth import synth_pose_problem
+    prob = synth_pose_problem(400, seed=3)
+    r = oracle_lib.pose_optimize(prob)
+    t_err0 = np.linalg.norm(prob["pose"][:3] - prob["truth_pose"][:3])
+    t_err1 = np.linalg.norm(r["pose"][:3] - prob["truth_pose"][:3])
+    assert t_err1 < 0.5 * t_err0 and t_err1 < 0.01
+    assert abs(abs(np.dot(r["pose"][3:], prob["truth_pose"][3:])) - 1) < 1e-4
+    gross = prob["is_gross_outlier"]
+    assert r["outlier"][gross].mean() > 0.9 and r["outlier"][~gross].mean() < 0.12
+    assert r["inliers"] == len(gross) - int(r["outlier"].sum())
+    assert np.all(np.isfinite(r["chi2"])) and r["chi2"][3] <= r["chi2"][0]
+    few = {k: (v[:2] if k in ("points", "meas", "info") else v) for k, v in prob.items()}
+    r2 = oracle_lib.pose_optimize(few)                       # < 3 correspondences: untouched, returns 0 (:443-445)
+    assert r2["inliers"] == 0 and np.array_equal(r2["pose"], prob["pose"])
+    nine = {k: (v[:9] if k in ("points", "meas", "info") else v) for k, v in prob.items()}
+    r3 = oracle_lib.pose_optimize(nine)                      # < 10 edges: one episode only (:494)
+    assert np.isfinite(r3["chi2"][0]) and np.all(np.isnan(r3["chi2"][1:]))

@@ -35,3 +35,19 @@ print("ydorb_search_by_projection mode 1, %d queries x %d keypoints: %.3f ms per
 m.set_profiling(True)
 for _ in range(20): m.search_by_projection(1, fv, q, d0)
 print({k: round(v, 4) for k, v in m.stage_times().items()})
+
+# Optimizer::optimizePose: one frame, and a batch
+from ydorbslam_amd.synth import synth_pose_problem
+pp = [synth_pose_problem(400, seed=i) for i in range(64)]
+y.Optimizer.optimize_poses(pp[:1]); y.Optimizer.optimize_poses(pp)
+t = time.perf_counter()
+for _ in range(50): y.Optimizer.optimize_poses(pp[:1])
+d1 = (time.perf_counter() - t) / 50
+t = time.perf_counter()
+for _ in range(20): y.Optimizer.optimize_poses(pp)
+d64 = (time.perf_counter() - t) / 20
+print("ydorb_pose_optimize, 400 correspondences: %.3f ms for one frame, %.3f ms for 64 frames (%.1f us per frame)" % (d1 * 1e3, d64 * 1e3, d64 / 64 * 1e6))
+from oracle import orb_oracle as oo
+t = time.perf_counter()
+for i in range(20): oo.pose_optimize(pp[i])
+print("oracle (1 CPU thread): %.3f ms per frame" % ((time.perf_counter() - t) / 20 * 1e3))

@@ -66,6 +66,7 @@ SYMBOLS = {
     "ydorb_ba_default_options": (None, [_VP]),
     "ydorb_ba_solve": (C.c_int, [_VP, _VP, _VP]),
     "ydorb_ba_dense_solve": (C.c_int, [_I, _VP, _I, _VP, _VP, C.POINTER(_I)]),
+    "ydorb_pose_optimize": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
 }
 
 BA_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
@@ -75,6 +76,11 @@ class YdBaProblem(C.Structure):
     _fields_ = [("n_poses", _I), ("n_points", _I), ("n_edges", _I), ("poses", _VP), ("pose_fixed", _VP), ("points", _VP),
                 ("edge_pose", _VP), ("edge_point", _VP), ("edge_meas", _VP), ("edge_inv_sigma2", _VP),
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double), ("stop", _VP)]
+
+
+class YdPoseBatch(C.Structure):
+    _fields_ = [("n_frames", _I), ("device", _I), ("edge_start", _VP), ("poses", _VP), ("points", _VP), ("meas", _VP),
+                ("inv_sigma2", _VP), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double)]
 
 
 class YdBaOptions(C.Structure):

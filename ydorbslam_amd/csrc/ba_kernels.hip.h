@@ -874,6 +874,38 @@ __global__ __launch_bounds__(128) void k_backsub(EdgeSoA Ed, const int* __restri
   xl[3 * l + 2] = di[2] * c0 + di[4] * c1 + di[5] * c2;
 }
 
+// VertexSE3Expmap::oplusImpl: pose <- exp(u) * pose, u = [omega, upsilon] (se3quat.h:100-106, 218-257)
+__device__ __forceinline__ void pose_oplus(V3& t, Q4& q, const R* u) {
+  const V3 omega{u[0], u[1], u[2]}, ups{u[3], u[4], u[5]};
+  const R theta = sqrt(omega.x * omega.x + omega.y * omega.y + omega.z * omega.z);
+  const R Om[3][3] = {{0, -omega.z, omega.y}, {omega.z, 0, -omega.x}, {-omega.y, omega.x, 0}};
+  R Om2[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) Om2[a][b] = Om[a][0] * Om[0][b] + Om[a][1] * Om[1][b] + Om[a][2] * Om[2][b];
+  R ca, cb, cc;
+  const bool small = theta < 0.00001;
+  if (small) { ca = 1; cb = 0.5; cc = 1. / 6.; }
+  else { ca = sin(theta) / theta; cb = (1 - cos(theta)) / (theta * theta); cc = (theta - sin(theta)) / pow(theta, 3.0); }
+  R Rm[3][3], V[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      const R I = a == b ? 1.0 : 0.0;
+      if (small) { Rm[a][b] = I + Om[a][b] + 0.5 * Om2[a][b]; V[a][b] = I + 0.5 * Om[a][b] + cc * Om2[a][b]; }
+      else { Rm[a][b] = I + ca * Om[a][b] + cb * Om2[a][b]; V[a][b] = I + cb * Om[a][b] + cc * Om2[a][b]; }
+    }
+  Q4 eq = rToQ(Rm);
+  qnormalize(eq);
+  const V3 et{V[0][0] * ups.x + V[0][1] * ups.y + V[0][2] * ups.z, V[1][0] * ups.x + V[1][1] * ups.y + V[1][2] * ups.z,
+              V[2][0] * ups.x + V[2][1] * ups.y + V[2][2] * ups.z};
+  t = add(et, qrot(eq, t));
+  q = qmul(eq, q);
+  qnormalize(q);
+}
+
 // SparseOptimizer::update (sparse_optimizer.cpp:433): poses <- exp(dxi) * pose (se3quat.h:100-106, 218-257),
 // points <- X + dX.  Reads `src`, writes `dst` (push/pop become a buffer swap on the host).
 __global__ __launch_bounds__(256) void k_update(const R* __restrict__ srcPoses, const R* __restrict__ srcPts, R* __restrict__ dstPoses,
@@ -884,35 +916,8 @@ __global__ __launch_bounds__(256) void k_update(const R* __restrict__ srcPoses, 
     const int k = poseOf[i];
     V3 t; Q4 q;
     load_pose(srcPoses, k, t, q);
-    const R* u = xp + 6 * i;
-    const V3 omega{u[0], u[1], u[2]}, ups{u[3], u[4], u[5]};
-    const R theta = sqrt(omega.x * omega.x + omega.y * omega.y + omega.z * omega.z);
-    const R Om[3][3] = {{0, -omega.z, omega.y}, {omega.z, 0, -omega.x}, {-omega.y, omega.x, 0}};
-    R Om2[3][3];
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int b = 0; b < 3; b++) Om2[a][b] = Om[a][0] * Om[0][b] + Om[a][1] * Om[1][b] + Om[a][2] * Om[2][b];
-    R ca, cb, cc;
-    const bool small = theta < 0.00001;
-    if (small) { ca = 1; cb = 0.5; cc = 1. / 6.; }
-    else { ca = sin(theta) / theta; cb = (1 - cos(theta)) / (theta * theta); cc = (theta - sin(theta)) / pow(theta, 3.0); }
-    R Rm[3][3], V[3][3];
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int b = 0; b < 3; b++) {
-        const R I = a == b ? 1.0 : 0.0;
-        if (small) { Rm[a][b] = I + Om[a][b] + 0.5 * Om2[a][b]; V[a][b] = I + 0.5 * Om[a][b] + cc * Om2[a][b]; }
-        else { Rm[a][b] = I + ca * Om[a][b] + cb * Om2[a][b]; V[a][b] = I + cb * Om[a][b] + cc * Om2[a][b]; }
-      }
-    Q4 eq = rToQ(Rm);
-    qnormalize(eq);
-    const V3 et{V[0][0] * ups.x + V[0][1] * ups.y + V[0][2] * ups.z, V[1][0] * ups.x + V[1][1] * ups.y + V[1][2] * ups.z,
-                V[2][0] * ups.x + V[2][1] * ups.y + V[2][2] * ups.z};
-    const V3 nt = add(et, qrot(eq, t));
-    Q4 nq = qmul(eq, q);
-    qnormalize(nq);
+    V3 nt = t; Q4 nq = q;
+    pose_oplus(nt, nq, xp + 6 * i);
     R* o = dstPoses + 7 * k;
     o[0] = nt.x; o[1] = nt.y; o[2] = nt.z; o[3] = nq.x; o[4] = nq.y; o[5] = nq.z; o[6] = nq.w;
   }
@@ -945,6 +950,251 @@ __global__ __launch_bounds__(256) void k_depths(const int* __restrict__ ePose, c
   load_pose(poses, ePose[e], t, q);
   const R* X = pts + 3 * ePt[e];
   depth[e] = add(qrot(q, V3{X[0], X[1], X[2]}), t).z;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Optimizer::optimizePose (reference src/optimizer.cpp:358-501): pose-only Levenberg on unary reprojection edges,
+// four episodes of <= 10 iterations from the same start pose with an inlier/outlier re-classification after each.
+// GPU form: ONE workgroup = one frame's whole optimizePose call (all 4 episodes, every LM trial) in a single launch — the
+// reference's per-iteration graph walk is ~40 dependent steps of a few microseconds each, far too fine for separate launches;
+// a batch of frames is a grid of such workgroups.  Per pass every thread walks its edges (stride 256), the 28 sums
+// (21 of H, 6 of b, chi2) are reduced in a fixed order (wave butterfly, then the 4 wave partials in order), and every thread
+// then runs the scalar LM bookkeeping and the 6x6 Cholesky redundantly on the same numbers, so no broadcast is needed.
+// Edge Jacobians follow EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose::linearizeOplus (invz products,
+// types_six_dof_expmap.cpp:415-494); the error is the same computeError as the binary edges.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int kPoseThreads = 256;
+
+__device__ __forceinline__ void pose_block_sums(R (&v)[28], R (*part)[28], R (&out)[28]) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 28; k++) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+  }
+  __syncthreads();                       // the previous reduction's readers are done with `part`
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 28; k++) part[wv][k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 28; k++) out[k] = ((part[0][k] + part[1][k]) + part[2][k]) + part[3][k];
+}
+__device__ __forceinline__ R pose_block_sum1(R v, R (*part)[28]) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][0] = v;
+  __syncthreads();
+  return ((part[0][0] + part[1][0]) + part[2][0]) + part[3][0];
+}
+// LL^T of the 6x6 system + both substitutions (LinearSolverDense, linear_solver_dense.h:66-109); false when not positive definite
+__device__ __forceinline__ bool pose_solve6(const R (&Hs)[21], R lambda, const R (&b)[6], R (&x)[6]) {
+  R L[6][6];
+  int k = 0;
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int c = r; c < 6; c++, k++) { L[c][r] = Hs[k] + (r == c ? lambda : 0.0); }   // lower triangle
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    R d = L[j][j];
+#pragma unroll
+    for (int q = 0; q < j; q++) d -= L[j][q] * L[j][q];
+    if (!(d > 0)) return false;
+    d = sqrt(d);
+    L[j][j] = d;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      R s2 = L[i][j];
+#pragma unroll
+      for (int q = 0; q < j; q++) s2 -= L[i][q] * L[j][q];
+      L[i][j] = s2 / d;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    R s2 = b[i];
+#pragma unroll
+    for (int q = 0; q < i; q++) s2 -= L[i][q] * x[q];
+    x[i] = s2 / L[i][i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    R s2 = x[i];
+#pragma unroll
+    for (int q = i + 1; q < 6; q++) s2 -= L[q][i] * x[q];
+    x[i] = s2 / L[i][i];
+  }
+  return true;
+}
+
+// state per edge in global scratch: err[3] (as last computed, stale for inactive edges like g2o's _error), flags (bit0 outlier/level,
+// bit1 robust kernel off)
+__global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(int nFrames, const int* __restrict__ edgeStart, R* __restrict__ poses,
+                                                                const R* __restrict__ Xw, const R* __restrict__ meas,
+                                                                const R* __restrict__ info, Cam cam, R deltaMono, R deltaStereo,
+                                                                R* __restrict__ err, uint8_t* __restrict__ flags,
+                                                                uint8_t* __restrict__ outlier, int* __restrict__ nInliers,
+                                                                R* __restrict__ chi2Log, int* __restrict__ trialsOut) {
+  __shared__ R part[4][28];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  if (f >= nFrames) return;
+  const int e0 = edgeStart[f], E = edgeStart[f + 1] - e0;
+  for (int k = tid; k < 4; k += kPoseThreads) chi2Log[4 * f + k] = __longlong_as_double(0x7ff8000000000000ll);
+  if (E < 3) {                               // :443-445
+    if (tid == 0) { nInliers[f] = 0; trialsOut[f] = 0; }
+    return;
+  }
+  V3 t0; Q4 q0;
+  load_pose(poses, f, t0, q0);
+  qnormalize(q0);
+  for (int i = tid; i < E; i += kPoseThreads) { flags[e0 + i] = 0; outlier[e0 + i] = 0; }
+  __syncthreads();
+  V3 t = t0; Q4 q = q0;
+  int bad = 0, trials = 0;
+  for (int epi = 0; epi < 4; epi++) {
+    t = t0; q = q0;                          // setEstimate(frame pose) at the top of every episode (:455)
+    int nAct = 0;
+    for (int i = tid; i < E; i += kPoseThreads) nAct += !(flags[e0 + i] & 1);
+    nAct = (int)pose_block_sum1((R)nAct, part);
+    if (nAct > 0) {
+      R lambda = 0, ni = 2, currentChi = 0;
+      for (int it = 0; it < 10; it++) {
+        // computeActiveErrors + robust chi2 + buildSystem in one pass
+        R acc[28];
+#pragma unroll
+        for (int k = 0; k < 28; k++) acc[k] = 0;
+        for (int i = tid; i < E; i += kPoseThreads) {
+          const int e = e0 + i;
+          const uint8_t fl = flags[e];
+          if (fl & 1) continue;
+          const R* z = meas + 3 * e;
+          const bool st = z[2] >= 0;
+          const V3 X{Xw[3 * e], Xw[3 * e + 1], Xw[3 * e + 2]};
+          R r[3], depth;
+          residual(t, q, X, z, st, cam, r, &depth);
+          err[3 * e] = r[0]; err[3 * e + 1] = r[1]; err[3 * e + 2] = r[2];
+          const R w = info[e], c2 = w * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+          R rho0 = c2, rho1 = 1;
+          if (!(fl & 2)) huber(c2, st ? deltaStereo : deltaMono, &rho0, &rho1);
+          acc[27] += rho0;
+          const V3 p = add(qrot(q, X), t);
+          const R x = p.x, y = p.y, invz = 1.0 / p.z, invz2 = invz * invz;
+          R J[3][6];
+          J[0][0] = x * y * invz2 * cam.fx; J[0][1] = -(1 + (x * x * invz2)) * cam.fx; J[0][2] = y * invz * cam.fx;
+          J[0][3] = -invz * cam.fx; J[0][4] = 0; J[0][5] = x * invz2 * cam.fx;
+          J[1][0] = (1 + y * y * invz2) * cam.fy; J[1][1] = -x * y * invz2 * cam.fy; J[1][2] = -x * invz * cam.fy;
+          J[1][3] = 0; J[1][4] = -invz * cam.fy; J[1][5] = y * invz2 * cam.fy;
+          if (st) {
+            J[2][0] = J[0][0] - cam.bf * y * invz2; J[2][1] = J[0][1] + cam.bf * x * invz2; J[2][2] = J[0][2];
+            J[2][3] = J[0][3]; J[2][4] = 0; J[2][5] = J[0][5] - cam.bf * invz2;
+          } else {
+#pragma unroll
+            for (int c = 0; c < 6; c++) J[2][c] = 0;
+          }
+          const R W = rho1 * w;
+          const R omr[3] = {-w * r[0] * rho1, -w * r[1] * rho1, st ? -w * r[2] * rho1 : 0.0};
+          int k = 0;
+#pragma unroll
+          for (int rr = 0; rr < 6; rr++)
+#pragma unroll
+            for (int c = rr; c < 6; c++, k++) acc[k] += J[0][rr] * W * J[0][c] + J[1][rr] * W * J[1][c] + J[2][rr] * W * J[2][c];
+#pragma unroll
+          for (int rr = 0; rr < 6; rr++) acc[21 + rr] += J[0][rr] * omr[0] + J[1][rr] * omr[1] + J[2][rr] * omr[2];
+        }
+        R S[28];
+        pose_block_sums(acc, part, S);
+        R Hs[21], b[6];
+#pragma unroll
+        for (int k = 0; k < 21; k++) Hs[k] = S[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) b[k] = S[21 + k];
+        currentChi = S[27];
+        if (it == 0) {                       // computeLambdaInit
+          R mx = 0;
+          int k = 0;
+#pragma unroll
+          for (int rr = 0; rr < 6; rr++) { mx = fmax(fabs(Hs[k]), mx); k += 6 - rr; }
+          lambda = 1e-5 * mx; ni = 2;
+        }
+        R rho = 0, x6[6] = {0, 0, 0, 0, 0, 0};
+        int qmax = 0;
+        do {
+          const V3 tb = t; const Q4 qb = q;  // push()
+          const bool ok = pose_solve6(Hs, lambda, b, x6);
+          pose_oplus(t, q, x6);              // g2o applies _x even after a failed solve (it then holds the previous step)
+          R chi = 0;
+          for (int i = tid; i < E; i += kPoseThreads) {
+            const int e = e0 + i;
+            const uint8_t fl = flags[e];
+            if (fl & 1) continue;
+            const R* z = meas + 3 * e;
+            const bool st = z[2] >= 0;
+            R r[3], depth;
+            residual(t, q, V3{Xw[3 * e], Xw[3 * e + 1], Xw[3 * e + 2]}, z, st, cam, r, &depth);
+            err[3 * e] = r[0]; err[3 * e + 1] = r[1]; err[3 * e + 2] = r[2];
+            const R c2 = info[e] * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+            R rho0 = c2, rho1;
+            if (!(fl & 2)) huber(c2, st ? deltaStereo : deltaMono, &rho0, &rho1);
+            chi += rho0;
+          }
+          R tempChi = pose_block_sum1(chi, part);
+          if (!ok) tempChi = 1.7976931348623157e308;
+          rho = currentChi - tempChi;
+          R sc = 1e-3;
+#pragma unroll
+          for (int j = 0; j < 6; j++) sc += x6[j] * (lambda * x6[j] + b[j]);
+          rho /= sc;
+          if (rho > 0 && isfinite(tempChi)) {
+            R alpha = 1. - pow((2 * rho - 1), 3.0);
+            alpha = fmin(alpha, 2. / 3.);
+            lambda *= fmax(1. / 3., alpha);
+            ni = 2;
+            currentChi = tempChi;
+          } else {
+            lambda *= ni; ni *= 2;
+            t = tb; q = qb;                  // pop()
+            if (!isfinite(lambda)) { qmax++; trials++; break; }
+          }
+          qmax++; trials++;
+        } while (rho < 0 && qmax < 10);
+        if (qmax == 10 || rho == 0 || !isfinite(lambda)) break;
+      }
+      if (tid == 0) chi2Log[4 * f + epi] = currentChi;
+    }
+    // classification (:458-493): excluded edges get a fresh error with the episode's final pose, active ones keep the last evaluated
+    int myBad = 0;
+    for (int i = tid; i < E; i += kPoseThreads) {
+      const int e = e0 + i;
+      uint8_t fl = flags[e];
+      const R* z = meas + 3 * e;
+      const bool st = z[2] >= 0;
+      if (fl & 1) {
+        R r[3], depth;
+        residual(t, q, V3{Xw[3 * e], Xw[3 * e + 1], Xw[3 * e + 2]}, z, st, cam, r, &depth);
+        err[3 * e] = r[0]; err[3 * e + 1] = r[1]; err[3 * e + 2] = r[2];
+      }
+      const float c2 = (float)(info[e] * (err[3 * e] * err[3 * e] + err[3 * e + 1] * err[3 * e + 1] + err[3 * e + 2] * err[3 * e + 2]));
+      const bool isBad = c2 > (st ? 7.815f : 5.991f);
+      fl = (uint8_t)((fl & 2) | (isBad ? 1 : 0));
+      if (epi == 2) fl |= 2;                 // setRobustKernel(0) before the last episode
+      flags[e] = fl;
+      outlier[e] = isBad ? 1 : 0;
+      myBad += isBad;
+    }
+    bad = (int)pose_block_sum1((R)myBad, part);
+    __syncthreads();                         // flags / err of this episode are visible to the next one
+    if (E < 10) break;                       // optimizer.edges().size() < 10 (:494)
+  }
+  if (tid == 0) {
+    R* o = poses + 7 * f;
+    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w;
+    nInliers[f] = E - bad;
+    trialsOut[f] = trials;
+  }
 }
 
 }  // namespace ba

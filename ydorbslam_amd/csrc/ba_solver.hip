@@ -59,6 +59,7 @@ struct Ctx {  // per-device scratch, reused across calls (localBundleAdjust runs
   hipEvent_t ev[2 * PH_COUNT + 2]{};
   bool evInit = false;
   double* hPin = nullptr;   // pinned read-back area: scal[8] + status[2] (one stream sync per LM trial)
+  DBuf pStart, pPoses, pX, pMeas, pInfo, pErr, pFlags, pOutlier, pInl, pChi, pTrials;   // pose-only batches
 };
 // A small pool of contexts per device: one localBundleAdjust at a time is the reference's use (LocalMapping thread), but the solve
 // is a latency chain that leaves most of the GPU idle, so several host threads (several maps / sessions) may solve concurrently,
@@ -518,6 +519,65 @@ int ydorb_ba_solve(const YdBaProblem* P, const YdBaOptions* optIn, YdBaResult* r
   if (R_.stopped()) res->stopped = 1;
   return YDORB_OK;
 }
+
+int ydorb_pose_optimize(const YdPoseBatch* B, uint8_t* outlier, int32_t* n_inliers, double* chi2_log, int32_t* trials) {
+  if (!B || B->n_frames < 0 || (B->n_frames && (!B->edge_start || !B->poses || !n_inliers)) || B->device < 0 || B->device >= 16) {
+    set_error("invalid pose batch");
+    return YDORB_ERR_INVALID_ARG;
+  }
+  const int n = B->n_frames;
+  if (n == 0) return YDORB_OK;
+  if (B->edge_start[0] != 0) { set_error("edge_start[0] must be 0"); return YDORB_ERR_INVALID_ARG; }
+  for (int f = 0; f < n; f++)
+    if (B->edge_start[f + 1] < B->edge_start[f]) { set_error("edge_start must be non-decreasing"); return YDORB_ERR_INVALID_ARG; }
+  const int E = B->edge_start[n];
+  if (E > 0 && (!B->points || !B->meas || !B->inv_sigma2 || !outlier)) { set_error("null edge arrays"); return YDORB_ERR_INVALID_ARG; }
+  int rc = require_device(B->device);
+  if (rc) return rc;
+  int slot = -1;
+  {
+    std::lock_guard<std::mutex> pick(g_pick);
+    for (int i = 0; i < kCtxPool && slot < 0; i++)
+      if (g_mu[B->device][i].try_lock()) slot = i;
+  }
+  if (slot < 0) { slot = 0; g_mu[B->device][0].lock(); }
+  std::lock_guard<std::mutex> lock(g_mu[B->device][slot], std::adopt_lock);
+  Ctx& c = g_ctx[B->device][slot];
+  if (!c.stream) {
+    c.device = B->device;
+    HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    for (auto& e : c.ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipHostMalloc(&c.hPin, sizeof(double) * 16));
+  }
+  hipStream_t s = c.stream;
+  const size_t Ez = (size_t)std::max(E, 1);
+  if ((rc = c.pStart.ensure(sizeof(int) * (n + 1))) || (rc = c.pPoses.ensure(sizeof(double) * 7 * n)) || (rc = c.pX.ensure(sizeof(double) * 3 * Ez)) ||
+      (rc = c.pMeas.ensure(sizeof(double) * 3 * Ez)) || (rc = c.pInfo.ensure(sizeof(double) * Ez)) || (rc = c.pErr.ensure(sizeof(double) * 3 * Ez)) ||
+      (rc = c.pFlags.ensure(Ez)) || (rc = c.pOutlier.ensure(Ez)) || (rc = c.pInl.ensure(sizeof(int) * n)) || (rc = c.pChi.ensure(sizeof(double) * 4 * n)) ||
+      (rc = c.pTrials.ensure(sizeof(int) * n)))
+    return rc;
+  HIPCHK(hipMemcpyAsync(c.pStart.p, B->edge_start, sizeof(int) * (n + 1), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(c.pPoses.p, B->poses, sizeof(double) * 7 * n, hipMemcpyHostToDevice, s));
+  if (E) {
+    HIPCHK(hipMemcpyAsync(c.pX.p, B->points, sizeof(double) * 3 * E, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c.pMeas.p, B->meas, sizeof(double) * 3 * E, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c.pInfo.p, B->inv_sigma2, sizeof(double) * E, hipMemcpyHostToDevice, s));
+  }
+  const Cam cam{B->fx, B->fy, B->cx, B->cy, B->bf};
+  const double dM = (double)(float)sqrt(5.991), dS = (double)(float)sqrt(7.815);   // optimizer.cpp:381-382
+  hipLaunchKernelGGL(k_pose_optimize, dim3(n), dim3(kPoseThreads), 0, s, n, c.pStart.as<int>(), c.pPoses.as<double>(), c.pX.as<double>(),
+                     c.pMeas.as<double>(), c.pInfo.as<double>(), cam, dM, dS, c.pErr.as<double>(), c.pFlags.as<uint8_t>(),
+                     c.pOutlier.as<uint8_t>(), c.pInl.as<int>(), c.pChi.as<double>(), c.pTrials.as<int>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(B->poses, c.pPoses.p, sizeof(double) * 7 * n, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(n_inliers, c.pInl.p, sizeof(int) * n, hipMemcpyDeviceToHost, s));
+  if (E) HIPCHK(hipMemcpyAsync(outlier, c.pOutlier.p, E, hipMemcpyDeviceToHost, s));
+  if (chi2_log) HIPCHK(hipMemcpyAsync(chi2_log, c.pChi.p, sizeof(double) * 4 * n, hipMemcpyDeviceToHost, s));
+  if (trials) HIPCHK(hipMemcpyAsync(trials, c.pTrials.p, sizeof(int) * n, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return YDORB_OK;
+}
+
 
 int ydorb_ba_dense_solve(int32_t device, const double* A, int32_t n0, const double* b, double* x, int32_t* ok) {
   if (!A || !b || !x || !ok || n0 < 1 || device < 0 || device >= 16) { set_error("invalid argument"); return YDORB_ERR_INVALID_ARG; }

@@ -5,7 +5,7 @@ The graph is passed flat (what optimizer.cpp:175-283 hands to g2o); the covisibi
 import ctypes as C
 import numpy as np
 
-from ._lib import BA_ALLREDUCE_FN, YdBaOptions, YdBaProblem, YdBaResult, check, lib
+from ._lib import BA_ALLREDUCE_FN, YdBaOptions, YdBaProblem, YdBaResult, YdPoseBatch, check, lib
 
 
 def _p(a):
@@ -65,6 +65,29 @@ class Optimizer:
                     stopped=bool(res.stopped),
                     ms=dict(total=res.ms_total, errors=res.ms_errors, build=res.ms_build, schur=res.ms_schur, solve=res.ms_solve,
                             update=res.ms_update))
+
+    @staticmethod
+    def optimize_poses(probs, device=0):
+        """Optimizer::optimizePose (optimizer.cpp:358-501) for a batch of frames in one launch.  probs: list of dicts as
+        ydorbslam_amd.synth.synth_pose_problem (pose[7], points[E,3], meas[E,3], info[E], camera[5] — the camera of probs[0] is used).
+        Returns a list of dict(pose, outlier, inliers, chi2[4], trials)."""
+        n = len(probs)
+        if n == 0:
+            return []
+        counts = [len(p["info"]) for p in probs]
+        start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        E = int(start[-1])
+        poses = np.ascontiguousarray(np.stack([p["pose"] for p in probs]), np.float64).copy()
+        cat = lambda k, w: (np.ascontiguousarray(np.concatenate([np.asarray(p[k], np.float64).reshape(-1, w) for p in probs]), np.float64)
+                            if E else np.zeros((0, w)))
+        X, z, wgt = cat("points", 3), cat("meas", 3), cat("info", 1)
+        cam = [float(v) for v in probs[0]["camera"]]
+        B = YdPoseBatch(n, device, _p(start), _p(poses), _p(X), _p(z), _p(wgt), *cam)
+        outlier = np.zeros(max(E, 1), np.uint8)
+        inl = np.zeros(n, np.int32); chi = np.zeros((n, 4), np.float64); trials = np.zeros(n, np.int32)
+        check(lib().ydorb_pose_optimize(C.byref(B), _p(outlier), _p(inl), _p(chi), _p(trials)))
+        return [dict(pose=poses[f].copy(), outlier=outlier[start[f]:start[f + 1]].copy(), inliers=int(inl[f]), chi2=chi[f].copy(),
+                     trials=int(trials[f])) for f in range(n)]
 
     @staticmethod
     def dense_solve(A, b, device=0):

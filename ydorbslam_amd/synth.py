@@ -94,3 +94,34 @@ def synth_ba_problem(n_kf=100, n_pts=10000, n_obs=8, seed=1, stereo=True, n_fixe
     return dict(poses=poses, fixed=fixed, points=points, edge_pose=np.array(ep, np.int32), edge_point=np.array(eq, np.int32),
                 meas=np.array(meas, np.float64), info=np.ones(E, np.float64), camera=np.array([fx, fy, cx, cy, bf], np.float64),
                 truth_poses=truth_poses, truth_points=pts)
+
+
+def synth_pose_problem(n_pts=400, seed=1, outlier_frac=0.1, mono_frac=0.3, pose_noise=0.02):
+    """One Tracking-style pose-only problem (Optimizer::optimizePose, optimizer.cpp:358-501): map points in front of the camera
+    (float32 world coordinates, as getPosInWorld returns them), pixel measurements with 1-px noise on a random octave's sigma,
+    some gross outliers, and a perturbed start pose.  Returns dict(pose[7], points[E,3], meas[E,3], info[E], camera[5], truth_pose)."""
+    rng = np.random.default_rng(seed)
+    fx = fy = 500.0
+    cx, cy, bf = 320.0, 240.0, 40.0
+    w = rng.normal(0, 0.3, 3)
+    Rt = _so3_exp(w)
+    tt = rng.normal(0, 0.5, 3)
+    Xc = np.stack([rng.uniform(-3, 3, n_pts), rng.uniform(-2, 2, n_pts), rng.uniform(2, 10, n_pts)], axis=1)
+    Xw = ((Xc - tt) @ Rt).astype(np.float32).astype(np.float64)        # X_c = R X_w + t
+    Xc = Xw @ Rt.T + tt
+    octave = rng.integers(0, 8, n_pts)
+    sigma = 1.2 ** octave
+    u = fx * Xc[:, 0] / Xc[:, 2] + cx + rng.normal(0, 1, n_pts) * sigma
+    v = fy * Xc[:, 1] / Xc[:, 2] + cy + rng.normal(0, 1, n_pts) * sigma
+    ur = np.where(rng.random(n_pts) >= mono_frac, u - bf / Xc[:, 2], -1.0)
+    bad = rng.random(n_pts) < outlier_frac
+    u = u + bad * rng.normal(0, 40, n_pts)
+    v = v + bad * rng.normal(0, 40, n_pts)
+    meas = np.stack([u, v, ur], axis=1).astype(np.float32).astype(np.float64)   # cv::KeyPoint / rightX are floats
+    info = (1.0 / (sigma * sigma)).astype(np.float32).astype(np.float64)       # m_v_invScaleFactorSquares is a float table
+    d = rng.normal(0, pose_noise, 6)
+    Rn = _so3_exp(d[:3]) @ Rt
+    pose = np.concatenate([Rn @ np.zeros(3) + _so3_exp(d[:3]) @ tt + d[3:], _rot_to_quat(Rn)])
+    truth = np.concatenate([tt, _rot_to_quat(Rt)])
+    return dict(pose=pose, points=Xw, meas=meas, info=info, camera=np.array([fx, fy, cx, cy, bf], np.float64), truth_pose=truth,
+                is_gross_outlier=bad)
