@@ -343,6 +343,20 @@ def main():
             out["ba"]["concurrent"] = {"problems": NT, "value": sum(res) / tcc, "unit": "it/s (aggregate)",
                                        "note": "independent copies of the same C5 problem, one host thread and one context each"}
 
+    # ---- pose-only optimisation (Optimizer::optimizePose): a batch of frames per launch -------------------
+    if not args.no_ba and world == 1:
+        from ydorbslam_amd.synth import synth_pose_problem
+        NPF = 256
+        pprobs = [synth_pose_problem(400, seed=100 + i) for i in range(NPF)]
+        y.Optimizer.optimize_poses(pprobs)
+        tp = time.perf_counter()
+        for _ in range(5):
+            pres = y.Optimizer.optimize_poses(pprobs)
+        tp = (time.perf_counter() - tp) / 5
+        out["pose_optimize"] = {"metric": "optimizePose frames/sec (400 correspondences per frame, 4 episodes x 10 LM iterations)",
+                                "frames_per_launch": NPF, "value": NPF / tp, "unit": "frames/s", "ms_per_launch": tp * 1e3,
+                                "mean_inliers": float(np.mean([r_["inliers"] for r_ in pres]))}
+
     # ---- CPU baseline: the oracle (port of the reference algorithm), one thread, bounded sample -------------------------
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle.orb_oracle import FrameOracle, OrbExtractorOracle, QUERY_DTYPE, ba_solve
@@ -374,6 +388,12 @@ def main():
             out["ba"]["cpu_baseline"] = {"value": rb["trials"] / tcb, "unit": "it/s", "cores": 1, "kind": "port",
                                          "sample": "one full localBundleAdjust schedule (%d LM trials) on the same problem" % rb["trials"]}
             out["ba"]["vs_cpu"] = out["ba"]["value"] / out["ba"]["cpu_baseline"]["value"]
+            from oracle.orb_oracle import pose_optimize as oracle_pose_optimize
+            tpc = time.perf_counter()
+            for i in range(32):
+                oracle_pose_optimize(pprobs[i])
+            tpc = (time.perf_counter() - tpc) / 32
+            out["pose_optimize"]["cpu_baseline"] = {"value": 1.0 / tpc, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "32 of the same frames"}
         out["vs_cpu"] = value / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))
