@@ -192,6 +192,26 @@ typedef struct YdBowSide {
 int ydorb_search_by_bow(ydorb_matcher_t* h, int32_t mode, const YdBowSide* a, const YdBowSide* b, float ratio,
                         int32_t check_orientation, int32_t* out, int32_t* n_matches);
 
+
+/* OrbMatcher::searchForTriangulation (src/orbMatcher.cpp:463-565): BoW-guided search between the features of two
+ * keyframes that have no MapPoint yet, kept when the second feature lies on the first one's epipolar line (:808-819).
+ * has_map_point[i] != 0 <=> KeyFrame::getMapPoint(i) is set; right_x = m_v_rightXcords.  F = _fMatrix_first2second row-major
+ * (F[r*3+c] = at<float>(r,c)); (epipole_x, epipole_y) = the first camera centre projected into the second image (:465-470, computed
+ * by the caller exactly as the reference does); second_scale_factors / _squares = the second keyframe's m_v_scaleFactors /
+ * m_v_scaleFactorSquares.  matched_second[first idx] = second idx or -1 (the reference's vector of pairs, in first-index order). */
+typedef struct YdTriSide {
+  const YdKeyPoint* kps;
+  const uint8_t* desc;
+  const float* right_x;
+  const uint8_t* has_map_point;
+  int32_t n;
+  YdFeatureVector fv;
+} YdTriSide;
+int ydorb_search_for_triangulation(ydorb_matcher_t* h, const YdTriSide* first, const YdTriSide* second, const float* F, float epipole_x,
+                                   float epipole_y, const float* second_scale_factors, const float* second_scale_factor_squares,
+                                   int32_t n_levels, int32_t stereo_only, int32_t check_orientation, int32_t* matched_second,
+                                   int32_t* n_matches);
+
 /* Device-resident streaming form used after ydorb_extract_batch_device: for f = 0..n_frames-2, the keypoints of
  * frame f are searched in frame f+1 with the searchByProjectionInLastAndCurrentFrame rules (mode 1; position
  * prediction = d_affine[f] (2x3, row-major) applied to the keypoint, NULL = identity; window th*scaleFactor[octave];

@@ -231,6 +231,39 @@ int searchByBowInTwoKeyFrames(ydorb_matcher_t* m, KeyFramePtr kf1, KeyFramePtr k
   return n;
 }
 
+// searchForTriangulation, src/orbMatcher.cpp:463-565: the epipole (:465-470) and the stereo / map-point flags are gathered here exactly as
+// the reference reads them; pairs come back in first-index order like the loop at :557-563.
+template <class KeyFramePtr, class FrameT>
+int searchForTriangulation(ydorb_matcher_t* m, KeyFramePtr kf1, KeyFramePtr kf2, const cv::Mat& F12, std::vector<std::pair<int, int>>& pairs,
+                           bool stereoOnly, bool checkOri) {
+  const cv::Mat Cw = kf1->getCameraOriginInWorld(), R2w = kf2->getRotation_c2w(), t2w = kf2->getTranslation_c2w();
+  const cv::Mat C2 = R2w * Cw + t2w;
+  const float ex = FrameT::m_flt_fx * C2.at<float>(0) / C2.at<float>(2) + FrameT::m_flt_cx;
+  const float ey = FrameT::m_flt_fy * C2.at<float>(1) / C2.at<float>(2) + FrameT::m_flt_cy;
+  const int n1 = kf1->m_int_keyPointsNum, n2 = kf2->m_int_keyPointsNum;
+  std::vector<uint8_t> mp1(n1), mp2(n2);
+  for (int i = 0; i < n1; i++) mp1[i] = kf1->getMapPoint(i) ? 1 : 0;
+  for (int i = 0; i < n2; i++) mp2[i] = kf2->getMapPoint(i) ? 1 : 0;
+  float Fm[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) Fm[r * 3 + c] = F12.at<float>(r, c);
+  BowCsr<decltype(kf1->m_bow_keyPointsVec)> a(kf1->m_bow_keyPointsVec), b(kf2->m_bow_keyPointsVec);
+  YdTriSide A{reinterpret_cast<const YdKeyPoint*>(kf1->m_v_keyPoints.data()), kf1->m_cvMat_descriptors.template ptr<uint8_t>(), kf1->m_v_rightXcords.data(),
+              mp1.data(), (int32_t)n1, a.c()};
+  YdTriSide B{reinterpret_cast<const YdKeyPoint*>(kf2->m_v_keyPoints.data()), kf2->m_cvMat_descriptors.template ptr<uint8_t>(), kf2->m_v_rightXcords.data(),
+              mp2.data(), (int32_t)n2, b.c()};
+  std::vector<int32_t> out(n1, -1);
+  int32_t n = 0;
+  if (ydorb_search_for_triangulation(m, &A, &B, Fm, ex, ey, kf2->m_v_scaleFactors.data(), kf2->m_v_scaleFactorSquares.data(),
+                                     (int32_t)kf2->m_v_scaleFactors.size(), stereoOnly ? 1 : 0, checkOri ? 1 : 0, out.data(), &n) != YDORB_OK)
+    throw std::runtime_error(std::string("ydorb: ") + ydorb_last_error());
+  pairs.clear();
+  pairs.reserve(n);
+  for (int i = 0; i < n1; i++)
+    if (out[i] >= 0) pairs.push_back(std::make_pair(i, (int)out[i]));
+  return n;
+}
+
 }  // namespace adapter
 }  // namespace ydorb
 #endif

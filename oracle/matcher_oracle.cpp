@@ -249,6 +249,76 @@ int yo_search_by_bow(int mode, const void* kpsA, const uint8_t* descA, int nA, c
   return matchNum;
 }
 
+// OrbMatcher::searchForTriangulation, orbMatcher.cpp:463-565 (+ isEpipolarLineDistCorrect :808-819): BoW-guided search between the
+// still-unmatched features of two keyframes, kept when the second feature lies on the first one's epipolar line.
+// hasMpA/B[i] != 0 <=> the feature already has a MapPoint; rightA/B = m_v_rightXcords (>= 0: stereo good).
+// F: the 3x3 float matrix _fMatrix_first2second, row-major F[r*3+c] = at<float>(r,c).  (ex, ey): the first camera's centre projected
+// into the second image (:465-470, computed by the caller from float cv::Mat products).  sfB / sf2B: the second keyframe's
+// m_v_scaleFactors / m_v_scaleFactorSquares.  out[firstIdx] = second index or -1.  Returns matchNum.
+int yo_search_for_triangulation(const void* kpsA, const uint8_t* descA, int nA, const uint8_t* hasMpA, const float* rightA,
+                                const uint32_t* nodeIdsA, const int* nodeStartA, int nNodesA, const int* featA, const void* kpsB,
+                                const uint8_t* descB, int nB, const uint8_t* hasMpB, const float* rightB, const uint32_t* nodeIdsB,
+                                const int* nodeStartB, int nNodesB, const int* featB, const float* F, float ex, float ey, const float* sfB,
+                                const float* sf2B, int stereoOnly, int checkOrientation, int* out) {
+  const KeyPoint* KA = (const KeyPoint*)kpsA;
+  const KeyPoint* KB = (const KeyPoint*)kpsB;
+  for (int i = 0; i < nA; i++) out[i] = -1;
+  std::vector<uint8_t> matchedB(nB, 0);
+  std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+  int matchNum = 0, a = 0, b = 0;
+  auto epipolarOk = [&](const KeyPoint& k1, const KeyPoint& k2) {   // :808-819, every operation a float operation as written
+    const float la = F[0] * k1.x + F[3] * k1.y + F[6];
+    const float lb = F[1] * k1.x + F[4] * k1.y + F[7];
+    const float lc = F[2] * k1.x + F[5] * k1.y + F[8];
+    const float den = la * la + lb * lb;
+    if (den > 0) {
+      const float num = la * k2.x + lb * k2.y + lc;
+      return (double)((num * num) / (den * den)) < 3.841 * (double)sf2B[k2.octave];   // the squared denominator is the reference's
+    }
+    return false;
+  };
+  while (a < nNodesA && b < nNodesB) {
+    if (nodeIdsA[a] == nodeIdsB[b]) {
+      for (int ia = nodeStartA[a]; ia < nodeStartA[a + 1]; ia++) {
+        const int i1 = featA[ia];
+        const bool goodA = rightA[i1] >= 0;
+        if (hasMpA[i1] || (stereoOnly && !goodA)) continue;
+        int bestDist = TH_LOW, bestIdx = -1;
+        for (int ib = nodeStartB[b]; ib < nodeStartB[b + 1]; ib++) {
+          const int i2 = featB[ib];
+          const bool goodB = rightB[i2] >= 0;
+          if (matchedB[i2] || hasMpB[i2] || (stereoOnly && !goodB)) continue;
+          const int dist = descriptorDistance(descA + (size_t)i1 * 32, descB + (size_t)i2 * 32);
+          if (dist <= TH_LOW && dist <= bestDist &&
+              (goodA || goodB ||
+               pow((float)ex - (float)KB[i2].x, 2.0) + pow((float)ey - (float)KB[i2].y, 2.0) >= 100 * sfB[KB[i2].octave])) {
+            if (epipolarOk(KA[i1], KB[i2])) { bestIdx = i2; bestDist = dist; }
+          }
+        }
+        if (bestIdx >= 0) {
+          matchedB[bestIdx] = 1;
+          out[i1] = bestIdx;
+          matchNum++;
+          if (checkOrientation) rotHist[rotBin(KA[i1].angle, KB[bestIdx].angle)].push_back(i1);
+        }
+      }
+      a++; b++;
+    } else if (nodeIdsA[a] < nodeIdsB[b]) {
+      a = (int)(std::lower_bound(nodeIdsA, nodeIdsA + nNodesA, nodeIdsB[b]) - nodeIdsA);
+    } else {
+      b = (int)(std::lower_bound(nodeIdsB, nodeIdsB + nNodesB, nodeIdsA[a]) - nodeIdsB);
+    }
+  }
+  if (checkOrientation) {
+    int i1 = -1, i2 = -1, i3 = -1;
+    threeMaxima(rotHist, HISTO_LENGTH, i1, i2, i3);
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != i1 && i != i2 && i != i3)
+        for (int idx : rotHist[i]) { out[idx] = -1; matchNum--; }
+  }
+  return matchNum;
+}
+
 void yo_three_maxima(const int* sizes, int L, int* idx3) {
   std::vector<std::vector<int>> h(L);
   for (int i = 0; i < L; i++) h[i].assign(sizes[i], 0);

@@ -254,6 +254,27 @@ def search_by_bow(mode, kps_a, desc_a, valid_a, fv_a, kps_b, desc_b, valid_b, fv
     return n, out
 
 
+def search_for_triangulation(kps_a, desc_a, has_mp_a, right_a, fv_a, kps_b, desc_b, has_mp_b, right_b, fv_b, F, epipole, sf_b, sf2_b,
+                             stereo_only, check_orientation):
+    """OrbMatcher::searchForTriangulation (orbMatcher.cpp:463-565).  F: 3x3 float32 (_fMatrix_first2second), epipole (x, y) float32,
+    sf_b / sf2_b: the second keyframe's scale factors / their squares.  Returns (matchNum, out[first idx] = second idx or -1)."""
+    ka = np.ascontiguousarray(kps_a, KP_DTYPE); kb = np.ascontiguousarray(kps_b, KP_DTYPE)
+    da = np.ascontiguousarray(desc_a, np.uint8); db = np.ascontiguousarray(desc_b, np.uint8)
+    ma = np.ascontiguousarray(has_mp_a, np.uint8); mb = np.ascontiguousarray(has_mp_b, np.uint8)
+    ra = np.ascontiguousarray(right_a, np.float32); rb = np.ascontiguousarray(right_b, np.float32)
+    ia, sa, fa = (np.ascontiguousarray(fv_a[0], np.uint32), np.ascontiguousarray(fv_a[1], np.int32), np.ascontiguousarray(fv_a[2], np.int32))
+    ib, sb, fb = (np.ascontiguousarray(fv_b[0], np.uint32), np.ascontiguousarray(fv_b[1], np.int32), np.ascontiguousarray(fv_b[2], np.int32))
+    Fm = np.ascontiguousarray(F, np.float32).reshape(9)
+    s1 = np.ascontiguousarray(sf_b, np.float32); s2 = np.ascontiguousarray(sf2_b, np.float32)
+    out = np.full(len(ka), -1, np.int32)
+    L = lib()
+    L.yo_search_for_triangulation.restype = C.c_int
+    n = L.yo_search_for_triangulation(_p(ka), _p(da), len(ka), _p(ma), _p(ra), _p(ia), _p(sa), len(ia), _p(fa), _p(kb), _p(db), len(kb), _p(mb),
+                                      _p(rb), _p(ib), _p(sb), len(ib), _p(fb), _p(Fm), C.c_float(float(epipole[0])), C.c_float(float(epipole[1])),
+                                      _p(s1), _p(s2), int(stereo_only), int(check_orientation), _p(out))
+    return n, out
+
+
 # ---------------------------------------------------------------------------------------------
 # local-BA oracle (oracle/ba_oracle.cpp)
 # ---------------------------------------------------------------------------------------------

@@ -34,6 +34,8 @@ struct Frame {
 struct KeyFrame {
   std::vector<cv::KeyPoint> m_v_keyPoints; cv::Mat m_cvMat_descriptors; FeatureVector m_bow_keyPointsVec; std::vector<float> m_v_rightXcords, m_v_invScaleFactorSquares;
   long int m_int_keyFrameID, m_int_localBAForKeyFrameID, m_int_fixedBAForKeyFrameID, m_int_globalBAForKeyFrameID; cv::Mat m_cvMat_T_c2w_GlobalBA;
+  int m_int_keyPointsNum; std::vector<float> m_v_scaleFactors, m_v_scaleFactorSquares;
+  std::shared_ptr<MapPoint> getMapPoint(const int&); cv::Mat getCameraOriginInWorld(); cv::Mat getRotation_c2w(); cv::Mat getTranslation_c2w();
   std::vector<std::shared_ptr<MapPoint>> getMatchedMapPointsVec(); std::vector<std::shared_ptr<KeyFrame>> getOrderedConnectedKeyFrames();
   bool isBad(); cv::Mat getCameraPoseByTransform_c2w(); void setCameraPoseByTransform_c2w(cv::Mat); void eraseMatchedMapPoint(std::shared_ptr<MapPoint>);
 };
@@ -51,6 +53,8 @@ int check(Frame& a, Frame& b, std::shared_ptr<KeyFrame> kf, std::shared_ptr<KeyF
   n += ya::searchByBowInKeyFrameAndFrame(ya::matcher(), kf, a, mps, 0.7f, true);
   n += ya::searchByBowInTwoKeyFrames(ya::matcher(), kf, kf2, mps, 0.75f, true);
   n += ya::computeDescriptorsDistance(a.m_cvMat_descriptors, b.m_cvMat_descriptors);
+  std::vector<std::pair<int, int>> pairs;
+  n += ya::searchForTriangulation<std::shared_ptr<KeyFrame>, Frame>(ya::matcher(), kf, kf2, a.m_cvMat_T_c2w, pairs, false, true);
 #ifdef YDORB_CHECK_OPTIMIZER
   bool stop = false;
   ya::localBundleAdjustImpl<std::shared_ptr<KeyFrame>, std::shared_ptr<Map>, Frame>(kf, std::make_shared<Map>(), &stop);

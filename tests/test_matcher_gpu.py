@@ -136,3 +136,29 @@ def test_consecutive_device_matches_host_call(oracle_lib):
         assert counts[f] == n_ref
         assert np.array_equal(assigned[f, :n[f + 1]], a_ref)
         assert n_ref > 20  # (few survive: frame.cpp:353 offers only |dx| > r candidates, then the 3-bin histogram cull)
+
+
+@pytest.mark.parametrize("stereo_only", [False, True])
+def test_search_for_triangulation(oracle_lib, scene, stereo_only):
+    """OrbMatcher::searchForTriangulation (orbMatcher.cpp:463-565, SURVEY 8f rank 3): eligibility flags, `<=` tie rule (last candidate
+    wins), epipole-distance exemption, float epipolar test, rotation histogram — identical integers to the oracle."""
+    import ydorbslam_amd as y
+    total = 0
+    for si, s in enumerate(scene):
+        rng = np.random.default_rng(90 + si)
+        ka, da, kb, db = s["ka"], s["da"], s["kb"], s["db"]
+        fa, fb = feature_vector(bow_nodes(da, 4)), feature_vector(bow_nodes(db, 4))
+        mpa = (rng.random(len(ka)) < 0.3).astype(np.uint8); mpb = (rng.random(len(kb)) < 0.3).astype(np.uint8)
+        ra = np.where(rng.random(len(ka)) < 0.5, ka["x"] - 5, -1).astype(np.float32)
+        rb = np.where(rng.random(len(kb)) < 0.5, kb["x"] - 5, -1).astype(np.float32)
+        F = np.array([[0, 0, 0], [0, 0, -1], [0, 1, -s["dy"]]], np.float32)      # epipolar "line" of a pure image shift: y' = y + dy
+        sf = s["sf"].astype(np.float32); sf2 = (sf * sf).astype(np.float32)
+        for epi, check in (((-900.0, 240.0), True), ((320.0, 240.0), False), ((100.5, 400.25), True)):
+            n_ref, o_ref = oracle_lib.search_for_triangulation(ka, da, mpa, ra, fa, kb, db, mpb, rb, fb, F, epi, sf, sf2, stereo_only, check)
+            m = y.OrbMatcher(0.6, check)
+            n_gpu, o_gpu = m.search_for_triangulation(ka, da, mpa, ra, y.FeatureVector(*fa), kb, db, mpb, rb, y.FeatureVector(*fb), F, epi, sf, sf2,
+                                                      stereo_only)
+            assert n_gpu == n_ref
+            assert np.array_equal(o_gpu, o_ref)
+            total += n_ref
+    assert total > 50

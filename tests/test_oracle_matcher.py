@@ -108,3 +108,69 @@ def test_bow_search_invariants(oracle_lib):
     assert len({b for _, b in pairs3}) == len(pairs3)                   # a frame feature is matched once
     nz, oz = oracle_lib.search_by_bow(3, ka, da, np.zeros(len(ka), np.uint8), fa, kb, db, vb, fb, 0.7, True)
     assert nz == 0 and (oz == -1).all()
+
+
+def _tri_inputs(oracle_lib, stereo_frac=0.5, mp_frac=0.3, seed=3, dy=-3):
+    ka, da, kb, db, sf = _scene(oracle_lib, dx=11, dy=dy)
+    rng = np.random.default_rng(seed)
+    fa, fb = feature_vector(bow_nodes(da, 4)), feature_vector(bow_nodes(db, 4))
+    mpa = (rng.random(len(ka)) < mp_frac).astype(np.uint8); mpb = (rng.random(len(kb)) < mp_frac).astype(np.uint8)
+    ra = np.where(rng.random(len(ka)) < stereo_frac, ka["x"] - 5, -1).astype(np.float32)
+    rb = np.where(rng.random(len(kb)) < stereo_frac, kb["x"] - 5, -1).astype(np.float32)
+    # image B is image A moved by (11, dy): l = F^T x1 = (0, 1, -(y + dy)), i.e. the "epipolar line" of a pure image shift
+    F = np.array([[0, 0, 0], [0, 0, -1], [0, 1, -dy]], np.float32)
+    sf = sf.astype(np.float32)
+    return ka, da, mpa, ra, fa, kb, db, mpb, rb, fb, F, sf, (sf * sf).astype(np.float32)
+
+
+def test_triangulation_search_matches_independent_statement(oracle_lib):
+    """OrbMatcher::searchForTriangulation (orbMatcher.cpp:463-565, SURVEY 8f rank 3) against a second, numpy-float32 statement of
+    the same rules: eligibility (no map point, stereo-only), `dist <= 50 && dist <= best` (ties: the LAST candidate wins), the
+    epipole-distance exemption for stereo points, the float epipolar test with its squared denominator, one match per second feature."""
+    f32 = np.float32
+    for stereo_only, epi in ((False, (-900.0, 240.0)), (True, (320.0, 240.0)), (False, (320.0, 240.0))):
+        ka, da, mpa, ra, fa, kb, db, mpb, rb, fb, F, sf, sf2 = _tri_inputs(oracle_lib)
+        n, out = oracle_lib.search_for_triangulation(ka, da, mpa, ra, fa, kb, db, mpb, rb, fb, F, epi, sf, sf2, stereo_only, False)
+        ex, ey = f32(epi[0]), f32(epi[1])
+        exp = np.full(len(ka), -1, np.int64)
+        matched = np.zeros(len(kb), bool)
+        nodes_b = {int(i): fb[2][fb[1][k]:fb[1][k + 1]] for k, i in enumerate(fb[0])}
+        for k, node in enumerate(fa[0]):
+            if int(node) not in nodes_b:
+                continue
+            for i1 in fa[2][fa[1][k]:fa[1][k + 1]]:
+                good_a = ra[i1] >= 0
+                if mpa[i1] or (stereo_only and not good_a):
+                    continue
+                x1, y1 = f32(ka["x"][i1]), f32(ka["y"][i1])
+                la = f32(f32(F[0, 0] * x1) + f32(F[1, 0] * y1)) + F[2, 0]
+                lb = f32(f32(F[0, 1] * x1) + f32(F[1, 1] * y1)) + F[2, 1]
+                lc = f32(f32(F[0, 2] * x1) + f32(F[1, 2] * y1)) + F[2, 2]
+                best, best_i = 50, -1
+                for i2 in nodes_b[int(node)]:
+                    good_b = rb[i2] >= 0
+                    if matched[i2] or mpb[i2] or (stereo_only and not good_b):
+                        continue
+                    d = int(np.unpackbits(da[i1] ^ db[i2]).sum())
+                    if not (d <= 50 and d <= best):
+                        continue
+                    x2, y2 = f32(kb["x"][i2]), f32(kb["y"][i2])
+                    far = float(f32(ex - x2)) ** 2 + float(f32(ey - y2)) ** 2 >= float(f32(f32(100) * sf[kb["octave"][i2]]))
+                    if not (good_a or good_b or far):
+                        continue
+                    den = f32(f32(la * la) + f32(lb * lb))
+                    if not den > 0:
+                        continue
+                    num = f32(f32(f32(la * x2) + f32(lb * y2)) + lc)
+                    if float(f32(f32(num * num) / f32(den * den))) < 3.841 * float(sf2[kb["octave"][i2]]):
+                        best, best_i = d, int(i2)
+                if best_i >= 0:
+                    matched[best_i] = True
+                    exp[i1] = best_i
+        assert np.array_equal(out, exp) and n == (exp >= 0).sum()
+        assert len(set(exp[exp >= 0])) == (exp >= 0).sum()
+    assert n > 10
+    ka, da, mpa, ra, fa, kb, db, mpb, rb, fb, F, sf, sf2 = _tri_inputs(oracle_lib)
+    n2, out2 = oracle_lib.search_for_triangulation(ka, da, mpa, ra, fa, kb, db, mpb, rb, fb, F, (-900.0, 240.0), sf, sf2, False, True)
+    n1, out1 = oracle_lib.search_for_triangulation(ka, da, mpa, ra, fa, kb, db, mpb, rb, fb, F, (-900.0, 240.0), sf, sf2, False, False)
+    assert n2 <= n1 and np.all((out2 == out1) | (out2 == -1))            # the rotation histogram only removes matches

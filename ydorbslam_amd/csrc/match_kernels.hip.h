@@ -237,7 +237,27 @@ struct BowCallDev {
   const int* qFeat; const int2* qRange; const int* featB; const uint8_t* validB;  // validB null for mode 3
   int nq;
   int2* qInfo;
+  // searchForTriangulation only (tri != 0): first/second keyframe keypoints, stereo flags, F (row-major), epipole, level tables
+  int tri;
+  const KeyPointDev* kpsA; const KeyPointDev* kpsB;
+  const uint8_t* goodA; const uint8_t* goodB;
+  float F[9], ex, ey, sfB[8], sf2B[8];
 };
+// isEpipolarLineDistCorrect (orbMatcher.cpp:808-819) and the epipole-distance exemption (:503-506), every operation as written
+__device__ __forceinline__ bool tri_pair_ok(const BowCallDev& B, const KeyPointDev& k1, bool good1, const KeyPointDev& k2, bool good2) {
+  if (!(good1 || good2)) {
+    const float dx = __fsub_rn(B.ex, k2.x), dy = __fsub_rn(B.ey, k2.y);
+    const double far = (double)dx * (double)dx + (double)dy * (double)dy;      // pow(float, 2.0) + pow(float, 2.0): exact squares in double
+    if (!(far >= (double)__fmul_rn(100.0f, B.sfB[k2.octave]))) return false;
+  }
+  const float la = __fadd_rn(__fadd_rn(__fmul_rn(B.F[0], k1.x), __fmul_rn(B.F[3], k1.y)), B.F[6]);
+  const float lb = __fadd_rn(__fadd_rn(__fmul_rn(B.F[1], k1.x), __fmul_rn(B.F[4], k1.y)), B.F[7]);
+  const float lc = __fadd_rn(__fadd_rn(__fmul_rn(B.F[2], k1.x), __fmul_rn(B.F[5], k1.y)), B.F[8]);
+  const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+  if (!(den > 0.0f)) return false;
+  const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, k2.x), __fmul_rn(lb, k2.y)), lc);
+  return (double)__fdiv_rn(__fmul_rn(num, num), __fmul_rn(den, den)) < 3.841 * (double)B.sf2B[k2.octave];
+}
 __global__ __launch_bounds__(256) void k_gather_bow(BowCallDev B, uint32_t* __restrict__ pool, unsigned* __restrict__ poolHead,
                                                     unsigned poolCap, int* __restrict__ status) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -263,6 +283,10 @@ __global__ __launch_bounds__(256) void k_gather_bow(BowCallDev B, uint32_t* __re
           idx = B.featB[rg.x + t];
           pass = !B.validB || B.validB[idx];
           if (pass) dist = hamming256(qd, B.descB + (size_t)idx * 32);
+          if (pass && B.tri) {   // static part of searchForTriangulation's acceptance test (the dynamic part, `<= best` and `matched`, is the replay's)
+            const int i1 = B.qFeat[q];
+            pass = dist <= kThLow && tri_pair_ok(B, B.kpsA[i1], B.goodA[i1] != 0, B.kpsB[idx], B.goodB[idx] != 0);
+          }
         }
         const unsigned long long m = __ballot(pass);
         if (pass) pool[base + written + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)dist << 16) | (uint32_t)idx;
@@ -303,6 +327,7 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
   const CallDev C = calls[blockIdx.x];
   const int nq = call_nq(C);
   const bool bow = C.mode >= 3;
+  const bool lastWins = C.mode == 5;
   const KeyPointDev* kps = C.tkps;
   const int n = takenWords * 32;
   for (int w = lane; w < takenWords; w += 64) {
@@ -347,14 +372,17 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
         if (t < L3.z) {
           rec = t0 == 0 ? recFirst : pool[L3.y + t];
           const unsigned idx = rec & 0xFFFFu;
-          if (!((takenBits[idx >> 5] >> (idx & 31)) & 1u)) key = ((rec >> 16) << 23) | (unsigned)t;
+          // searchForTriangulation keeps a candidate when `dist <= best` (:503): of equal distances the LAST one wins, so its scan
+          // position is stored complemented and the same first-minimum reduction picks it
+          if (!((takenBits[idx >> 5] >> (idx & 31)) & 1u)) key = ((rec >> 16) << 23) | (lastWins ? 0x7FFFFFu - (unsigned)t : (unsigned)t);
         }
         const unsigned b1 = wave_min_u32(key);
         if (b1 == 0xFFFFFFFFu) continue;
         const unsigned b2 = wave_min_u32(key == b1 ? 0xFFFFFFFFu : key);
         // keys are unique, so the low 6 bits of the scan position name the owning lane of this chunk
-        const unsigned r1 = (unsigned)__builtin_amdgcn_readlane((int)rec, (int)(b1 & 63u));
-        const unsigned r2 = b2 != 0xFFFFFFFFu ? (unsigned)__builtin_amdgcn_readlane((int)rec, (int)(b2 & 63u)) : 0u;
+        const unsigned l1 = lastWins ? (0x7FFFFFu - (b1 & 0x7FFFFFu)) & 63u : b1 & 63u, l2 = lastWins ? (0x7FFFFFu - (b2 & 0x7FFFFFu)) & 63u : b2 & 63u;
+        const unsigned r1 = (unsigned)__builtin_amdgcn_readlane((int)rec, (int)l1);
+        const unsigned r2 = b2 != 0xFFFFFFFFu ? (unsigned)__builtin_amdgcn_readlane((int)rec, (int)l2) : 0u;
         if (b1 < best) {
           if (best < b2) { second = best; secondRec = bestRec; } else { second = b2; secondRec = r2; }
           best = b1; bestRec = r1;
@@ -369,12 +397,13 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
           accept = bestDist <= kThHigh && (bestLevel != secondLevel || (float)bestDist <= __fmul_rn(C.ratio, (float)secondDist));
         } else if (C.mode == 1) accept = bestDist < kThHigh;
         else if (C.mode == 2) accept = bestDist <= C.orbDist;
+        else if (C.mode == 5) accept = true;   // every record already passed dist <= 50 and the geometric tests
         else accept = bestDist <= kThLow && (float)bestDist < __fmul_rn(C.ratio, (float)secondDist);
         if (accept) {
           matchNum++;
           if (lane == 0) {
             const int qflags = bow ? 3 : C.queries[q].flags;
-            if (C.mode == 4) C.assigned[q] = bestIdx;   // out[firstIdx] = second-keyframe index; q is remapped by the host
+            if (C.mode >= 4) C.assigned[q] = bestIdx;   // out[firstIdx] = second-keyframe index; q is remapped by the host
             else C.assigned[bestIdx] = q;
             const bool nowTaken = C.mode >= 2 ? true : (qflags & 2) != 0;
             if (nowTaken) takenBits[bestIdx >> 5] |= 1u << (bestIdx & 31);
@@ -419,7 +448,7 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
       if (v < 0) continue;
       const int bin = v >> 24, t = v & 0xFFFFFF;
       if (bin != i1 && bin != i2 && bin != i3) {
-        if (C.mode == 4) C.assigned[q] = -1; else C.assigned[t] = -1;
+        if (C.mode >= 4) C.assigned[q] = -1; else C.assigned[t] = -1;
         culled++;
       }
     }

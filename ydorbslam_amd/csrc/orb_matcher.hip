@@ -58,7 +58,7 @@ struct ydorb_matcher {
   int device = 0;
   hipStream_t stream = nullptr;
   Buf kps, desc, rightX, queries, qdesc, taken, assigned, matchQ, qInfo, cellStart, cellIdx, pool, frames, calls, misc, kps2,
-      desc2, feat, valid, qFeat, qRange, qAngle, sf, heads, sortedKp, sortedDesc;
+      desc2, feat, valid, qFeat, qRange, qAngle, sf, heads, sortedKp, sortedDesc, kps1, good1, good2;
   size_t poolRecords = 1u << 20;
   // cached descriptors of the last batched launch (re-uploaded only when they change)
   std::vector<FrameDev> hFrames;
@@ -361,6 +361,103 @@ int ydorb_search_by_bow(ydorb_matcher_t* m, int32_t mode, const YdBowSide* A, co
   } else {
     for (int q = 0; q < nq; q++) out[qFeat[q]] = res[q];
   }
+  *nMatches = hmisc[2];
+  return YDORB_OK;
+}
+
+int ydorb_search_for_triangulation(ydorb_matcher_t* m, const YdTriSide* A, const YdTriSide* B, const float* F, float ex, float ey,
+                                   const float* sfB, const float* sf2B, int32_t nLevels, int32_t stereoOnly, int32_t checkOri, int32_t* out,
+                                   int32_t* nMatches) {
+  if (!m || !A || !B || !F || !sfB || !sf2B || !out || !nMatches || nLevels < 1 || nLevels > 8 || A->n < 0 || B->n < 0 ||
+      (A->n > 0 && (!A->kps || !A->desc || !A->right_x || !A->has_map_point)) || (B->n > 0 && (!B->kps || !B->desc || !B->right_x || !B->has_map_point))) {
+    set_error("invalid argument");
+    return YDORB_ERR_INVALID_ARG;
+  }
+  HIPCHK(hipSetDevice(m->device));
+  for (int i = 0; i < A->n; i++) out[i] = -1;
+  *nMatches = 0;
+  if (A->n == 0 || B->n == 0) return YDORB_OK;
+  if (B->n > 65535) { set_error("more than 65535 features per frame are not supported"); return YDORB_ERR_UNSUPPORTED; }
+  for (int i = 0; i < B->n; i++)
+    if (B->kps[i].octave < 0 || B->kps[i].octave >= nLevels) { set_error("second keyframe: octave %d outside the %d-level tables", B->kps[i].octave, nLevels); return YDORB_ERR_INVALID_ARG; }
+  // eligibility (:491-492, :497-500) is static: no map point yet, and a good stereo coordinate when only stereo points are wanted
+  std::vector<uint8_t> goodA(A->n), goodB(B->n), validB(B->n);
+  for (int i = 0; i < A->n; i++) goodA[i] = A->right_x[i] >= 0;
+  for (int i = 0; i < B->n; i++) { goodB[i] = B->right_x[i] >= 0; validB[i] = !B->has_map_point[i] && (!stereoOnly || goodB[i]); }
+  std::vector<int> qFeat;
+  std::vector<int2> qRange;
+  std::vector<float> qAngle;
+  size_t records = 0;
+  {
+    int a = 0, b = 0;
+    const YdFeatureVector &fa = A->fv, &fb = B->fv;
+    while (a < fa.n_nodes && b < fb.n_nodes) {   // merge-join of the two ascending node id lists (:484-541)
+      if (fa.node_ids[a] == fb.node_ids[b]) {
+        for (int ia = fa.node_start[a]; ia < fa.node_start[a + 1]; ia++) {
+          const int i1 = fa.feat[ia];
+          if (A->has_map_point[i1] || (stereoOnly && !goodA[i1])) continue;
+          qFeat.push_back(i1);
+          qRange.push_back(make_int2(fb.node_start[b], fb.node_start[b + 1]));
+          qAngle.push_back(A->kps[i1].angle);
+          records += (size_t)(fb.node_start[b + 1] - fb.node_start[b]);
+        }
+        a++; b++;
+      } else if (fa.node_ids[a] < fb.node_ids[b]) {
+        a = (int)(std::lower_bound(fa.node_ids, fa.node_ids + fa.n_nodes, fb.node_ids[b]) - fa.node_ids);
+      } else {
+        b = (int)(std::lower_bound(fb.node_ids, fb.node_ids + fb.n_nodes, fa.node_ids[a]) - fb.node_ids);
+      }
+    }
+  }
+  const int nq = (int)qFeat.size();
+  if (nq == 0) return YDORB_OK;
+  const int nFeatB = B->fv.node_start[B->fv.n_nodes];
+  m->poolRecords = std::max<size_t>(m->poolRecords, records + 1024);
+  int rc;
+  if ((rc = m->desc.ensure((size_t)32 * A->n)) || (rc = m->desc2.ensure((size_t)32 * B->n)) || (rc = m->kps2.ensure(sizeof(YdKeyPoint) * B->n)) ||
+      (rc = m->kps1.ensure(sizeof(YdKeyPoint) * A->n)) || (rc = m->good1.ensure(A->n)) || (rc = m->good2.ensure(B->n)) ||
+      (rc = m->feat.ensure(sizeof(int) * std::max(nFeatB, 1))) || (rc = m->valid.ensure(B->n)) || (rc = m->qFeat.ensure(sizeof(int) * nq)) ||
+      (rc = m->qRange.ensure(sizeof(int2) * nq)) || (rc = m->qAngle.ensure(sizeof(float) * nq)) || (rc = m->qInfo.ensure(sizeof(int2) * nq)) ||
+      (rc = m->matchQ.ensure(sizeof(int) * nq)) || (rc = m->assigned.ensure(sizeof(int) * std::max(nq, B->n))) ||
+      (rc = m->pool.ensure(sizeof(uint32_t) * m->poolRecords)) || (rc = m->calls.ensure(sizeof(CallDev))) || (rc = resetMisc(m, m->stream)))
+    return rc;
+  HIPCHK(hipMemcpyAsync(m->desc.p, A->desc, (size_t)32 * A->n, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(m->desc2.p, B->desc, (size_t)32 * B->n, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(m->kps1.p, A->kps, sizeof(YdKeyPoint) * A->n, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(m->kps2.p, B->kps, sizeof(YdKeyPoint) * B->n, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(m->good1.p, goodA.data(), A->n, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(m->good2.p, goodB.data(), B->n, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(m->valid.p, validB.data(), B->n, hipMemcpyHostToDevice, m->stream));
+  if (nFeatB) HIPCHK(hipMemcpyAsync(m->feat.p, B->fv.feat, sizeof(int) * nFeatB, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(m->qFeat.p, qFeat.data(), sizeof(int) * nq, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(m->qRange.p, qRange.data(), sizeof(int2) * nq, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(m->qAngle.p, qAngle.data(), sizeof(float) * nq, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemsetAsync(m->assigned.p, 0xFF, sizeof(int) * std::max(nq, B->n), m->stream));
+  BowCallDev BC{};
+  BC.descA = m->desc.as<uint8_t>(); BC.descB = m->desc2.as<uint8_t>(); BC.qFeat = m->qFeat.as<int>(); BC.qRange = m->qRange.as<int2>();
+  BC.featB = m->feat.as<int>(); BC.validB = m->valid.as<uint8_t>(); BC.nq = nq; BC.qInfo = m->qInfo.as<int2>();
+  BC.tri = 1; BC.kpsA = m->kps1.as<KeyPointDev>(); BC.kpsB = m->kps2.as<KeyPointDev>(); BC.goodA = m->good1.as<uint8_t>(); BC.goodB = m->good2.as<uint8_t>();
+  for (int i = 0; i < 9; i++) BC.F[i] = F[i];
+  BC.ex = ex; BC.ey = ey;
+  for (int i = 0; i < 8; i++) { BC.sfB[i] = i < nLevels ? sfB[i] : 0.f; BC.sf2B[i] = i < nLevels ? sf2B[i] : 0.f; }
+  hipLaunchKernelGGL(k_gather_bow, dim3((nq + 3) / 4), dim3(256), 0, m->stream, BC, m->pool.as<uint32_t>(), m->misc.as<unsigned>(),
+                     (unsigned)m->poolRecords, m->misc.as<int>() + 1);
+  CallDev C{};
+  C.frame = 0; C.tkps = m->kps2.as<KeyPointDev>(); C.qAngle = m->qAngle.as<float>(); C.queries = nullptr; C.qdesc = nullptr; C.nqPtr = nullptr;
+  C.nq = nq; C.qInfo = m->qInfo.as<int2>(); C.taken = nullptr; C.assigned = m->assigned.as<int>(); C.matchQ = m->matchQ.as<int>();
+  C.count = m->misc.as<int>() + 2; C.mode = 5; C.ratio = 0.f; C.orbDist = 0; C.checkOri = checkOri;
+  HIPCHK(hipMemcpyAsync(m->calls.p, &C, sizeof(CallDev), hipMemcpyHostToDevice, m->stream));
+  const int takenWords = (B->n + 31) / 32;
+  hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), sizeof(unsigned) * takenWords, m->stream, m->calls.as<CallDev>(), (const FrameDev*)nullptr,
+                     m->pool.as<uint32_t>(), takenWords);
+  HIPCHK(hipGetLastError());
+  int hmisc[3];
+  std::vector<int> res(std::max(nq, B->n));
+  HIPCHK(hipMemcpyAsync(hmisc, m->misc.p, sizeof(hmisc), hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipMemcpyAsync(res.data(), m->assigned.p, sizeof(int) * res.size(), hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  if (hmisc[1] != 0) { set_error("bow record pool overflow"); return YDORB_ERR_CAPACITY; }
+  for (int q = 0; q < nq; q++) out[qFeat[q]] = res[q];
   *nMatches = hmisc[2];
   return YDORB_OK;
 }

@@ -2,7 +2,7 @@
 import ctypes as C
 import numpy as np
 
-from ._lib import YdBowSide, YdFeatureVector, YdFrameView, YdorbError, check, lib
+from ._lib import YdBowSide, YdFeatureVector, YdFrameView, YdTriSide, YdorbError, check, lib
 from .extractor import KP_DTYPE
 
 QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("r", "<f4"), ("min_level", "<i4"), ("max_level", "<i4"),
@@ -115,6 +115,23 @@ class OrbMatcher:
         out = np.full(len(kb) if mode == 3 else len(ka), -1, np.int32)
         n = C.c_int32(0)
         check(self._L.ydorb_search_by_bow(self._h, mode, C.byref(A), C.byref(B), self.ratio, int(self.check_orientation), _p(out), C.byref(n)))
+        return n.value, out
+
+    def search_for_triangulation(self, kps_a, desc_a, has_mp_a, right_a, fv_a, kps_b, desc_b, has_mp_b, right_b, fv_b, F, epipole, sf_b, sf2_b,
+                                 stereo_only=False):
+        """OrbMatcher::searchForTriangulation (orbMatcher.cpp:463-565).  Returns (n_matches, out[first idx] = second idx or -1)."""
+        ka = np.ascontiguousarray(kps_a, KP_DTYPE); kb = np.ascontiguousarray(kps_b, KP_DTYPE)
+        da = np.ascontiguousarray(desc_a, np.uint8); db = np.ascontiguousarray(desc_b, np.uint8)
+        ma = np.ascontiguousarray(has_mp_a, np.uint8); mb = np.ascontiguousarray(has_mp_b, np.uint8)
+        ra = np.ascontiguousarray(right_a, np.float32); rb = np.ascontiguousarray(right_b, np.float32)
+        Fm = np.ascontiguousarray(F, np.float32).reshape(9)
+        s1 = np.ascontiguousarray(sf_b, np.float32); s2 = np.ascontiguousarray(sf2_b, np.float32)
+        A = YdTriSide(_p(ka), _p(da), _p(ra), _p(ma), len(ka), fv_a.c())
+        B = YdTriSide(_p(kb), _p(db), _p(rb), _p(mb), len(kb), fv_b.c())
+        out = np.full(len(ka), -1, np.int32)
+        n = C.c_int32(0)
+        check(self._L.ydorb_search_for_triangulation(self._h, C.byref(A), C.byref(B), _p(Fm), float(epipole[0]), float(epipole[1]), _p(s1), _p(s2),
+                                                     len(s1), int(stereo_only), int(self.check_orientation), _p(out), C.byref(n)))
         return n.value, out
 
     def match_consecutive_device(self, d_kps, d_desc, d_n, cap, n_frames, width, height, th, scale_factors, d_assigned, d_counts,
