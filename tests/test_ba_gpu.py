@@ -132,14 +132,16 @@ def test_pose_only_optimisation_batch(oracle_lib):
     probs = [synth_pose_problem(n, seed=50 + i, outlier_frac=o, mono_frac=m) for i, (n, o, m) in enumerate(
         [(400, 0.1, 0.3), (1000, 0.05, 0.0), (150, 0.3, 1.0), (9, 0.0, 0.5), (2, 0.0, 0.0), (2500, 0.15, 0.2), (40, 0.5, 0.5)])]
     got = y.Optimizer.optimize_poses(probs)
-    for p, g in zip(probs, got):
+    for i, (p, g) in enumerate(zip(probs, got)):
         r = oracle_lib.pose_optimize(p)
-        assert g["inliers"] == r["inliers"] and (g["trials"] > 0) == (r["trials"] > 0)
-        assert np.array_equal(g["outlier"], r["outlier"])
-        assert np.array_equal(np.isnan(g["chi2"]), np.isnan(r["chi2"]))
+        tag = "frame %d (E=%d): gpu chi2 %s oracle chi2 %s, inliers %d/%d, trials %d/%d" % (
+            i, len(p["info"]), g["chi2"], r["chi2"], g["inliers"], r["inliers"], g["trials"], r["trials"])
+        assert g["inliers"] == r["inliers"] and (g["trials"] > 0) == (r["trials"] > 0), tag
+        assert np.array_equal(g["outlier"], r["outlier"]), tag
+        assert np.array_equal(np.isnan(g["chi2"]), np.isnan(r["chi2"])), tag
         ok = ~np.isnan(r["chi2"])
-        assert np.allclose(g["chi2"][ok], r["chi2"][ok], rtol=1e-6, atol=0)
-        assert np.allclose(g["pose"].astype(np.float32), r["pose"].astype(np.float32), rtol=1e-4, atol=1e-6)
+        assert np.allclose(g["chi2"][ok], r["chi2"][ok], rtol=1e-6, atol=0), tag
+        assert np.allclose(g["pose"].astype(np.float32), r["pose"].astype(np.float32), rtol=1e-4, atol=1e-6), tag + " pose %s vs %s" % (g["pose"], r["pose"])
     assert got[4]["inliers"] == 0 and np.array_equal(got[4]["pose"], probs[4]["pose"])      # < 3 correspondences: untouched
     one = y.Optimizer.optimize_poses(probs[:1])[0]                                            # batch position does not matter
     assert one["pose"].tobytes() == got[0]["pose"].tobytes() and np.array_equal(one["outlier"], got[0]["outlier"])
