@@ -193,6 +193,17 @@ int ydorb_search_by_bow(ydorb_matcher_t* h, int32_t mode, const YdBowSide* a, co
                         int32_t check_orientation, int32_t* out, int32_t* n_matches);
 
 
+/* Search half of OrbMatcher::fuseByProjection (src/orbMatcher.cpp:682-745; fuseBySim3 :746-807 runs the same test on a
+ * Sim3-projected point).  One query per map point that passed the reference's own predicates (not bad, not already in the keyframe,
+ * in front of the camera, inside the image, inside the distance invariance, viewing angle — flags bit 0 set; other queries are
+ * skipped): u, v = projection, r = th * scaleFactor[predicted level], ur = projected right x, level = predicted level.
+ * best_idx[q] = the keyframe feature with the smallest descriptor distance (<= 50) among the window's features at level
+ * predicted-1 .. predicted whose squared reprojection error passes the chi-square test (5.99 mono / 7.81 stereo), or -1.
+ * The caller then walks the list in order and applies beReplacedBy / addObservation exactly as :726-737 (re-checking isBad /
+ * isInKeyFrame at each step, because earlier replacements can change them; they cannot change a later point's search result). */
+int ydorb_fuse_search(ydorb_matcher_t* h, const YdFrameView* keyframe, const YdQuery* queries, const uint8_t* qdesc, int32_t n_queries,
+                      const float* inv_scale_factor_squares, int32_t n_levels, int32_t* best_idx, int32_t* n_found);
+
 /* OrbMatcher::searchForTriangulation (src/orbMatcher.cpp:463-565): BoW-guided search between the features of two
  * keyframes that have no MapPoint yet, kept when the second feature lies on the first one's epipolar line (:808-819).
  * has_map_point[i] != 0 <=> KeyFrame::getMapPoint(i) is set; right_x = m_v_rightXcords.  F = _fMatrix_first2second row-major

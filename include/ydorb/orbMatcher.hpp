@@ -231,6 +231,59 @@ int searchByBowInTwoKeyFrames(ydorb_matcher_t* m, KeyFramePtr kf1, KeyFramePtr k
   return n;
 }
 
+// fuseByProjection, src/orbMatcher.cpp:682-745.  Pass 1 (host, the reference's own float cv::Mat arithmetic): projection, predicted
+// level and the predicates of :688 / :704-708 for every map point.  Pass 2 (GPU): the window search with the level and chi-square tests.
+// Pass 3 (host, list order): the replace / add bookkeeping of :726-737 on the search results.  A replacement can make a LATER list entry
+// bad or put it into the keyframe, so those two predicates are evaluated again at each entry's turn, as the reference does implicitly;
+// it cannot change a later entry's search result (the survivor of a replacement is either already in the keyframe or already processed).
+template <class KeyFramePtr, class MapPointPtr, class FrameT>
+int fuseByProjection(ydorb_matcher_t* m, KeyFramePtr kf, const std::vector<MapPointPtr>& mps, float th) {
+  const cv::Mat Rcw = kf->getRotation_c2w(), tcw = kf->getTranslation_c2w(), Ow = kf->getCameraOriginInWorld();
+  std::vector<YdQuery> q(mps.size());
+  cv::Mat desc((int)mps.size() + 1, 32, CV_8U);   // rows of skipped entries are never read (flags 0)
+  for (size_t i = 0; i < mps.size(); i++) {
+    YdQuery& Q = q[i];
+    Q = YdQuery{};
+    const MapPointPtr& mp = mps[i];
+    if (!mp || mp->isBad() || mp->isInKeyFrame(kf)) continue;
+    const cv::Mat Pw = mp->getPosInWorld();
+    const cv::Mat Pc = Rcw * Pw + tcw;
+    const float xc = Pc.template at<float>(0), yc = Pc.template at<float>(1), zc = Pc.template at<float>(2);
+    const float u = FrameT::m_flt_fx * xc / zc + FrameT::m_flt_cx, v = FrameT::m_flt_fy * yc / zc + FrameT::m_flt_cy;
+    const float ur = u - FrameT::m_flt_baseLineTimesFx / zc;
+    const cv::Mat PO = Pw - Ow;
+    const float dist3D = (float)cv::norm(PO);
+    const int level = mp->predictScaleLevel(dist3D, kf);
+    Q.u = u; Q.v = v; Q.ur = ur; Q.level = level; Q.min_level = -1; Q.max_level = -1;
+    Q.r = th * kf->m_v_scaleFactors[level];
+    const bool ok = zc >= 0.0f && kf->isInImage(u, v) && dist3D >= mp->getMinDistanceInvariance() && dist3D <= mp->getMaxDistanceInvariance() &&
+                    PO.dot(mp->getNormal()) >= 0.5 * dist3D;
+    Q.flags = ok ? 1 : 0;
+    mp->getDescriptor().copyTo(desc.row((int)i));
+  }
+  YdFrameView V = frameView(*kf);
+  std::vector<int32_t> best(mps.size() + 1, -1);
+  int32_t found = 0;
+  if (ydorb_fuse_search(m, &V, q.data(), desc.data, (int32_t)mps.size(), kf->m_v_invScaleFactorSquares.data(),
+                        (int32_t)kf->m_v_invScaleFactorSquares.size(), best.data(), &found) != YDORB_OK)
+    throw std::runtime_error(std::string("ydorb: ") + ydorb_last_error());
+  int fuseNum = 0;
+  for (size_t i = 0; i < mps.size(); i++) {
+    const MapPointPtr& mp = mps[i];
+    if (best[i] < 0 || !(q[i].flags & 1) || mp->isBad() || mp->isInKeyFrame(kf)) continue;
+    MapPointPtr inKF = kf->getMapPoint(best[i]);
+    if (inKF) {
+      if (!inKF->isBad() && inKF->getObservationsNum() > mp->getObservationsNum()) mp->beReplacedBy(inKF);
+      else if (!inKF->isBad() && inKF->getObservationsNum() <= mp->getObservationsNum()) inKF->beReplacedBy(mp);
+    } else {
+      mp->addObservation(kf, best[i]);
+      kf->addMapPoint(mp, best[i]);
+    }
+    fuseNum++;
+  }
+  return fuseNum;
+}
+
 // searchForTriangulation, src/orbMatcher.cpp:463-565: the epipole (:465-470) and the stereo / map-point flags are gathered here exactly as
 // the reference reads them; pairs come back in first-index order like the loop at :557-563.
 template <class KeyFramePtr, class FrameT>

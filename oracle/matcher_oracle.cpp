@@ -195,6 +195,36 @@ int yo_search_by_projection(void* fp, int mode, const void* queries, const uint8
   return matchNum;
 }
 
+// The search half of OrbMatcher::fuseByProjection (orbMatcher.cpp:682-745; fuseBySim3 :746-807 uses the same test): for every map point
+// that passed the caller-side predicates (:688, :704-708 — flags bit 0), the keyframe feature with the smallest descriptor distance
+// among those in the projection window whose level is predicted-1 .. predicted (:715-716) and whose reprojection error passes the
+// chi-square test (:711-718).  Query fields used: u, v (projection), r (radius), ur (projected right x), level (predicted level).
+// best[q] = feature index when bestDist <= TH_LOW (:725), else -1.  The replace / add bookkeeping (:726-737) stays with the caller
+// and runs in list order on these results.  invSigma2 = the keyframe's m_v_invScaleFactorSquares.
+int yo_fuse_search(void* fp, const void* queries, const uint8_t* qdesc, int nq, const float* invSigma2, int* best) {
+  Frame& F = *(Frame*)fp;
+  const Query* Q = (const Query*)queries;
+  int found = 0;
+  for (int q = 0; q < nq; q++) {
+    best[q] = -1;
+    if (!(Q[q].flags & 1)) continue;
+    const std::vector<int> vIdx = F.keyPointsInArea(Q[q].u, Q[q].v, Q[q].r, -1, -1);
+    int bestDist = 256, bestIdx = -1;
+    for (int idx : vIdx) {
+      const int level = F.kps[idx].octave;
+      const float monoErr = pow(F.kps[idx].x - Q[q].u, 2.0) + pow(F.kps[idx].y - Q[q].v, 2.0);
+      const float stereoErr = monoErr + pow(F.rightX[idx] - Q[q].ur, 2.0);
+      if (level >= Q[q].level - 1 && level <= Q[q].level &&
+          ((F.rightX[idx] >= 0 && stereoErr * invSigma2[level] <= 7.81) || (F.rightX[idx] < 0 && monoErr * invSigma2[level] <= 5.99))) {
+        const int dist = descriptorDistance(qdesc + (size_t)q * 32, &F.desc[(size_t)idx * 32]);
+        if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+      }
+    }
+    if (bestDist <= TH_LOW) { best[q] = bestIdx; found++; }
+  }
+  return found;
+}
+
 // DBoW3::FeatureVector as CSR: nodeIds ascending (std::map order), nodeStart[nNodes+1], feat[] in append order.
 // mode 3: searchByBowInKeyFrameAndFrame  orbMatcher.cpp:303-379 — out[frameIdx] = keyframe feature index (stands for its MapPoint)
 // mode 4: searchByBowInTwoKeyFrames      orbMatcher.cpp:380-462 — out[firstIdx] = second-keyframe feature index

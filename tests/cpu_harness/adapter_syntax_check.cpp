@@ -21,6 +21,8 @@ struct MapPoint {
   float getMaxDistanceInvariance(); float getMinDistanceInvariance(); int predictScaleLevel(const float&, const Frame&);
   std::map<std::shared_ptr<KeyFrame>, int> getObservations(); void eraseObservation(std::shared_ptr<KeyFrame>);
   void setPosInWorld(const cv::Mat&); void updateNormalAndDepth();
+  bool isInKeyFrame(std::shared_ptr<KeyFrame>); cv::Mat getNormal(); int predictScaleLevel(const float&, std::shared_ptr<KeyFrame>);
+  void beReplacedBy(std::shared_ptr<MapPoint>); void addObservation(std::shared_ptr<KeyFrame>, int);
 };
 typedef std::map<unsigned, std::vector<unsigned>> FeatureVector;
 struct Frame {
@@ -35,7 +37,8 @@ struct KeyFrame {
   std::vector<cv::KeyPoint> m_v_keyPoints; cv::Mat m_cvMat_descriptors; FeatureVector m_bow_keyPointsVec; std::vector<float> m_v_rightXcords, m_v_invScaleFactorSquares;
   long int m_int_keyFrameID, m_int_localBAForKeyFrameID, m_int_fixedBAForKeyFrameID, m_int_globalBAForKeyFrameID; cv::Mat m_cvMat_T_c2w_GlobalBA;
   int m_int_keyPointsNum; std::vector<float> m_v_scaleFactors, m_v_scaleFactorSquares;
-  std::shared_ptr<MapPoint> getMapPoint(const int&); cv::Mat getCameraOriginInWorld(); cv::Mat getRotation_c2w(); cv::Mat getTranslation_c2w();
+  std::shared_ptr<MapPoint> getMapPoint(const int&); void addMapPoint(std::shared_ptr<MapPoint>, const int&); bool isInImage(const float&, const float&) const;
+  static float m_flt_minX, m_flt_maxX, m_flt_minY, m_flt_maxY; cv::Mat getCameraOriginInWorld(); cv::Mat getRotation_c2w(); cv::Mat getTranslation_c2w();
   std::vector<std::shared_ptr<MapPoint>> getMatchedMapPointsVec(); std::vector<std::shared_ptr<KeyFrame>> getOrderedConnectedKeyFrames();
   bool isBad(); cv::Mat getCameraPoseByTransform_c2w(); void setCameraPoseByTransform_c2w(cv::Mat); void eraseMatchedMapPoint(std::shared_ptr<MapPoint>);
 };
@@ -54,6 +57,7 @@ int check(Frame& a, Frame& b, std::shared_ptr<KeyFrame> kf, std::shared_ptr<KeyF
   n += ya::searchByBowInTwoKeyFrames(ya::matcher(), kf, kf2, mps, 0.75f, true);
   n += ya::computeDescriptorsDistance(a.m_cvMat_descriptors, b.m_cvMat_descriptors);
   std::vector<std::pair<int, int>> pairs;
+  n += ya::fuseByProjection<std::shared_ptr<KeyFrame>, std::shared_ptr<MapPoint>, Frame>(ya::matcher(), kf, mps, 3.0f);
   n += ya::searchForTriangulation<std::shared_ptr<KeyFrame>, Frame>(ya::matcher(), kf, kf2, a.m_cvMat_T_c2w, pairs, false, true);
 #ifdef YDORB_CHECK_OPTIMIZER
   bool stop = false;

@@ -25,6 +25,7 @@ struct Mat {
   template <class T> T* ptr(); template <class T> const T* ptr() const;
   void copyTo(Mat) const;
   void create(int, int, int);
+  double dot(const Mat&) const;
   void copyTo(const _OutputArray&) const;
   static MatExpr eye(int, int, int);
 };

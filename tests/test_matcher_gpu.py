@@ -162,3 +162,32 @@ def test_search_for_triangulation(oracle_lib, scene, stereo_only):
             assert np.array_equal(o_gpu, o_ref)
             total += n_ref
     assert total > 50
+
+
+@pytest.mark.parametrize("stereo", [False, True])
+def test_fuse_search(oracle_lib, scene, stereo):
+    """Search half of OrbMatcher::fuseByProjection (orbMatcher.cpp:682-745, SURVEY 8f rank 3): window without level check, explicit level
+    window predicted-1 .. predicted, chi-square test on the float squared error, best distance <= 50 — identical indices to the oracle.
+    (With the reference's th = 3 the `|dx| > r` test of frame.cpp:353 leaves no candidate that can pass the chi-square test; small
+    radii are used here so that every branch is exercised.)"""
+    import ydorbslam_amd as y
+    total = 0
+    for si, s in enumerate(scene):
+        bounds = (0.0, 640.0, 0.0, 480.0)
+        rng = np.random.default_rng(300 + si)
+        kb = s["kb"]
+        right = np.where(rng.random(len(kb)) > 0.4, kb["x"] - 20 + rng.normal(0, 0.5, len(kb)), -1).astype(np.float32) if stereo else None
+        sf = s["sf"].astype(np.float32)
+        inv_s2 = (np.float32(1.0) / (sf * sf)).astype(np.float32)
+        for th in (0.6, 1.0, 1.6):
+            q = projection_queries(s["ka"], s["sf"], s["dx"], s["dy"], th, 1, seed=500 + si, stereo=stereo)
+            q["min_level"], q["max_level"] = -1, -1
+            q["level"] = np.clip(s["ka"]["octave"] + rng.integers(-1, 2, len(q)), 0, 7)
+            q["r"] = (np.float32(th) * sf[q["level"]]).astype(np.float32)
+            fo = oracle_lib.FrameOracle(kb, s["db"], bounds, right)
+            n_ref, b_ref = fo.fuse_search(q, s["da"], inv_s2)
+            m = y.OrbMatcher(0.6, True)
+            n_gpu, b_gpu = m.fuse_search(y.FrameView(kb, s["db"], bounds, right), q, s["da"], inv_s2)
+            assert n_gpu == n_ref and np.array_equal(b_gpu, b_ref)
+            total += n_ref
+    assert total > 20

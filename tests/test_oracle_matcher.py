@@ -174,3 +174,38 @@ def test_triangulation_search_matches_independent_statement(oracle_lib):
     n2, out2 = oracle_lib.search_for_triangulation(ka, da, mpa, ra, fa, kb, db, mpb, rb, fb, F, (-900.0, 240.0), sf, sf2, False, True)
     n1, out1 = oracle_lib.search_for_triangulation(ka, da, mpa, ra, fa, kb, db, mpb, rb, fb, F, (-900.0, 240.0), sf, sf2, False, False)
     assert n2 <= n1 and np.all((out2 == out1) | (out2 == -1))            # the rotation histogram only removes matches
+
+
+def test_fuse_search_matches_brute_force_statement(oracle_lib):
+    """Search half of fuseByProjection (orbMatcher.cpp:682-745) against a brute-force statement built on the oracle's own
+    getKeyPointsInArea (checked separately above): level window, float chi-square test, first minimum, <= 50."""
+    f32 = np.float32
+    ka, da, kb, db, sf = _scene(oracle_lib)
+    sf = sf.astype(np.float32)
+    inv_s2 = (f32(1.0) / (sf * sf)).astype(np.float32)
+    rng = np.random.default_rng(9)
+    right = np.where(rng.random(len(kb)) > 0.5, kb["x"] - 20 + rng.normal(0, 0.5, len(kb)), -1).astype(np.float32)
+    fo = oracle_lib.FrameOracle(kb, db, (0.0, 640.0, 0.0, 480.0), right)
+    q = projection_queries(ka, sf, 5, -3, 1.0, 1, seed=77, stereo=True)
+    q["min_level"], q["max_level"] = -1, -1
+    q["level"] = np.clip(ka["octave"] + rng.integers(-1, 2, len(q)), 0, 7)
+    q["r"] = (f32(1.0) * sf[q["level"]]).astype(np.float32)
+    n, best = fo.fuse_search(q, da, inv_s2)
+    exp = np.full(len(q), -1, np.int64)
+    for i in range(len(q)):
+        if not (q["flags"][i] & 1):
+            continue
+        bd, bi = 256, -1
+        for idx in fo.keypoints_in_area(float(q["u"][i]), float(q["v"][i]), float(q["r"][i])):
+            lvl = int(kb["octave"][idx])
+            mono = f32(float(f32(kb["x"][idx] - q["u"][i])) ** 2 + float(f32(kb["y"][idx] - q["v"][i])) ** 2)
+            stereo = f32(float(mono) + float(f32(right[idx] - q["ur"][i])) ** 2)
+            ok = (right[idx] >= 0 and float(f32(stereo * inv_s2[lvl])) <= 7.81) or (right[idx] < 0 and float(f32(mono * inv_s2[lvl])) <= 5.99)
+            if not (q["level"][i] - 1 <= lvl <= q["level"][i] and ok):
+                continue
+            d = int(np.unpackbits(da[i] ^ db[idx]).sum())
+            if d < bd:
+                bd, bi = d, int(idx)
+        if bd <= 50:
+            exp[i] = bi
+    assert np.array_equal(best, exp) and n == (exp >= 0).sum() > 10

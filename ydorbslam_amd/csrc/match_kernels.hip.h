@@ -124,9 +124,10 @@ struct CallDev {          // one search call (one target frame, one ordered quer
   int* assigned;          // [n] in/out (query index or -1)
   int* matchQ;            // [nq] scratch: accepted target index per query (or -1), used by the histogram cull
   int* count;             // out: matchNum
-  int mode;               // 0 M1, 1 M3, 2 M4 (projection family); 3 M5, 4 M6 (BoW family)
+  int mode;               // 0 M1, 1 M3, 2 M4 (projection family); 3 M5, 4 M6 (BoW family); 5 searchForTriangulation; 6 fuse search
   float ratio;
   int orbDist, checkOri;
+  float invSigma2[8];     // mode 6: the keyframe's m_v_invScaleFactorSquares
 };
 __device__ __forceinline__ int call_nq(const CallDev& C) { return C.nqPtr ? *C.nqPtr : C.nq; }
 
@@ -207,7 +208,17 @@ __global__ __launch_bounds__(256) void k_gather_projection(const CallDev* __rest
               if (Q.minLevel > 0 || Q.maxLevel >= 0)
                 if (octave < Q.minLevel || (Q.maxLevel >= 0 && octave < Q.maxLevel)) pass = false;
               if (!(fabsf(__fsub_rn(kp.x, Q.u)) > Q.r && fabsf(__fsub_rn(kp.y, Q.v)) < Q.r)) pass = false;
-              if (pass && C.mode != 2 && F.rightX) {
+              if (pass && C.mode == 6) {
+                // fuseByProjection's candidate test (orbMatcher.cpp:711-718): level predicted-1 .. predicted and the chi-square test
+                // on the squared reprojection error — pow(float, 2.0) sums in double, stored to float, times the float inverse sigma^2
+                const float rx = F.rightX ? F.rightX[idx] : -1.0f;
+                const double ax = (double)__fsub_rn(kp.x, Q.u), ay = (double)__fsub_rn(kp.y, Q.v), ar = (double)__fsub_rn(rx, Q.ur);
+                const float monoErr = (float)(ax * ax + ay * ay);
+                const float stereoErr = (float)((double)monoErr + ar * ar);
+                const bool lv = octave >= Q.level - 1 && octave <= Q.level;
+                const float is2 = C.invSigma2[octave & 7];
+                pass = lv && ((rx >= 0 && (double)__fmul_rn(stereoErr, is2) <= 7.81) || (rx < 0 && (double)__fmul_rn(monoErr, is2) <= 5.99));
+              } else if (pass && C.mode != 2 && F.rightX) {
                 const float rx = F.rightX[idx];
                 if (!(rx <= 0 || fabsf(__fsub_rn(Q.ur, rx)) <= Q.rs)) pass = false;
               }
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
   const int lane = threadIdx.x;
   const CallDev C = calls[blockIdx.x];
   const int nq = call_nq(C);
-  const bool bow = C.mode >= 3;
+  const bool bow = C.mode >= 3 && C.mode <= 5;
   const bool lastWins = C.mode == 5;
   const KeyPointDev* kps = C.tkps;
   const int n = takenWords * 32;
@@ -398,6 +409,7 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
         } else if (C.mode == 1) accept = bestDist < kThHigh;
         else if (C.mode == 2) accept = bestDist <= C.orbDist;
         else if (C.mode == 5) accept = true;   // every record already passed dist <= 50 and the geometric tests
+        else if (C.mode == 6) accept = bestDist <= kThLow;   // fuseByProjection :725; nothing is taken, the caller applies the result
         else accept = bestDist <= kThLow && (float)bestDist < __fmul_rn(C.ratio, (float)secondDist);
         if (accept) {
           matchNum++;
@@ -405,7 +417,7 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
             const int qflags = bow ? 3 : C.queries[q].flags;
             if (C.mode >= 4) C.assigned[q] = bestIdx;   // out[firstIdx] = second-keyframe index; q is remapped by the host
             else C.assigned[bestIdx] = q;
-            const bool nowTaken = C.mode >= 2 ? true : (qflags & 2) != 0;
+            const bool nowTaken = C.mode == 6 ? false : C.mode >= 2 ? true : (qflags & 2) != 0;
             if (nowTaken) takenBits[bestIdx >> 5] |= 1u << (bestIdx & 31);
             C.matchQ[q] = bestIdx;
           }

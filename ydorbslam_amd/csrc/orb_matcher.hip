@@ -190,7 +190,8 @@ int ydorb_descriptor_distance_rows(ydorb_matcher_t* m, const uint8_t* a, const u
 
 static int searchProjectionImpl(ydorb_matcher_t* m, int32_t mode, const YdFrameView* fv, const YdQuery* queries, const uint8_t* qdesc,
                                 int32_t nq, float ratio, int32_t orbDist, int32_t checkOri, uint8_t* taken, int32_t* assigned,
-                                int32_t* nMatches, std::vector<uint32_t>* recordsOut) {
+                                int32_t* nMatches, std::vector<uint32_t>* recordsOut, const float* invSigma2 = nullptr, int nLevels = 0,
+                                int32_t* bestOut = nullptr) {
   HIPCHK(hipSetDevice(m->device));
   const int n = fv->n;
   if (n > 65535) { set_error("frames with more than 65535 keypoints are not supported"); return YDORB_ERR_UNSUPPORTED; }
@@ -213,6 +214,7 @@ static int searchProjectionImpl(ydorb_matcher_t* m, int32_t mode, const YdFrameV
     C.queries = m->queries.as<QueryDev>(); C.qdesc = m->qdesc.as<uint8_t>(); C.nqPtr = nullptr; C.nq = nq;
     C.qInfo = m->qInfo.as<int2>(); C.taken = m->taken.as<uint8_t>(); C.assigned = m->assigned.as<int>(); C.matchQ = m->matchQ.as<int>();
     C.count = m->misc.as<int>() + 2; C.mode = mode; C.ratio = ratio; C.orbDist = orbDist; C.checkOri = checkOri;
+    for (int i = 0; i < 8; i++) C.invSigma2[i] = (invSigma2 && i < nLevels) ? invSigma2[i] : 0.f;
     HIPCHK(hipMemcpyAsync(m->calls.p, &C, sizeof(CallDev), hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(k_gather_projection, dim3((nq + 3) / 4, 1), dim3(256), 0, m->stream, m->calls.as<CallDev>(), m->frames.as<FrameDev>(), nq,
                        m->pool.as<uint32_t>(), m->misc.as<unsigned>(), (unsigned)((size_t)nq * kSlot + m->poolRecords), m->misc.as<int>() + 1);
@@ -238,6 +240,7 @@ static int searchProjectionImpl(ydorb_matcher_t* m, int32_t mode, const YdFrameV
     }
     if (taken) HIPCHK(hipMemcpy(taken, m->taken.p, n, hipMemcpyDeviceToHost));
     if (assigned) HIPCHK(hipMemcpy(assigned, m->assigned.p, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (bestOut) HIPCHK(hipMemcpy(bestOut, m->matchQ.p, sizeof(int) * nq, hipMemcpyDeviceToHost));
     *nMatches = hmisc[2];
     return YDORB_OK;
   }
@@ -254,6 +257,20 @@ int ydorb_search_by_projection(ydorb_matcher_t* m, int32_t mode, const YdFrameVi
     return YDORB_ERR_INVALID_ARG;
   }
   return searchProjectionImpl(m, mode, fv, queries, qdesc, nq, ratio, orbDist, checkOri, taken, assigned, nMatches, nullptr);
+}
+
+int ydorb_fuse_search(ydorb_matcher_t* m, const YdFrameView* fv, const YdQuery* queries, const uint8_t* qdesc, int32_t nq,
+                      const float* invSigma2, int32_t nLevels, int32_t* best, int32_t* nFound) {
+  if (!m || !fv || !nFound || nq < 0 || fv->n < 0 || (nq > 0 && (!queries || !qdesc || !best)) || !invSigma2 || nLevels < 1 || nLevels > 8 ||
+      (fv->n > 0 && (!fv->kps || !fv->desc)) || !(fv->max_x > fv->min_x) || !(fv->max_y > fv->min_y)) {
+    set_error("invalid argument");
+    return YDORB_ERR_INVALID_ARG;
+  }
+  for (int q = 0; q < nq; q++) best[q] = -1;
+  *nFound = 0;
+  for (int i = 0; i < fv->n; i++)
+    if (fv->kps[i].octave < 0 || fv->kps[i].octave >= nLevels) { set_error("keyframe feature %d: octave %d outside the %d-level table", i, fv->kps[i].octave, nLevels); return YDORB_ERR_INVALID_ARG; }
+  return searchProjectionImpl(m, 6, fv, queries, qdesc, nq, 0.f, 0, 0, nullptr, nullptr, nFound, nullptr, invSigma2, nLevels, best);
 }
 
 int ydorb_frame_keypoints_in_area(ydorb_matcher_t* m, const YdFrameView* fv, float x, float y, float r, int32_t minLevel, int32_t maxLevel,
