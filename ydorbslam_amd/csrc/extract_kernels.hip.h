@@ -987,10 +987,16 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, s
   // padded-row coordinates: level x <-> x + 19, so the tile's first source column x0-3 sits at byte x0+16: dword aligned
   // (pitch and padOff are multiples of 64), and the source loads are whole dwords.
   const uint8_t* padded = pyr + (size_t)f * pyrFrameStride + L.padOff;
-  for (int i = threadIdx.x; i < SH * SWW; i += 256) {
-    const int r = i / SWW, wd = i - r * SWW;
-    const int prow = min(y0 + r + kPad - 3, L.h + 2 * kPad - 1), pcol = x0 + 16 + 4 * wd;
-    src[i] = pcol < L.pitch ? *reinterpret_cast<const uint32_t*>(padded + (size_t)prow * L.pitch + pcol) : 0u;
+  {  // 14 source rows of 18 dwords per pass (252 of the 256 threads): the row / dword split is computed once per thread
+    const int r0 = threadIdx.x / SWW, wd = threadIdx.x - r0 * SWW;
+    const int pcol = x0 + 16 + 4 * wd;
+    const bool colOk = pcol < L.pitch;
+    if (r0 < 14)
+#pragma unroll
+      for (int r = r0; r < SH; r += 14) {
+        const int prow = min(y0 + r + kPad - 3, L.h + 2 * kPad - 1);
+        src[r * SWW + wd] = colOk ? *reinterpret_cast<const uint32_t*>(padded + (size_t)prow * L.pitch + pcol) : 0u;
+      }
   }
   __syncthreads();
   // horizontal pass, two source rows per thread: the 7 taps of an output are two v_dot4_u32_u8 over the byte windows
