@@ -242,25 +242,25 @@ def main():
     t_dom = stages[dom] * 1e-3
     launch_frames = F if dom in ("grid_build", "gather_distances", "resolve") else FL
     achieved = kbytes.get(dom, A_frame) * launch_frames / t_dom if t_dom > 0 else 0.0
-    # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01d_pmc_hbm_traffic.csv: separate
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01f_pmc_hbm_traffic.csv: separate
     # FETCH_SIZE / WRITE_SIZE runs of the same kernels at 128 frames per launch; FETCH under-counts this 4-byte access pattern
     # by 1.33x, calibrated on k_pyr_level0's known read size; WRITE_SIZE is exact) scaled to this run's frames per launch.
     traffic = None
     try:
         import csv
-        stage_kernels = {"pyramid": ("k_pyr_level0", "k_pyr_resize"), "fast_cells": ("k_fast_cells",), "blur": ("k_blur",),
+        stage_kernels = {"pyramid": ("k_pyr_level0", "k_pyr_resize", "k_pyr_borders"), "fast_cells": ("k_fast_cells",), "blur": ("k_blur",),
                          "quadtree_after_blur": ("k_quadtree_flat", "k_quadtree"), "orient_describe": ("k_orient_describe",)}
-        rows = {r["kernel"]: r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01d_pmc_hbm_traffic.csv")))}
+        rows = {r["kernel"]: r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01f_pmc_hbm_traffic.csv")))}
         if dom in stage_kernels:
             per_frame = sum(float(rows[k]["fetch_MB_per_frame_raw"]) * 1.33 + float(rows[k]["write_MB_per_frame"]) for k in stage_kernels[dom])
             traffic = per_frame * 1e6 * (F / NEX)
     except Exception:  # noqa: BLE001
         traffic = None
     # what actually bounds the dominant kernel: share of the launch's SIMD cycles spent issuing vector instructions
-    # (4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), committed SQ pass profiles/r01d_pmc_sq_valu.csv)
+    # (4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), committed SQ pass profiles/r01f_pmc_sq_valu.csv)
     valu_busy = None
     try:
-        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01d_pmc_sq_valu.csv"))):
+        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01f_pmc_sq_valu.csv"))):
             if dom in stage_kernels and r["kernel"] == stage_kernels[dom][0]:
                 valu_busy = float(r["VALU_busy_pct_of_SIMD_cycles"]) / 100.0
     except Exception:  # noqa: BLE001

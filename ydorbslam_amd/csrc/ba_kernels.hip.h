@@ -1044,7 +1044,8 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(int nFrames, con
   if (f >= nFrames) return;
   const int e0 = edgeStart[f], E = edgeStart[f + 1] - e0;
   for (int k = tid; k < 4; k += kPoseThreads) chi2Log[4 * f + k] = __longlong_as_double(0x7ff8000000000000ll);
-  if (E < 3) {                               // :443-445
+  if (E < 3) {                               // :443-445 (m_v_isOutliers of the few correspondences was already cleared at :392)
+    for (int i = tid; i < E; i += kPoseThreads) outlier[e0 + i] = 0;
     if (tid == 0) { nInliers[f] = 0; trialsOut[f] = 0; }
     return;
   }

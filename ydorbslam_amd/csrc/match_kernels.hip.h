@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void k_gather_projection(const CallDev* __rest
                 const float monoErr = (float)(ax * ax + ay * ay);
                 const float stereoErr = (float)((double)monoErr + ar * ar);
                 const bool lv = octave >= Q.level - 1 && octave <= Q.level;
-                const float is2 = C.invSigma2[octave & 7];
+                const float is2 = calls[blockIdx.y].invSigma2[octave & 7];   // indexed from global memory: a dynamic index into the local copy of the call record would move the whole record to scratch
                 pass = lv && ((rx >= 0 && (double)__fmul_rn(stereoErr, is2) <= 7.81) || (rx < 0 && (double)__fmul_rn(monoErr, is2) <= 5.99));
               } else if (pass && C.mode != 2 && F.rightX) {
                 const float rx = F.rightX[idx];
