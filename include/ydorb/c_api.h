@@ -161,6 +161,7 @@ int ydorb_frame_keypoints_in_area(ydorb_matcher_t* h, const YdFrameView* frame, 
 #define YDORB_SEARCH_FRAME_MAPPOINT 0   /* searchByProjectionInFrameAndMapPoint,       orbMatcher.cpp:24-64   */
 #define YDORB_SEARCH_LAST_CURRENT 1     /* searchByProjectionInLastAndCurrentFrame,    orbMatcher.cpp:65-155  */
 #define YDORB_SEARCH_KEYFRAME_CURRENT 2 /* searchByProjectionInKeyFrameAndCurrentFrame, orbMatcher.cpp:156-239 */
+#define YDORB_SEARCH_SIM_PROJECTION 7   /* searchByProjectionInSim,                    orbMatcher.cpp:240-302 */
 #define YDORB_SEARCH_BOW_KEYFRAME_FRAME 3 /* searchByBowInKeyFrameAndFrame,            orbMatcher.cpp:303-379 */
 #define YDORB_SEARCH_BOW_TWO_KEYFRAMES 4  /* searchByBowInTwoKeyFrames,                orbMatcher.cpp:380-462 */
 
@@ -168,7 +169,9 @@ int ydorb_frame_keypoints_in_area(ydorb_matcher_t* h, const YdFrameView* frame, 
  * blocks it (observations > 0 for modes 0/1, any map point for mode 2).  assigned[idx] (in/out, n ints): query
  * index written where the reference writes frame.m_v_sptrMapPoints[bestIdx]; untouched entries keep their value.
  * *n_matches = the int the reference returns (it counts overwrites and subtracts histogram culls exactly as
- * orbMatcher.cpp does). */
+ * orbMatcher.cpp does).  * mode 7 = OrbMatcher::searchByProjectionInSim (orbMatcher.cpp:240-302, loop closing): the caller projects the map points with the
+ * Sim3 it decomposed as the reference does; window without level check, explicit level window query.level-1 .. query.level, taken[idx] =
+ * "_vSptrMatchedMapPoints[idx] is set" (a match takes its feature), best distance <= 50, no orientation check. */
 int ydorb_search_by_projection(ydorb_matcher_t* h, int32_t mode, const YdFrameView* frame, const YdQuery* queries,
                                const uint8_t* qdesc, int32_t nq, float ratio, int32_t orb_dist, int32_t check_orientation,
                                uint8_t* taken, int32_t* assigned, int32_t* n_matches);

@@ -284,6 +284,95 @@ int fuseByProjection(ydorb_matcher_t* m, KeyFramePtr kf, const std::vector<MapPo
   return fuseNum;
 }
 
+// Sim3 decomposition shared by searchByProjectionInSim / fuseBySim3 (orbMatcher.cpp:241-247, :747-753), the reference's own cv::Mat arithmetic
+struct SimProjection {
+  cv::Mat R, t, Ow;
+  explicit SimProjection(const cv::Mat& S) {
+    const cv::Mat sR = S.rowRange(0, 3).colRange(0, 3);
+    const float scale = (float)std::sqrt(sR.row(0).dot(sR.row(0)));
+    R = sR / scale;
+    t = S.rowRange(0, 3).col(3);
+    Ow = -R.t() * t;
+  }
+  // query for one map point (:255-280 / :759-778); returns false when the predicates of :278-282 fail
+  template <class KeyFramePtr, class MapPointPtr, class FrameT>
+  bool query(const KeyFramePtr& kf, const MapPointPtr& mp, float th, YdQuery& Q) const {
+    const cv::Mat Pw = mp->getPosInWorld();
+    const cv::Mat Pc = R * Pw + t;
+    const float xc = Pc.template at<float>(0), yc = Pc.template at<float>(1), zc = Pc.template at<float>(2);
+    const float u = FrameT::m_flt_fx * xc / zc + FrameT::m_flt_cx, v = FrameT::m_flt_fy * yc / zc + FrameT::m_flt_cy;
+    const cv::Mat PO = Pw - Ow;
+    const float dist = (float)cv::norm(PO);
+    const int level = mp->predictScaleLevel(dist, kf);
+    Q = YdQuery{};
+    Q.u = u; Q.v = v; Q.level = level; Q.min_level = -1; Q.max_level = -1; Q.r = th * kf->m_v_scaleFactors[level];
+    return zc >= 0.0f && kf->isInImage(u, v) && dist >= mp->getMinDistanceInvariance() && dist <= mp->getMaxDistanceInvariance() &&
+           PO.dot(mp->getNormal()) >= 0.5 * dist;
+  }
+};
+
+// searchByProjectionInSim, src/orbMatcher.cpp:240-302 (loop closing): matched[idx] is filled for the keyframe features that receive a point
+template <class KeyFramePtr, class MapPointPtr, class FrameT>
+int searchByProjectionInSim(ydorb_matcher_t* m, KeyFramePtr kf, const cv::Mat& S, const std::vector<MapPointPtr>& mps, std::vector<MapPointPtr>& matched, int th) {
+  const SimProjection P(S);
+  std::set<MapPointPtr> found(matched.begin(), matched.end());
+  found.erase(MapPointPtr());
+  std::vector<YdQuery> q(mps.size());
+  cv::Mat desc((int)mps.size() + 1, 32, CV_8U);
+  for (size_t i = 0; i < mps.size(); i++) {
+    q[i] = YdQuery{};
+    if (!mps[i] || mps[i]->isBad() || found.count(mps[i])) continue;
+    q[i].flags = P.template query<KeyFramePtr, MapPointPtr, FrameT>(kf, mps[i], (float)th, q[i]) ? 3 : 0;
+    mps[i]->getDescriptor().copyTo(desc.row((int)i));
+  }
+  std::vector<uint8_t> taken(matched.size());
+  for (size_t i = 0; i < matched.size(); i++) taken[i] = matched[i] ? 1 : 0;
+  std::vector<int32_t> assigned(matched.size(), -1);
+  YdFrameView V = frameView(*kf);
+  int32_t n = 0;
+  if (ydorb_search_by_projection(m, YDORB_SEARCH_SIM_PROJECTION, &V, q.data(), desc.data, (int32_t)mps.size(), 0.f, 0, 0, taken.data(), assigned.data(), &n) != YDORB_OK)
+    throw std::runtime_error(std::string("ydorb: ") + ydorb_last_error());
+  for (size_t i = 0; i < assigned.size(); i++)
+    if (assigned[i] >= 0) matched[i] = mps[assigned[i]];
+  return n;
+}
+
+// fuseBySim3, src/orbMatcher.cpp:746-807: the same search as fuseByProjection without the chi-square test (a zero inverse-sigma table
+// makes that test pass for every finite error), then the reference's bookkeeping in list order
+template <class KeyFramePtr, class MapPointPtr, class FrameT>
+int fuseBySim3(ydorb_matcher_t* m, KeyFramePtr kf, const cv::Mat& S, const std::vector<MapPointPtr>& mps, float th) {
+  const SimProjection P(S);
+  const std::set<MapPointPtr> found = kf->getMatchedMapPointsSet();
+  std::vector<YdQuery> q(mps.size());
+  cv::Mat desc((int)mps.size() + 1, 32, CV_8U);
+  for (size_t i = 0; i < mps.size(); i++) {
+    q[i] = YdQuery{};
+    if (!mps[i] || mps[i]->isBad() || found.count(mps[i])) continue;
+    q[i].flags = P.template query<KeyFramePtr, MapPointPtr, FrameT>(kf, mps[i], th, q[i]) ? 1 : 0;
+    mps[i]->getDescriptor().copyTo(desc.row((int)i));
+  }
+  YdFrameView V = frameView(*kf);
+  V.right_x = nullptr;   // every feature takes the monocular branch of the (disabled) error test
+  const float zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  std::vector<int32_t> best(mps.size() + 1, -1);
+  int32_t n = 0;
+  if (ydorb_fuse_search(m, &V, q.data(), desc.data, (int32_t)mps.size(), zero, 8, best.data(), &n) != YDORB_OK)
+    throw std::runtime_error(std::string("ydorb: ") + ydorb_last_error());
+  int fuseNum = 0;
+  for (size_t i = 0; i < mps.size(); i++) {
+    if (best[i] < 0 || !(q[i].flags & 1) || mps[i]->isBad()) continue;   // the found-set is a snapshot taken before the loop, as in the reference
+    MapPointPtr inKF = kf->getMapPoint(best[i]);
+    if (inKF) {
+      if (!inKF->isBad()) mps[i]->beReplacedBy(inKF);
+    } else {
+      mps[i]->addObservation(kf, best[i]);
+      kf->addMapPoint(mps[i], best[i]);
+    }
+    fuseNum++;
+  }
+  return fuseNum;
+}
+
 // searchForTriangulation, src/orbMatcher.cpp:463-565: the epipole (:465-470) and the stereo / map-point flags are gathered here exactly as
 // the reference reads them; pairs come back in first-index order like the loop at :557-563.
 template <class KeyFramePtr, class FrameT>

@@ -149,6 +149,7 @@ int yo_frame_keypoints_in_area(void* fp, float x, float y, float r, int minLevel
 // mode 0: searchByProjectionInFrameAndMapPoint      orbMatcher.cpp:24-64   (best + second, level rule, <= TH_HIGH)
 // mode 1: searchByProjectionInLastAndCurrentFrame   orbMatcher.cpp:65-155  (best only, < TH_HIGH, rotation histogram)
 // mode 2: searchByProjectionInKeyFrameAndCurrentFrame  :156-239            (best only, <= orbDist, rotation histogram)
+// mode 7: searchByProjectionInSim                      :240-302            (level window predicted-1..predicted, <= TH_LOW, no histogram)
 // taken[idx] != 0  <=>  frame.m_v_sptrMapPoints[idx] holds a point with observations > 0 (modes 0,1) or any point (mode 2).
 // assigned[idx]: query index written at :57 / :118 / :203 (or -1).  Returns matchNum.
 int yo_search_by_projection(void* fp, int mode, const void* queries, const uint8_t* qdesc, int nq, float ratio, int orbDist,
@@ -164,7 +165,8 @@ int yo_search_by_projection(void* fp, int mode, const void* queries, const uint8
     int bestDist = 256, bestLevel = -1, secondDist = 256, secondLevel = -1, bestIdx = -1;
     for (int idx : vIdx) {
       if (taken[idx]) continue;
-      if (mode != 2 && !(F.rightX[idx] <= 0 || fabsf(Q[q].ur - F.rightX[idx]) <= Q[q].rs)) continue;
+      if (mode == 7) { if (!(F.kps[idx].octave >= Q[q].level - 1 && F.kps[idx].octave <= Q[q].level)) continue; }   // searchByProjectionInSim :283-285
+      else if (mode != 2 && !(F.rightX[idx] <= 0 || fabsf(Q[q].ur - F.rightX[idx]) <= Q[q].rs)) continue;
       const int dist = descriptorDistance(qdesc + (size_t)q * 32, &F.desc[(size_t)idx * 32]);
       if (dist < bestDist) {
         secondDist = bestDist; bestDist = dist;
@@ -178,14 +180,15 @@ int yo_search_by_projection(void* fp, int mode, const void* queries, const uint8
     bool accept;
     if (mode == 0) accept = bestDist <= TH_HIGH && (bestLevel != secondLevel || bestDist <= ratio * secondDist);
     else if (mode == 1) accept = bestDist < TH_HIGH;
+    else if (mode == 7) accept = bestDist <= TH_LOW;   // :293
     else accept = bestDist <= orbDist;
     if (!accept) continue;
     assigned[bestIdx] = q;
-    taken[bestIdx] = mode == 2 ? 1 : ((Q[q].flags & 2) ? 1 : 0);
+    taken[bestIdx] = (mode == 2 || mode == 7) ? 1 : ((Q[q].flags & 2) ? 1 : 0);
     matchNum++;
-    if (mode != 0 && checkOrientation) rotHist[rotBin(Q[q].angle, F.kps[bestIdx].angle)].push_back(bestIdx);
+    if (mode != 0 && mode != 7 && checkOrientation) rotHist[rotBin(Q[q].angle, F.kps[bestIdx].angle)].push_back(bestIdx);
   }
-  if (mode != 0 && checkOrientation) {
+  if (mode != 0 && mode != 7 && checkOrientation) {
     int i1 = -1, i2 = -1, i3 = -1;
     threeMaxima(rotHist, HISTO_LENGTH, i1, i2, i3);
     for (int i = 0; i < HISTO_LENGTH; i++)

@@ -37,7 +37,7 @@ struct KeyFrame {
   std::vector<cv::KeyPoint> m_v_keyPoints; cv::Mat m_cvMat_descriptors; FeatureVector m_bow_keyPointsVec; std::vector<float> m_v_rightXcords, m_v_invScaleFactorSquares;
   long int m_int_keyFrameID, m_int_localBAForKeyFrameID, m_int_fixedBAForKeyFrameID, m_int_globalBAForKeyFrameID; cv::Mat m_cvMat_T_c2w_GlobalBA;
   int m_int_keyPointsNum; std::vector<float> m_v_scaleFactors, m_v_scaleFactorSquares;
-  std::shared_ptr<MapPoint> getMapPoint(const int&); void addMapPoint(std::shared_ptr<MapPoint>, const int&); bool isInImage(const float&, const float&) const;
+  std::set<std::shared_ptr<MapPoint>> getMatchedMapPointsSet(); std::shared_ptr<MapPoint> getMapPoint(const int&); void addMapPoint(std::shared_ptr<MapPoint>, const int&); bool isInImage(const float&, const float&) const;
   static float m_flt_minX, m_flt_maxX, m_flt_minY, m_flt_maxY; cv::Mat getCameraOriginInWorld(); cv::Mat getRotation_c2w(); cv::Mat getTranslation_c2w();
   std::vector<std::shared_ptr<MapPoint>> getMatchedMapPointsVec(); std::vector<std::shared_ptr<KeyFrame>> getOrderedConnectedKeyFrames();
   bool isBad(); cv::Mat getCameraPoseByTransform_c2w(); void setCameraPoseByTransform_c2w(cv::Mat); void eraseMatchedMapPoint(std::shared_ptr<MapPoint>);
@@ -58,6 +58,8 @@ int check(Frame& a, Frame& b, std::shared_ptr<KeyFrame> kf, std::shared_ptr<KeyF
   n += ya::computeDescriptorsDistance(a.m_cvMat_descriptors, b.m_cvMat_descriptors);
   std::vector<std::pair<int, int>> pairs;
   n += ya::fuseByProjection<std::shared_ptr<KeyFrame>, std::shared_ptr<MapPoint>, Frame>(ya::matcher(), kf, mps, 3.0f);
+  n += ya::fuseBySim3<std::shared_ptr<KeyFrame>, std::shared_ptr<MapPoint>, Frame>(ya::matcher(), kf, a.m_cvMat_T_c2w, mps, 4.0f);
+  n += ya::searchByProjectionInSim<std::shared_ptr<KeyFrame>, std::shared_ptr<MapPoint>, Frame>(ya::matcher(), kf, a.m_cvMat_T_c2w, mps, mps, 10);
   n += ya::searchForTriangulation<std::shared_ptr<KeyFrame>, Frame>(ya::matcher(), kf, kf2, a.m_cvMat_T_c2w, pairs, false, true);
 #ifdef YDORB_CHECK_OPTIMIZER
   bool stop = false;

@@ -31,7 +31,7 @@ struct Mat {
 };
 struct MatExpr { operator Mat() const; template <class T> T& at(int); };
 MatExpr operator*(const Mat&, const Mat&); MatExpr operator*(const MatExpr&, const Mat&); MatExpr operator+(const MatExpr&, const Mat&);
-MatExpr operator-(const Mat&); MatExpr operator-(const Mat&, const Mat&); MatExpr operator-(const MatExpr&);
+MatExpr operator-(const Mat&); MatExpr operator-(const Mat&, const Mat&); MatExpr operator-(const MatExpr&); MatExpr operator/(const Mat&, double);
 double norm(const MatExpr&); double norm(const Mat&);
 struct _InputArray { _InputArray(const Mat&); bool empty() const; Mat getMat() const; };
 struct _OutputArray { _OutputArray(Mat&); void release() const; };

@@ -191,3 +191,33 @@ def test_fuse_search(oracle_lib, scene, stereo):
             assert n_gpu == n_ref and np.array_equal(b_gpu, b_ref)
             total += n_ref
     assert total > 20
+
+
+def test_search_by_projection_in_sim_and_fuse_by_sim3(oracle_lib, scene):
+    """Loop-closing variants: searchByProjectionInSim (orbMatcher.cpp:240-302) = mode 7 — window without level check,
+    explicit level window, taken = already matched, <= 50, no histogram; fuseBySim3's search (:746-807) = the fuse search with the
+    chi-square test disabled (zero inverse-sigma table).  Identical integers to the oracle."""
+    import ydorbslam_amd as y
+    total = 0
+    for si, s in enumerate(scene):
+        bounds = (0.0, 640.0, 0.0, 480.0)
+        rng = np.random.default_rng(700 + si)
+        kb = s["kb"]
+        for th in (0.8, 1.5, 4.0):
+            q = projection_queries(s["ka"], s["sf"], s["dx"], s["dy"], th, 1, seed=800 + si)
+            q["min_level"], q["max_level"] = -1, -1
+            q["level"] = np.clip(s["ka"]["octave"] + rng.integers(-1, 2, len(q)), 0, 7)
+            q["r"] = (np.float32(th) * s["sf"].astype(np.float32)[q["level"]]).astype(np.float32)
+            taken0 = (rng.random(len(kb)) < 0.2).astype(np.uint8)
+            assigned0 = np.where(taken0 > 0, 100000 + np.arange(len(taken0)), -1).astype(np.int32)
+            fo = oracle_lib.FrameOracle(kb, s["db"], bounds, None)
+            n_ref, a_ref, t_ref = fo.search_by_projection(7, q, s["da"], 0.0, False, taken0, assigned0)
+            m = y.OrbMatcher(0.6, True)
+            n_gpu, a_gpu, t_gpu = m.search_by_projection(7, y.FrameView(kb, s["db"], bounds, None), q, s["da"], taken0, assigned0)
+            assert n_gpu == n_ref and np.array_equal(a_gpu, a_ref) and np.array_equal(t_gpu, t_ref)
+            zero = np.zeros(8, np.float32)
+            nf_ref, b_ref = fo.fuse_search(q, s["da"], zero)
+            nf_gpu, b_gpu = m.fuse_search(y.FrameView(kb, s["db"], bounds, None), q, s["da"], zero)
+            assert nf_gpu == nf_ref and np.array_equal(b_gpu, b_ref)
+            total += n_ref + nf_ref
+    assert total > 50

@@ -124,7 +124,7 @@ struct CallDev {          // one search call (one target frame, one ordered quer
   int* assigned;          // [n] in/out (query index or -1)
   int* matchQ;            // [nq] scratch: accepted target index per query (or -1), used by the histogram cull
   int* count;             // out: matchNum
-  int mode;               // 0 M1, 1 M3, 2 M4 (projection family); 3 M5, 4 M6 (BoW family); 5 searchForTriangulation; 6 fuse search
+  int mode;               // 0 M1, 1 M3, 2 M4 (projection family); 3 M5, 4 M6 (BoW family); 5 searchForTriangulation; 6 fuse search; 7 searchByProjectionInSim
   float ratio;
   int orbDist, checkOri;
   float invSigma2[8];     // mode 6: the keyframe's m_v_invScaleFactorSquares
@@ -218,6 +218,8 @@ __global__ __launch_bounds__(256) void k_gather_projection(const CallDev* __rest
                 const bool lv = octave >= Q.level - 1 && octave <= Q.level;
                 const float is2 = calls[blockIdx.y].invSigma2[octave & 7];   // indexed from global memory: a dynamic index into the local copy of the call record would move the whole record to scratch
                 pass = lv && ((rx >= 0 && (double)__fmul_rn(stereoErr, is2) <= 7.81) || (rx < 0 && (double)__fmul_rn(monoErr, is2) <= 5.99));
+              } else if (pass && C.mode == 7) {
+                pass = octave >= Q.level - 1 && octave <= Q.level;   // searchByProjectionInSim's explicit level window (orbMatcher.cpp:283-285)
               } else if (pass && C.mode != 2 && F.rightX) {
                 const float rx = F.rightX[idx];
                 if (!(rx <= 0 || fabsf(__fsub_rn(Q.ur, rx)) <= Q.rs)) pass = false;
@@ -410,12 +412,13 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
         else if (C.mode == 2) accept = bestDist <= C.orbDist;
         else if (C.mode == 5) accept = true;   // every record already passed dist <= 50 and the geometric tests
         else if (C.mode == 6) accept = bestDist <= kThLow;   // fuseByProjection :725; nothing is taken, the caller applies the result
+        else if (C.mode == 7) accept = bestDist <= kThLow;   // searchByProjectionInSim :293
         else accept = bestDist <= kThLow && (float)bestDist < __fmul_rn(C.ratio, (float)secondDist);
         if (accept) {
           matchNum++;
           if (lane == 0) {
             const int qflags = bow ? 3 : C.queries[q].flags;
-            if (C.mode >= 4) C.assigned[q] = bestIdx;   // out[firstIdx] = second-keyframe index; q is remapped by the host
+            if (C.mode == 4 || C.mode == 5) C.assigned[q] = bestIdx;   // out[firstIdx] = second-keyframe index; q is remapped by the host
             else C.assigned[bestIdx] = q;
             const bool nowTaken = C.mode == 6 ? false : C.mode >= 2 ? true : (qflags & 2) != 0;
             if (nowTaken) takenBits[bestIdx >> 5] |= 1u << (bestIdx & 31);
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
       if (v < 0) continue;
       const int bin = v >> 24, t = v & 0xFFFFFF;
       if (bin != i1 && bin != i2 && bin != i3) {
-        if (C.mode >= 4) C.assigned[q] = -1; else C.assigned[t] = -1;
+        if (C.mode == 4 || C.mode == 5) C.assigned[q] = -1; else C.assigned[t] = -1;
         culled++;
       }
     }

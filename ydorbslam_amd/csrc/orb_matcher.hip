@@ -251,11 +251,12 @@ static int searchProjectionImpl(ydorb_matcher_t* m, int32_t mode, const YdFrameV
 int ydorb_search_by_projection(ydorb_matcher_t* m, int32_t mode, const YdFrameView* fv, const YdQuery* queries, const uint8_t* qdesc,
                                int32_t nq, float ratio, int32_t orbDist, int32_t checkOri, uint8_t* taken, int32_t* assigned,
                                int32_t* nMatches) {
-  if (!m || !fv || !nMatches || mode < 0 || mode > 2 || nq < 0 || fv->n < 0 || (nq > 0 && (!queries || !qdesc)) ||
+  if (!m || !fv || !nMatches || mode < 0 || (mode > 2 && mode != 7) || nq < 0 || fv->n < 0 || (nq > 0 && (!queries || !qdesc)) ||
       (fv->n > 0 && (!fv->kps || !fv->desc || !assigned)) || !(fv->max_x > fv->min_x) || !(fv->max_y > fv->min_y)) {
     set_error("invalid argument");
     return YDORB_ERR_INVALID_ARG;
   }
+  if (mode == 7) checkOri = 0;   // searchByProjectionInSim has no rotation-consistency step
   return searchProjectionImpl(m, mode, fv, queries, qdesc, nq, ratio, orbDist, checkOri, taken, assigned, nMatches, nullptr);
 }
 
