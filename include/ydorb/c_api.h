@@ -206,6 +206,11 @@ int ydorb_search_by_bow(ydorb_matcher_t* h, int32_t mode, const YdBowSide* a, co
  * isInKeyFrame at each step, because earlier replacements can change them; they cannot change a later point's search result). */
 int ydorb_fuse_search(ydorb_matcher_t* h, const YdFrameView* keyframe, const YdQuery* queries, const uint8_t* qdesc, int32_t n_queries,
                       const float* inv_scale_factor_squares, int32_t n_levels, int32_t* best_idx, int32_t* n_found);
+/* The same search with the acceptance distance as a parameter (ydorb_fuse_search = max_dist 50).  An all-zero inverse-sigma table
+ * disables the chi-square test: that is fuseBySim3's search (orbMatcher.cpp:746-807) and, with max_dist = 100 (TH_HIGH), each of the two
+ * directions of searchBySim3 (:594-667), whose agreement check (:668-679) the caller runs on the two result vectors. */
+int ydorb_window_search(ydorb_matcher_t* h, const YdFrameView* keyframe, const YdQuery* queries, const uint8_t* qdesc, int32_t n_queries,
+                        const float* inv_scale_factor_squares, int32_t n_levels, int32_t max_dist, int32_t* best_idx, int32_t* n_found);
 
 /* OrbMatcher::searchForTriangulation (src/orbMatcher.cpp:463-565): BoW-guided search between the features of two
  * keyframes that have no MapPoint yet, kept when the second feature lies on the first one's epipolar line (:808-819).

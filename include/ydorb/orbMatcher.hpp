@@ -373,6 +373,54 @@ int fuseBySim3(ydorb_matcher_t* m, KeyFramePtr kf, const cv::Mat& S, const std::
   return fuseNum;
 }
 
+// searchBySim3, src/orbMatcher.cpp:566-681.  As written, the reference projects with the keyframes' own poses (the Sim3 products of :572-574
+// are computed and never used), each direction is an independent window search (level window, best distance <= TH_HIGH, nothing taken),
+// and a pair is kept when the two directions agree (:668-679).  Two ydorb_window_search calls + the agreement loop.
+template <class KeyFramePtr, class MapPointPtr, class FrameT>
+int searchBySim3(ydorb_matcher_t* m, KeyFramePtr kf1, KeyFramePtr kf2, std::vector<MapPointPtr>& matched12, float th) {
+  const std::vector<MapPointPtr> mp1 = kf1->getMatchedMapPointsVec(), mp2 = kf2->getMatchedMapPointsVec();
+  std::vector<uint8_t> done1(mp1.size(), 0), done2(mp2.size(), 0);
+  for (size_t i = 0; i < matched12.size() && i < mp1.size(); i++)
+    if (matched12[i]) {
+      done1[i] = 1;
+      const int idx = matched12[i]->getIdxInKeyFrame(kf2);
+      if (idx >= 0 && idx < (int)mp2.size()) done2[idx] = 1;
+    }
+  auto direction = [&](const std::vector<MapPointPtr>& src, const std::vector<uint8_t>& done, const KeyFramePtr& dst, std::vector<int32_t>& best) {
+    const cv::Mat R = dst->getRotation_c2w(), t = dst->getTranslation_c2w();
+    std::vector<YdQuery> q(src.size());
+    cv::Mat desc((int)src.size() + 1, 32, CV_8U);
+    for (size_t i = 0; i < src.size(); i++) {
+      q[i] = YdQuery{};
+      if (!src[i] || done[i] || src[i]->isBad()) continue;
+      const cv::Mat Pc = R * src[i]->getPosInWorld() + t;
+      const float xc = Pc.template at<float>(0), yc = Pc.template at<float>(1), zc = Pc.template at<float>(2);
+      const float u = FrameT::m_flt_fx * xc / zc + FrameT::m_flt_cx, v = FrameT::m_flt_fy * yc / zc + FrameT::m_flt_cy;
+      const float dist = (float)cv::norm(Pc);
+      const int level = src[i]->predictScaleLevel(dist, dst);
+      q[i].u = u; q[i].v = v; q[i].level = level; q[i].min_level = -1; q[i].max_level = -1; q[i].r = th * dst->m_v_scaleFactors[level];
+      q[i].flags = (zc >= 0.0f && dst->isInImage(u, v) && dist >= src[i]->getMinDistanceInvariance() && dist <= src[i]->getMaxDistanceInvariance()) ? 1 : 0;
+      src[i]->getDescriptor().copyTo(desc.row((int)i));
+    }
+    YdFrameView V = frameView(*dst);
+    V.right_x = nullptr;
+    const float zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    best.assign(src.size() + 1, -1);
+    int32_t n = 0;
+    if (ydorb_window_search(m, &V, q.data(), desc.data, (int32_t)src.size(), zero, 8, 100, best.data(), &n) != YDORB_OK)
+      throw std::runtime_error(std::string("ydorb: ") + ydorb_last_error());
+  };
+  std::vector<int32_t> m12, m21;
+  direction(mp1, done1, kf2, m12);
+  direction(mp2, done2, kf1, m21);
+  int found = 0;
+  for (size_t i = 0; i < mp1.size(); i++) {
+    const int i2 = m12[i];
+    if (i2 >= 0 && m21[i2] == (int)i) { matched12[i] = mp2[i2]; found++; }
+  }
+  return found;
+}
+
 // searchForTriangulation, src/orbMatcher.cpp:463-565: the epipole (:465-470) and the stereo / map-point flags are gathered here exactly as
 // the reference reads them; pairs come back in first-index order like the loop at :557-563.
 template <class KeyFramePtr, class FrameT>

@@ -203,8 +203,9 @@ int yo_search_by_projection(void* fp, int mode, const void* queries, const uint8
 // among those in the projection window whose level is predicted-1 .. predicted (:715-716) and whose reprojection error passes the
 // chi-square test (:711-718).  Query fields used: u, v (projection), r (radius), ur (projected right x), level (predicted level).
 // best[q] = feature index when bestDist <= TH_LOW (:725), else -1.  The replace / add bookkeeping (:726-737) stays with the caller
-// and runs in list order on these results.  invSigma2 = the keyframe's m_v_invScaleFactorSquares.
-int yo_fuse_search(void* fp, const void* queries, const uint8_t* qdesc, int nq, const float* invSigma2, int* best) {
+// and runs in list order on these results.  invSigma2 = the keyframe's m_v_invScaleFactorSquares (all zeros: no chi-square test, which is
+// fuseBySim3's search :746-807 and each direction of searchBySim3 :594-667, the latter with maxDist = TH_HIGH).
+int yo_fuse_search(void* fp, const void* queries, const uint8_t* qdesc, int nq, const float* invSigma2, int maxDist, int* best) {
   Frame& F = *(Frame*)fp;
   const Query* Q = (const Query*)queries;
   int found = 0;
@@ -223,7 +224,7 @@ int yo_fuse_search(void* fp, const void* queries, const uint8_t* qdesc, int nq, 
         if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
       }
     }
-    if (bestDist <= TH_LOW) { best[q] = bestIdx; found++; }
+    if (bestDist <= maxDist) { best[q] = bestIdx; found++; }   // TH_LOW for the fuse functions (:725, :789), TH_HIGH for searchBySim3 (:625, :662)
   }
   return found;
 }

@@ -55,7 +55,7 @@ def lib():
         L.yo_cv_round.restype = C.c_int
         L.yo_cv_round.argtypes = [C.c_float]
         L.yo_fuse_search.restype = C.c_int
-        L.yo_fuse_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.yo_fuse_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.yo_reflect101.restype = C.c_int
         L.yo_reflect101.argtypes = [C.c_int, C.c_int]
         L.yo_cosf_det.restype = C.c_float
@@ -234,12 +234,12 @@ class FrameOracle:
         n = lib().yo_frame_keypoints_in_area(self.h, x, y, r, min_level, max_level, _p(out), len(out))
         return out[:n].copy()
 
-    def fuse_search(self, queries, qdesc, inv_sigma2):
+    def fuse_search(self, queries, qdesc, inv_sigma2, max_dist=50):
         """Search half of OrbMatcher::fuseByProjection (orbMatcher.cpp:682-745): best[q] = keyframe feature index or -1."""
         q = np.ascontiguousarray(queries, QUERY_DTYPE); d = np.ascontiguousarray(qdesc, np.uint8)
         s2 = np.ascontiguousarray(inv_sigma2, np.float32)
         best = np.full(len(q), -1, np.int32)
-        n = lib().yo_fuse_search(self.h, _p(q), _p(d), len(q), _p(s2), _p(best))
+        n = lib().yo_fuse_search(self.h, _p(q), _p(d), len(q), _p(s2), int(max_dist), _p(best))
         return n, best
 
     def search_by_projection(self, mode, queries, qdesc, ratio, check_orientation, taken=None, assigned=None, orb_dist=0):

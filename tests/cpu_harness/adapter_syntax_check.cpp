@@ -21,7 +21,7 @@ struct MapPoint {
   float getMaxDistanceInvariance(); float getMinDistanceInvariance(); int predictScaleLevel(const float&, const Frame&);
   std::map<std::shared_ptr<KeyFrame>, int> getObservations(); void eraseObservation(std::shared_ptr<KeyFrame>);
   void setPosInWorld(const cv::Mat&); void updateNormalAndDepth();
-  bool isInKeyFrame(std::shared_ptr<KeyFrame>); cv::Mat getNormal(); int predictScaleLevel(const float&, std::shared_ptr<KeyFrame>);
+  bool isInKeyFrame(std::shared_ptr<KeyFrame>); int getIdxInKeyFrame(std::shared_ptr<KeyFrame>); cv::Mat getNormal(); int predictScaleLevel(const float&, std::shared_ptr<KeyFrame>);
   void beReplacedBy(std::shared_ptr<MapPoint>); void addObservation(std::shared_ptr<KeyFrame>, int);
 };
 typedef std::map<unsigned, std::vector<unsigned>> FeatureVector;
@@ -59,6 +59,7 @@ int check(Frame& a, Frame& b, std::shared_ptr<KeyFrame> kf, std::shared_ptr<KeyF
   std::vector<std::pair<int, int>> pairs;
   n += ya::fuseByProjection<std::shared_ptr<KeyFrame>, std::shared_ptr<MapPoint>, Frame>(ya::matcher(), kf, mps, 3.0f);
   n += ya::fuseBySim3<std::shared_ptr<KeyFrame>, std::shared_ptr<MapPoint>, Frame>(ya::matcher(), kf, a.m_cvMat_T_c2w, mps, 4.0f);
+  n += ya::searchBySim3<std::shared_ptr<KeyFrame>, std::shared_ptr<MapPoint>, Frame>(ya::matcher(), kf, kf2, mps, 7.5f);
   n += ya::searchByProjectionInSim<std::shared_ptr<KeyFrame>, std::shared_ptr<MapPoint>, Frame>(ya::matcher(), kf, a.m_cvMat_T_c2w, mps, mps, 10);
   n += ya::searchForTriangulation<std::shared_ptr<KeyFrame>, Frame>(ya::matcher(), kf, kf2, a.m_cvMat_T_c2w, pairs, false, true);
 #ifdef YDORB_CHECK_OPTIMIZER

@@ -219,5 +219,8 @@ def test_search_by_projection_in_sim_and_fuse_by_sim3(oracle_lib, scene):
             nf_ref, b_ref = fo.fuse_search(q, s["da"], zero)
             nf_gpu, b_gpu = m.fuse_search(y.FrameView(kb, s["db"], bounds, None), q, s["da"], zero)
             assert nf_gpu == nf_ref and np.array_equal(b_gpu, b_ref)
+            nh_ref, h_ref = fo.fuse_search(q, s["da"], zero, 100)                  # one direction of searchBySim3 (:594-627): <= TH_HIGH
+            nh_gpu, h_gpu = m.fuse_search(y.FrameView(kb, s["db"], bounds, None), q, s["da"], zero, 100)
+            assert nh_gpu == nh_ref >= nf_ref and np.array_equal(h_gpu, h_ref)
             total += n_ref + nf_ref
     assert total > 50

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
         } else if (C.mode == 1) accept = bestDist < kThHigh;
         else if (C.mode == 2) accept = bestDist <= C.orbDist;
         else if (C.mode == 5) accept = true;   // every record already passed dist <= 50 and the geometric tests
-        else if (C.mode == 6) accept = bestDist <= kThLow;   // fuseByProjection :725; nothing is taken, the caller applies the result
+        else if (C.mode == 6) accept = bestDist <= C.orbDist;   // fuseByProjection :725 / fuseBySim3 :789 (50), searchBySim3 :625 (100); nothing is taken
         else if (C.mode == 7) accept = bestDist <= kThLow;   // searchByProjectionInSim :293
         else accept = bestDist <= kThLow && (float)bestDist < __fmul_rn(C.ratio, (float)secondDist);
         if (accept) {

@@ -262,7 +262,12 @@ int ydorb_search_by_projection(ydorb_matcher_t* m, int32_t mode, const YdFrameVi
 
 int ydorb_fuse_search(ydorb_matcher_t* m, const YdFrameView* fv, const YdQuery* queries, const uint8_t* qdesc, int32_t nq,
                       const float* invSigma2, int32_t nLevels, int32_t* best, int32_t* nFound) {
-  if (!m || !fv || !nFound || nq < 0 || fv->n < 0 || (nq > 0 && (!queries || !qdesc || !best)) || !invSigma2 || nLevels < 1 || nLevels > 8 ||
+  return ydorb_window_search(m, fv, queries, qdesc, nq, invSigma2, nLevels, 50, best, nFound);
+}
+
+int ydorb_window_search(ydorb_matcher_t* m, const YdFrameView* fv, const YdQuery* queries, const uint8_t* qdesc, int32_t nq,
+                        const float* invSigma2, int32_t nLevels, int32_t maxDist, int32_t* best, int32_t* nFound) {
+  if (!m || !fv || !nFound || nq < 0 || maxDist < 0 || maxDist > 256 || fv->n < 0 || (nq > 0 && (!queries || !qdesc || !best)) || !invSigma2 || nLevels < 1 || nLevels > 8 ||
       (fv->n > 0 && (!fv->kps || !fv->desc)) || !(fv->max_x > fv->min_x) || !(fv->max_y > fv->min_y)) {
     set_error("invalid argument");
     return YDORB_ERR_INVALID_ARG;
@@ -271,7 +276,7 @@ int ydorb_fuse_search(ydorb_matcher_t* m, const YdFrameView* fv, const YdQuery* 
   *nFound = 0;
   for (int i = 0; i < fv->n; i++)
     if (fv->kps[i].octave < 0 || fv->kps[i].octave >= nLevels) { set_error("keyframe feature %d: octave %d outside the %d-level table", i, fv->kps[i].octave, nLevels); return YDORB_ERR_INVALID_ARG; }
-  return searchProjectionImpl(m, 6, fv, queries, qdesc, nq, 0.f, 0, 0, nullptr, nullptr, nFound, nullptr, invSigma2, nLevels, best);
+  return searchProjectionImpl(m, 6, fv, queries, qdesc, nq, 0.f, maxDist, 0, nullptr, nullptr, nFound, nullptr, invSigma2, nLevels, best);
 }
 
 int ydorb_frame_keypoints_in_area(ydorb_matcher_t* m, const YdFrameView* fv, float x, float y, float r, int32_t minLevel, int32_t maxLevel,

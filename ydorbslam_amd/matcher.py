@@ -117,7 +117,7 @@ class OrbMatcher:
         check(self._L.ydorb_search_by_bow(self._h, mode, C.byref(A), C.byref(B), self.ratio, int(self.check_orientation), _p(out), C.byref(n)))
         return n.value, out
 
-    def fuse_search(self, frame, queries, qdesc, inv_sigma2):
+    def fuse_search(self, frame, queries, qdesc, inv_sigma2, max_dist=50):
         """Search half of OrbMatcher::fuseByProjection (orbMatcher.cpp:682-745).  Returns (n_found, best[q] = feature index or -1)."""
         queries = np.ascontiguousarray(queries, QUERY_DTYPE)
         qdesc = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
@@ -125,7 +125,7 @@ class OrbMatcher:
         best = np.full(max(len(queries), 1), -1, np.int32)
         n = C.c_int32(0)
         fv = frame.c()
-        check(self._L.ydorb_fuse_search(self._h, C.byref(fv), _p(queries), _p(qdesc), len(queries), _p(s2), len(s2), _p(best), C.byref(n)))
+        check(self._L.ydorb_window_search(self._h, C.byref(fv), _p(queries), _p(qdesc), len(queries), _p(s2), len(s2), int(max_dist), _p(best), C.byref(n)))
         return n.value, best[:len(queries)]
 
     def search_for_triangulation(self, kps_a, desc_a, has_mp_a, right_a, fv_a, kps_b, desc_b, has_mp_b, right_b, fv_b, F, epipole, sf_b, sf2_b,
