@@ -138,6 +138,8 @@ def test_quadtree_flat_and_pass_kernels_agree(oracle_lib, monkeypatch):
     (752, 480, 1200, 1.5, 5, 30),
     (97, 61, 200, 1.2, 8, 20),        # smallest levels have no FAST cells and borders wider than the interior
     (1280, 720, 3000, 1.2, 8, 20),    # bigger than any BASELINE config: quotas above 600 per level, candidates beyond the LDS slots
+    (661, 370, 4000, 1.5, 2, 12),     # two levels x 4000 features: the pass kernel's node tables no longer fit the LDS (HBM tables)
+    (1145, 756, 2000, 2.3, 5, 12),    # > 8192 candidates on level 0 AND a quota too large for LDS node tables: hand-over to HBM tables
 ])
 def test_other_pyramid_configurations(oracle_lib, w, h, nf, sf, nl, thr):
     """Constructor arguments other than the TUM/KITTI/EuRoC settings (orbExtractor.cpp:315-354 takes them freely)."""
@@ -153,3 +155,18 @@ def test_other_pyramid_configurations(oracle_lib, w, h, nf, sf, nl, thr):
             assert np.array_equal(gpu.read_level(l), cpu.level_padded(l)[:, :cw + 38]), "pyramid level %d" % l
         _same_kps(gk, ck)
         assert np.array_equal(gd, cd)
+
+
+def test_huge_quota_pass_kernel_uses_hbm_node_tables(oracle_lib, monkeypatch):
+    """With YDORB_QT_PASS=1 every unit goes through the pass kernel; a level whose quota needs more than the LDS for its node tables
+    (here ~2700 features on level 0) must take them from HBM scratch and still give the oracle's keypoints."""
+    import ydorbslam_amd as y
+    from oracle.orb_oracle import OrbExtractorOracle
+    monkeypatch.setenv("YDORB_QT_PASS", "1")
+    gpu = y.OrbExtractor(4000, 1.5, 2, 20, 7)
+    monkeypatch.delenv("YDORB_QT_PASS")
+    img = synth_frame(640, 480, 31)
+    gk, gd = gpu.extract(img)
+    ck, cd = OrbExtractorOracle(4000, 1.5, 2, 20, 7).extract(img)
+    _same_kps(gk, ck)
+    assert np.array_equal(gd, cd) and gpu.debug_read(3, 0) == 1

@@ -1,0 +1,73 @@
+"""One-off differential sweep on the GPU box: random image sizes / extractor configurations / matcher inputs / BA and pose problems,
+product vs oracle.  Not part of the test suite (the suite pins fixed cases); run it after kernel changes:  python tools/fuzz_parity.py 120"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import ydorbslam_amd as y
+from oracle import orb_oracle as oo
+from ydorbslam_amd.synth import synth_frame, synth_ba_problem, synth_pose_problem
+from helpers import bow_nodes, feature_vector, projection_queries
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+t0 = time.time()
+n_ex = n_ma = n_ba = n_po = 0
+while time.time() - t0 < budget:
+    # ---- extractor
+    w, h = int(rng.integers(60, 1400)), int(rng.integers(60, 800))
+    nf = int(rng.choice([100, 500, 1000, 2000, 4000])); sf = float(rng.choice([1.1, 1.2, 1.5, 2.0, 2.3])); nl = int(rng.integers(1, 9))
+    thr = int(rng.choice([7, 12, 20, 40]))
+    img = synth_frame(w, h, int(rng.integers(0, 1000)))
+    mode = rng.integers(0, 4)
+    if mode == 1: img[: h // 2] = 100
+    if mode == 2: img = (img // 4 + 90).astype(np.uint8)          # low contrast: sparse, deep quad-trees
+    try:
+        g = y.OrbExtractor(nf, sf, nl, thr, 7); c = oo.OrbExtractorOracle(nf, sf, nl, thr, 7)
+    except Exception as e:  # unsupported configuration on either side must be an error on both
+        print("config rejected:", (w, h, nf, sf, nl, thr), str(e)[:80]); continue
+    try:
+        gk, gd = g.extract(img)
+    except y.YdorbError as e:
+        print("extract rejected:", (w, h, nf, sf, nl, thr), str(e)[:100]); continue
+    ck, cd = c.extract(img)
+    assert gk.tobytes() == ck.tobytes() and np.array_equal(gd, cd), ("extractor", w, h, nf, sf, nl, thr, mode)
+    n_ex += 1
+    # ---- matcher on this frame vs a shifted copy
+    if len(gk) > 50 and w > 200 and h > 200:
+        img2 = np.roll(img, (int(rng.integers(-6, 7)), int(rng.integers(-6, 7))), (0, 1))
+        kb, db = c.extract(img2)
+        if len(kb) > 20:
+            tab = c.tables()["scale"]
+            for m_ in (0, 1, 2, 7):
+                q = projection_queries(ck, tab, 0, 0, float(rng.choice([3, 7, 15])), m_ if m_ < 3 else 1, seed=int(rng.integers(0, 1 << 30)), stereo=False)
+                if m_ == 7:
+                    q["min_level"], q["max_level"] = -1, -1
+                taken0 = (rng.random(len(kb)) < 0.1).astype(np.uint8); a0 = np.where(taken0 > 0, 100000 + np.arange(len(kb)), -1).astype(np.int32)
+                fo = oo.FrameOracle(kb, db, (0.0, float(w), 0.0, float(h)), None)
+                r = fo.search_by_projection(m_, q, cd, 0.8, True, taken0, a0, orb_dist=64)
+                mm = y.OrbMatcher(0.8, True)
+                p = mm.search_by_projection(m_, y.FrameView(kb, db, (0.0, float(w), 0.0, float(h)), None), q, cd, taken0, a0, orb_dist=64)
+                assert p[0] == r[0] and np.array_equal(p[1], r[1]) and np.array_equal(p[2], r[2]), ("projection", m_, w, h)
+            fa, fb = feature_vector(bow_nodes(cd, 4)), feature_vector(bow_nodes(db, 4))
+            va = (rng.random(len(ck)) > 0.2).astype(np.uint8); vb = (rng.random(len(kb)) > 0.2).astype(np.uint8)
+            for m_ in (3, 4):
+                r = oo.search_by_bow(m_, ck, cd, va, fa, kb, db, vb, fb, 0.75, True)
+                p = y.OrbMatcher(0.75, True).search_by_bow(m_, ck, cd, va, y.FeatureVector(*fa), kb, db, vb if m_ == 4 else None, y.FeatureVector(*fb))
+                assert p[0] == r[0] and np.array_equal(p[1], r[1]), ("bow", m_)
+            n_ma += 1
+    # ---- BA + pose
+    if rng.random() < 0.3:
+        prob = synth_ba_problem(int(rng.integers(3, 40)), int(rng.integers(30, 1500)), int(rng.integers(2, 8)), seed=int(rng.integers(0, 1 << 30)),
+                                outlier_frac=float(rng.choice([0, 0.05, 0.2])), mono_frac=float(rng.choice([0, 0.3, 1.0])), n_fixed=int(rng.integers(1, 3)))
+        r = oo.ba_solve(prob); p = y.Optimizer.local_bundle_adjust(prob)
+        assert np.array_equal(p["outlier"], r["outlier"]) and len(p["log"]) == len(r["log"]) and np.allclose(p["log"][:, 0], r["log"][:, 0], rtol=1e-6), "ba"
+        assert np.allclose(p["poses"].astype(np.float32), r["poses"].astype(np.float32), rtol=1e-4, atol=1e-6), "ba poses"
+        n_ba += 1
+        pp = [synth_pose_problem(int(rng.integers(3, 1500)), seed=int(rng.integers(0, 1 << 30)), outlier_frac=float(rng.choice([0, 0.1, 0.4])),
+                                 mono_frac=float(rng.choice([0, 0.5, 1.0]))) for _ in range(5)]
+        for p_, g_ in zip(pp, y.Optimizer.optimize_poses(pp)):
+            r_ = oo.pose_optimize(p_)
+            assert g_["inliers"] == r_["inliers"] and np.array_equal(g_["outlier"], r_["outlier"]), ("pose", len(p_["info"]))
+            n_po += 1
+print("fuzz ok: %d extractor configs, %d matcher scenes, %d BA problems, %d pose problems in %.0f s" % (n_ex, n_ma, n_ba, n_po, time.time() - t0))

@@ -36,12 +36,14 @@ struct LevelDev {
   int candOff;              // entry offset of the level's quad-tree scratch inside a frame's scratch
   int kpOff;                // entry offset of the level's keypoints inside a frame's level-keypoint array
   int tabOff;               // offset of the resize tables (level >= 1)
+  int nodeTabOff;           // >= 0: byte offset of this level's node tables inside a frame's HBM node scratch (quota too large for LDS), else -1
   float scale;              // m_v_scaleFactors[level]
   float size;               // (float)(int)(31 * scale), orbExtractor.cpp:595
 };
 struct PlanDev {
   int nLevels, nCellsTotal, cellCap, sumQuota;
   int maxX[16];             // m_v_maxXcords[0..15]
+  unsigned nodeTabFrameStride;         // bytes of HBM node scratch per frame (0 when every level's node table fits the LDS)
   int blurTileBegin[kMaxLevels + 1];   // first 64x32 blur tile of each level in the flat per-frame tile list
   int borderBegin[kMaxLevels + 1];     // first border thread of each level in k_pyr_borders' flat per-frame list (multiples of 256)
   LevelDev lv[kMaxLevels];
@@ -468,7 +470,7 @@ struct QtBlockCtx {   // workgroup of kQtThreads threads: barriers + LDS hand-of
     return x + off;
   }
   // all lanes of the wave call this together; lanes with k < 0 only take part in the ballots
-  __device__ void count_child(QT_LDS unsigned long long* cc, int k, int q) {
+  template <class P64> __device__ void count_child(P64 cc, int k, int q) {
     unsigned long long remaining = __ballot(k >= 0);
     const int lane = threadIdx.x & 63;
     while (remaining) {
@@ -518,7 +520,7 @@ struct QtWaveCtx {
     return x;
   }
   // all lanes of the wave call this together; lanes with k < 0 only take part in the ballots
-  __device__ void count_child(QT_LDS unsigned long long* cc, int k, int q) {
+  template <class P64> __device__ void count_child(P64 cc, int k, int q) {
     unsigned long long remaining = __ballot(k >= 0);
     const int lane = threadIdx.x & 63;
     while (remaining) {
@@ -541,31 +543,48 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(PlanDev P, const uint32
                                                  const uint32_t* __restrict__ cellCand, uint32_t* __restrict__ qtCand,
                                                  uint16_t* __restrict__ qtNode, size_t qtFrameStride, int nodeCap, int ldsCandCap, int levelBase,
                                                  uint32_t* __restrict__ lvlKp, int* __restrict__ lvlCount, int* __restrict__ status,
-                                                 const uint8_t* __restrict__ needPass) {
+                                                 const uint8_t* __restrict__ needPass, uint8_t* __restrict__ nodeScratch) {
   extern __shared__ __align__(16) uint8_t smem[];
   __shared__ unsigned w32[16];
   __shared__ unsigned long long w64[16];
   const int level = levelBase + blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
   if (needPass && !needPass[f * kMaxLevels + level]) return;   // k_quadtree_flat already produced this unit
   const LevelDev L = P.lv[level];
+  bool nodesInHbm = false;
   if (nodeCap <= 0) {   // one launch over all levels (-nodeCap = nodes the launch's LDS holds): each level derives its own table size
     const int have = -nodeCap;
     nodeCap = 4 * max(L.quota, 1);
-    if (nodeCap > have) {   // quota too large for an LDS node table: this unit cannot be handed over
-      if (lane == 0) { atomicMax(status, 3); lvlCount[f * kMaxLevels + level] = 0; }
-      return;
-    }
+    nodesInHbm = nodeCap > have;
+  }
+  if (L.nodeTabOff >= 0) nodesInHbm = true;   // the plan gave this level HBM node tables (its quota does not fit the LDS)
+  if (nodesInHbm && (L.nodeTabOff < 0 || !nodeScratch)) {
+    if (lane == 0) { atomicMax(status, 3); lvlCount[f * kMaxLevels + level] = 0; }
+    return;
   }
   uint8_t* sp = smem;
   QtShared S;
-  S.cc = (QT_LDS unsigned long long*)(sp); sp += sizeof(unsigned long long) * nodeCap;
-  S.geom[0] = (QT_LDS QtGeom*)(sp); sp += sizeof(QtGeom) * nodeCap;
-  S.geom[1] = (QT_LDS QtGeom*)(sp); sp += sizeof(QtGeom) * nodeCap;
-  S.childIdx = (QT_LDS uint16_t*)(sp); sp += sizeof(uint16_t) * 4 * nodeCap;
-  S.cnt[0] = (QT_LDS uint32_t*)(sp); sp += sizeof(uint32_t) * nodeCap;
-  S.cnt[1] = (QT_LDS uint32_t*)(sp); sp += sizeof(uint32_t) * nodeCap;
-  S.base[0] = (QT_LDS uint32_t*)(sp); sp += sizeof(uint32_t) * nodeCap;
-  S.base[1] = (QT_LDS uint32_t*)(sp); sp += sizeof(uint32_t) * nodeCap;
+  QtSharedT<false> SG;
+  if (!nodesInHbm) {
+    S.cc = (QT_LDS unsigned long long*)(sp); sp += sizeof(unsigned long long) * nodeCap;
+    S.geom[0] = (QT_LDS QtGeom*)(sp); sp += sizeof(QtGeom) * nodeCap;
+    S.geom[1] = (QT_LDS QtGeom*)(sp); sp += sizeof(QtGeom) * nodeCap;
+    S.childIdx = (QT_LDS uint16_t*)(sp); sp += sizeof(uint16_t) * 4 * nodeCap;
+    S.cnt[0] = (QT_LDS uint32_t*)(sp); sp += sizeof(uint32_t) * nodeCap;
+    S.cnt[1] = (QT_LDS uint32_t*)(sp); sp += sizeof(uint32_t) * nodeCap;
+    S.base[0] = (QT_LDS uint32_t*)(sp); sp += sizeof(uint32_t) * nodeCap;
+    S.base[1] = (QT_LDS uint32_t*)(sp); sp += sizeof(uint32_t) * nodeCap;
+  } else {   // same layout in this (frame, level)'s slice of the HBM node scratch
+    uint8_t* gp = nodeScratch + (size_t)f * P.nodeTabFrameStride + L.nodeTabOff;
+    SG.cc = (unsigned long long*)(gp); gp += sizeof(unsigned long long) * nodeCap;
+    SG.geom[0] = (QtGeom*)(gp); gp += sizeof(QtGeom) * nodeCap;
+    SG.geom[1] = (QtGeom*)(gp); gp += sizeof(QtGeom) * nodeCap;
+    SG.childIdx = (uint16_t*)(gp); gp += sizeof(uint16_t) * 4 * nodeCap;
+    SG.cnt[0] = (uint32_t*)(gp); gp += sizeof(uint32_t) * nodeCap;
+    SG.cnt[1] = (uint32_t*)(gp); gp += sizeof(uint32_t) * nodeCap;
+    SG.base[0] = (uint32_t*)(gp); gp += sizeof(uint32_t) * nodeCap;
+    SG.base[1] = (uint32_t*)(gp);
+    ldsCandCap = 0;                          // candidates from HBM scratch as well: the launch's LDS only holds the cell bases
+  }
   QT_LDS uint32_t* ldsCand = (QT_LDS uint32_t*)(sp); sp += sizeof(uint32_t) * 2 * ldsCandCap;
   QT_LDS uint16_t* ldsNode = (QT_LDS uint16_t*)(sp); sp += sizeof(uint16_t) * 2 * ldsCandCap;
   QT_LDS uint32_t* cellBase = (QT_LDS uint32_t*)(sp);
@@ -607,7 +626,8 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(PlanDev P, const uint32
     return;
 #endif
     uint32_t* outKp = lvlKp + (size_t)f * P.sumQuota + L.kpOff;
-    if (inLds) nOut = qt_distribute(cx, S, GL, (int)n, L.w - 2 * kBorder, L.h - 2 * kBorder, L.quota, nodeCap, outKp);
+    if (nodesInHbm) nOut = qt_distribute(cx, SG, GG, (int)n, L.w - 2 * kBorder, L.h - 2 * kBorder, L.quota, nodeCap, outKp);
+    else if (inLds) nOut = qt_distribute(cx, S, GL, (int)n, L.w - 2 * kBorder, L.h - 2 * kBorder, L.quota, nodeCap, outKp);
     else nOut = qt_distribute(cx, S, GG, (int)n, L.w - 2 * kBorder, L.h - 2 * kBorder, L.quota, nodeCap, outKp);
     if (nOut < 0) {
       if (lane == 0) atomicMax(status, 2);

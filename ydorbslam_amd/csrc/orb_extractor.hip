@@ -62,6 +62,7 @@ struct ydorb_extractor {
   uint8_t *d_img = nullptr, *d_pyr = nullptr, *d_blur = nullptr;
   uint32_t *d_cellCount = nullptr, *d_cellCand = nullptr, *d_qtCand = nullptr, *d_qtKeys = nullptr, *d_lvlKp = nullptr;
   uint16_t* d_qtNode = nullptr;
+  uint8_t* d_nodeScratch = nullptr;  // HBM node tables of the levels whose quota does not fit the LDS (usually none)
   uint8_t* d_needPass = nullptr;   // [frame][level]: 1 = the flat quad-tree kernel left the unit to the pass kernel
   int *d_lvlCount = nullptr, *d_status = nullptr, *d_nOut = nullptr;
   int *d_lvlMaxN = nullptr, *h_lvlMaxN = nullptr;   // largest candidate count seen per level (device max, copied back after every call)
@@ -102,7 +103,7 @@ namespace {
 void freeBuffers(ydorb_extractor* e) {
   auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
   F(e->d_img); F(e->d_pyr); F(e->d_blur); F(e->d_cellCount); F(e->d_cellCand); F(e->d_qtCand); F(e->d_qtKeys);
-  F(e->d_lvlKp); F(e->d_qtNode); F(e->d_needPass); F(e->d_lvlCount); F(e->d_lvlMaxN); F(e->d_status); F(e->d_nOut); F(e->d_lvlAngle); F(e->d_cells);
+  F(e->d_lvlKp); F(e->d_qtNode); F(e->d_needPass); F(e->d_nodeScratch); F(e->d_lvlCount); F(e->d_lvlMaxN); F(e->d_status); F(e->d_nOut); F(e->d_lvlAngle); F(e->d_cells);
   F(e->d_tabInt); F(e->d_tabShort); F(e->d_kps); F(e->d_desc);
   auto H = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
   H(e->h_img); H(e->h_kps); H(e->h_desc); H(e->h_nOut); H(e->h_status); H(e->h_lvlMaxN);
@@ -237,24 +238,29 @@ int buildPlan(ydorb_extractor* e, int w, int h, HostPlan& P) {
       Q.candCap = 0;
       Q.lds = (size_t)Q.nodeCap * 48 + (size_t)(L.nCells + 1) * 4;
     }
-    // very large quotas (few levels x many features): the pass kernel's node table (48 B x 4 x quota) no longer fits LDS.  The flat
-    // kernel has no node table, so the level still works; only a unit that the flat kernel would hand over cannot be taken
-    // (reported as YDORB_ERR_CAPACITY by the call's status check — never silently wrong).
+    // very large quotas (few levels x many features): the pass kernel's node table (48 B x 4 x quota) no longer fits the LDS; such a
+    // level gets its node tables (and candidates) in HBM scratch — slow, but the flat kernel takes every unit with <= 8192 candidates
+    // and a tree no deeper than 7 levels, so this is the rare hand-over path of an unusual configuration
     Q.passOk = Q.lds <= 150 * 1024;
     if (Q.passOk) {
       P.qtLdsMax = std::max(P.qtLdsMax, Q.lds);
       P.qtPassLds = std::max(P.qtPassLds, (size_t)Q.nodeCap * 48 + (size_t)(L.nCells + 1) * 4);
       P.qtPassNodes = std::max(P.qtPassNodes, Q.nodeCap);
+      D.lv[l].nodeTabOff = -1;
+    } else {
+      if (Q.nodeCap > 65535) { set_error("n_features=%d: level %d would need %d quad-tree nodes (max 65535)", e->cfg.n_features, l, Q.nodeCap); return YDORB_ERR_UNSUPPORTED; }
+      D.lv[l].nodeTabOff = (int)D.nodeTabFrameStride;
+      D.nodeTabFrameStride += (unsigned)alignUpZ((size_t)Q.nodeCap * 48, 256);
+      Q.candCap = 0;
+      Q.lds = (size_t)(L.nCells + 1) * 4 + 64;
+      P.qtLdsMax = std::max(P.qtLdsMax, Q.lds);
+      P.qtPassLds = std::max(P.qtPassLds, Q.lds);
     }
     // flat kernel: 512*items candidate slots.  First guess from the densities above (L0 1/45 .. L7 1/20 of the band); enqueue()
     // re-sizes it from the candidate counts the device actually saw.  A unit with more candidates goes to the pass kernel.
     Q.flatItems = flatItemsFor((long)((double)band / (45.0 - 3.5 * l)) + 64);
     Q.flatLds = qt_flat_lds_bytes(Q.flatItems, L.quota);
     if (Q.flatLds > 150 * 1024) { Q.flatItems = 0; Q.flatLds = 0; }   // huge quotas: pass kernel only
-    if (!Q.passOk && (!Q.flatItems || e->forcePassQuadtree)) {
-      set_error("n_features=%d needs %zu B of LDS for the level-%d quad-tree (max 150 KiB)", e->cfg.n_features, Q.lds, l);
-      return YDORB_ERR_UNSUPPORTED;
-    }
   }
   P.qtPassLds = std::max<size_t>(P.qtPassLds, 1024);
   return YDORB_OK;
@@ -280,6 +286,7 @@ int ensurePlan(ydorb_extractor* e, int w, int h, int nFrames) {
   HIPCHK(hipMalloc(&e->d_cellCand, sizeof(uint32_t) * (size_t)D.nCellsTotal * D.cellCap * B));
   HIPCHK(hipMalloc(&e->d_qtCand, sizeof(uint32_t) * 2 * P.qtFrameStride * B));
   HIPCHK(hipMalloc(&e->d_qtNode, sizeof(uint16_t) * 2 * P.qtFrameStride * B));
+  if (D.nodeTabFrameStride) HIPCHK(hipMalloc(&e->d_nodeScratch, (size_t)D.nodeTabFrameStride * B));
   HIPCHK(hipMalloc(&e->d_needPass, (size_t)kMaxLevels * B));
   HIPCHK(hipMemsetAsync(e->d_needPass, 0, (size_t)kMaxLevels * B, e->stream));
 
@@ -403,7 +410,7 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
     // hands over (rare) are picked up by ONE launch over all levels after the join (below)
     if (!needPass)
       hipLaunchKernelGGL(k_quadtree, dim3(1, nFrames), dim3(kQtThreads), Q.lds, e->qtStream[l], D, e->d_cellCount, e->d_cellCand,
-                         e->d_qtCand, e->d_qtNode, P.qtFrameStride, Q.nodeCap, Q.candCap, l, e->d_lvlKp, e->d_lvlCount, e->d_status, needPass);
+                         e->d_qtCand, e->d_qtNode, P.qtFrameStride, Q.nodeCap, Q.candCap, l, e->d_lvlKp, e->d_lvlCount, e->d_status, needPass, e->d_nodeScratch);
     else
       anyFlat = true;
     HIPCHK(hipEventRecord(e->evJoin[l], e->qtStream[l]));
@@ -412,7 +419,7 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   for (int l = 0; l < D.nLevels; l++) HIPCHK(hipStreamWaitEvent(s, e->evJoin[l], 0));
   if (anyFlat)   // hand-over units of every level: node table in LDS, candidates in HBM scratch (candCap 0); others exit at once
     hipLaunchKernelGGL(k_quadtree, dim3(D.nLevels, nFrames), dim3(kQtThreads), P.qtPassLds, s, D, e->d_cellCount, e->d_cellCand, e->d_qtCand,
-                       e->d_qtNode, P.qtFrameStride, -P.qtPassNodes, 0, 0, e->d_lvlKp, e->d_lvlCount, e->d_status, e->d_needPass);
+                       e->d_qtNode, P.qtFrameStride, -std::max(P.qtPassNodes, 1), 0, 0, e->d_lvlKp, e->d_lvlCount, e->d_status, e->d_needPass, e->d_nodeScratch);
   if (prof) HIPCHK(hipEventRecord(e->ev[4], s));
   hipLaunchKernelGGL(k_orient_describe, dim3(((D.sumQuota + 3) / 4 + 7) / 8 * 8, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
                      P.blurFrameStride, D, e->d_lvlKp, e->d_lvlCount, d_kps, d_desc, cap, d_nOut, e->d_lvlAngle);

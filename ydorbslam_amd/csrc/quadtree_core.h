@@ -155,13 +155,23 @@ template <class P> YD_HD inline int qt_sort_front(P a, int m) {
 #else
 #define QT_LDS
 #endif
-struct QtShared {           // LDS (device) / heap (host); arrays of nodeCap entries
-  QT_LDS QtGeom* geom[2];
-  QT_LDS uint32_t* cnt[2];
-  QT_LDS uint32_t* base[2];
-  QT_LDS unsigned long long* cc;   // packed 4x16 child counts; re-used as the segment-start prefix in sweep 2
-  QT_LDS uint16_t* childIdx;       // [nodeCap*4] new list index of child q (slot 0: own new index for a leaf)
+// Node tables (arrays of nodeCap entries): LDS on the device in the normal case, heap on the host; `InLds = false` on the device puts
+// them in HBM scratch — only for quotas so large (few levels x thousands of features) that 48 B x 4 x quota exceeds the LDS.
+template <bool InLds> struct QtNodePtr {
+  typedef QtGeom* Geom; typedef uint32_t* U32; typedef unsigned long long* U64; typedef uint16_t* U16;
 };
+template <> struct QtNodePtr<true> {
+  typedef QT_LDS QtGeom* Geom; typedef QT_LDS uint32_t* U32; typedef QT_LDS unsigned long long* U64; typedef QT_LDS uint16_t* U16;
+};
+template <bool InLds>
+struct QtSharedT {
+  typename QtNodePtr<InLds>::Geom geom[2];
+  typename QtNodePtr<InLds>::U32 cnt[2];
+  typename QtNodePtr<InLds>::U32 base[2];
+  typename QtNodePtr<InLds>::U64 cc;        // packed 4x16 child counts; re-used as the segment-start prefix in sweep 2
+  typename QtNodePtr<InLds>::U16 childIdx;  // [nodeCap*4] new list index of child q (slot 0: own new index for a leaf)
+};
+typedef QtSharedT<true> QtShared;
 template <bool InLds> struct QtCandPtr { typedef uint32_t* U32; typedef uint16_t* U16; };
 template <> struct QtCandPtr<true> { typedef QT_LDS uint32_t* U32; typedef QT_LDS uint16_t* U16; };
 template <bool InLds>
@@ -172,8 +182,8 @@ struct QtCandT {            // per (frame, level) candidate state, n entries eac
 typedef QtCandT<false> QtGlobal;
 
 // Ctx: tid(), nthreads(), sync(), scan_incl_u64(v,&total), scan_incl_u32(v,&total), count_child(cc,k,q) (k < 0: lane idle)
-template <class Ctx, class Cand>
-YD_HD int qt_distribute(Ctx& cx, const QtShared& S, const Cand& G, int n, int rootX1, int rootY1, int quota,
+template <class Ctx, class Shared, class Cand>
+YD_HD int qt_distribute(Ctx& cx, const Shared& S, const Cand& G, int n, int rootX1, int rootY1, int quota,
                         int nodeCap, uint32_t* out) {
   const int tid = cx.tid(), nt = cx.nthreads();
   if (n <= 0 || quota <= 0) return 0;  // resize(desired) of an empty or zero-quota list
