@@ -231,6 +231,35 @@ int ydorb_search_for_triangulation(ydorb_matcher_t* h, const YdTriSide* first, c
                                    int32_t n_levels, int32_t stereo_only, int32_t check_orientation, int32_t* matched_second,
                                    int32_t* n_matches);
 
+/* Frame::computeStereoMatches(), src/frame.cpp:362-477: for every left keypoint the best right descriptor among the right
+ * keypoints whose row band covers its row, an 11x11 block match over 11 column shifts at the keypoint's pyramid level,
+ * parabola refinement, disparity -> depth, and the final outlier rule.  One call handles n_pairs rectified pairs.
+ * The image pyramids are those the two extractors built in their last call (m_v_imagePyramid, read at :366,412-427):
+ * pair p reads frame first_frame + p*frame_step of that call on each side (so one batched extractor call over interleaved
+ * left/right images, or two extractors, both work).  Keypoints are the undistorted ones (frame.cpp:91-93).
+ * right_x / depth: float [n_pairs][left->cap] = m_v_rightXcords / m_v_depth (-1 = none, -2 = removed by the outlier rule).
+ * n_kept[p] = entries of vDistIndices; status[p]: bit0 = a left keypoint's (int)pt.y was outside [0, rows) (undefined vector
+ * index in the reference; counted as a row without right keypoints), bit1 = a block-match window started left of the image
+ * (cv::Exception in the reference; treated like the other window `continue`s).  Either may be NULL.
+ * flags: default 0 replays the reference as written, including its left index that only advances when a keypoint reaches
+ * the end of the loop body (:462) - a serial chain over the keypoints of a pair; YDORB_STEREO_INDEX_BY_KEYPOINT uses the
+ * keypoint's own index for the descriptor row and the output slot (one wave per keypoint).  With
+ * YDORB_STEREO_DEVICE_POINTERS every array argument is a device pointer and the call is asynchronous on `stream`
+ * (a hipStream_t) or the matcher's own, ordered by the caller after the extractor calls. */
+#define YDORB_STEREO_INDEX_BY_KEYPOINT 1
+#define YDORB_STEREO_DEVICE_POINTERS 2
+typedef struct YdStereoSide {
+  const ydorb_extractor_t* extractor;
+  int32_t first_frame, frame_step;
+  const YdKeyPoint* kps;  /* [n_pairs][cap] */
+  const uint8_t* desc;    /* [n_pairs][cap][32] */
+  const int32_t* n;       /* [n_pairs] */
+  int32_t cap;            /* right side: <= 8192 */
+  int32_t reserved;
+} YdStereoSide;
+int ydorb_stereo_matches(ydorb_matcher_t* h, const YdStereoSide* left, const YdStereoSide* right, int32_t n_pairs, float bf, float b,
+                         int32_t flags, float* right_x, float* depth, int32_t* n_kept, int32_t* status, void* stream);
+
 /* Device-resident streaming form used after ydorb_extract_batch_device: for f = 0..n_frames-2, the keypoints of
  * frame f are searched in frame f+1 with the searchByProjectionInLastAndCurrentFrame rules (mode 1; position
  * prediction = d_affine[f] (2x3, row-major) applied to the keypoint, NULL = identity; window th*scaleFactor[octave];

@@ -86,6 +86,9 @@ def lib():
         L.yo_ba_chol_solve.restype = C.c_int
         L.yo_ba_chol_solve.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.yo_ba_huber.argtypes = [C.c_double, C.c_double, C.c_void_p]
+        L.yo_stereo_matches.restype = C.c_int
+        L.yo_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + \
+            [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -343,3 +346,24 @@ def pose_optimize(prob):
     L.yo_pose_optimize.restype = C.c_int
     n = L.yo_pose_optimize(_p(pose), E, _p(X), _p(z), _p(w), _p(cam), _p(outlier), _p(chi), C.byref(trials))
     return dict(pose=pose, outlier=outlier[:E], inliers=n, chi2=chi, trials=trials.value)
+
+
+def stereo_matches(kps_l, desc_l, kps_r, desc_r, levels_l, levels_r, scale, inv_scale, bf, b, index_by_keypoint=False):
+    """Frame::computeStereoMatches (frame.cpp:362-477) for one pair.  levels_*: list of 2-D uint8 arrays (the level ROIs).
+    Returns (right_x, depth, n_kept, status)."""
+    L = lib()
+    kl = np.ascontiguousarray(kps_l, KP_DTYPE); kr = np.ascontiguousarray(kps_r, KP_DTYPE)
+    dl = np.ascontiguousarray(desc_l, np.uint8); dr = np.ascontiguousarray(desc_r, np.uint8)
+    ll = [np.ascontiguousarray(a, np.uint8) for a in levels_l]; lr = [np.ascontiguousarray(a, np.uint8) for a in levels_r]
+    nlv = len(ll)
+    assert len(lr) == nlv and all(a.shape == c.shape for a, c in zip(ll, lr))
+    pl = (C.c_void_p * nlv)(*[a.ctypes.data for a in ll]); pr = (C.c_void_p * nlv)(*[a.ctypes.data for a in lr])
+    w = np.array([a.shape[1] for a in ll], np.int32); h = np.array([a.shape[0] for a in ll], np.int32)
+    sl = np.array([a.strides[0] for a in ll], np.int32); sr = np.array([a.strides[0] for a in lr], np.int32)
+    sc = np.ascontiguousarray(scale, np.float32); isc = np.ascontiguousarray(inv_scale, np.float32)
+    rx = np.zeros(max(len(kl), 1), np.float32); depth = np.zeros(max(len(kl), 1), np.float32)
+    st = C.c_int(0)
+    kept = L.yo_stereo_matches(_p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), C.cast(pl, C.c_void_p), C.cast(pr, C.c_void_p), _p(w), _p(h),
+                               _p(sl), _p(sr), nlv, _p(sc), _p(isc), float(bf), float(b), 1 if index_by_keypoint else 0, _p(rx), _p(depth),
+                               C.byref(st))
+    return rx[:len(kl)], depth[:len(kl)], kept, st.value

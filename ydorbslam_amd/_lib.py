@@ -62,6 +62,7 @@ SYMBOLS = {
     "ydorb_fuse_search": (C.c_int, [_VP, _VP, _VP, _VP, _I, _VP, _I, _VP, C.POINTER(_I)]),
     "ydorb_window_search": (C.c_int, [_VP, _VP, _VP, _VP, _I, _VP, _I, _I, _VP, C.POINTER(_I)]),
     "ydorb_search_for_triangulation": (C.c_int, [_VP, _VP, _VP, _VP, C.c_float, C.c_float, _VP, _VP, _I, _I, _I, _VP, C.POINTER(_I)]),
+    "ydorb_stereo_matches": (C.c_int, [_VP, _VP, _VP, _I, C.c_float, C.c_float, _I, _VP, _VP, _VP, _VP, _VP]),
     "ydorb_match_consecutive_device": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, C.c_float, _VP, _I, _VP, _I, _VP, _VP, _VP]),
     "ydorb_matcher_synchronize": (C.c_int, [_VP]),
     "ydorb_matcher_set_profiling": (C.c_int, [_VP, _I]),
@@ -118,6 +119,15 @@ class YdBowSide(C.Structure):
 
 class YdTriSide(C.Structure):
     _fields_ = [("kps", _VP), ("desc", _VP), ("right_x", _VP), ("has_map_point", _VP), ("n", _I), ("fv", YdFeatureVector)]
+
+
+class YdStereoSide(C.Structure):
+    _fields_ = [("extractor", _VP), ("first_frame", _I), ("frame_step", _I), ("kps", _VP), ("desc", _VP), ("n", _VP), ("cap", _I),
+                ("reserved", _I)]
+
+
+STEREO_INDEX_BY_KEYPOINT = 1
+STEREO_DEVICE_POINTERS = 2
 
 
 def lib():

@@ -449,6 +449,19 @@ void collectProfile(ydorb_extractor* e) {
 
 }  // namespace
 
+int ydorb::extractor_pyramid_view(const ydorb_extractor* e, PyramidView* v) {
+  if (!e || !v || !e->planValid || e->lastFrames < 1) { set_error("the extractor holds no pyramid (no call yet)"); return YDORB_ERR_INVALID_ARG; }
+  v->device = e->cfg.device; v->nLevels = e->cfg.n_levels; v->frames = e->lastFrames; v->frameStride = (long long)e->plan.pyrFrameStride;
+  v->stream = e->stream;
+  for (int l = 0; l < e->cfg.n_levels; l++) {
+    const LevelDev& L = e->plan.dev.lv[l];
+    v->roi[l] = e->d_pyr + L.padOff + (size_t)kPad * L.pitch + kPad;
+    v->w[l] = L.w; v->h[l] = L.h; v->pitch[l] = L.pitch;
+    v->scale[l] = e->sf[l]; v->invScale[l] = e->isf[l];
+  }
+  return YDORB_OK;
+}
+
 extern "C" {
 
 int ydorb_extractor_create(const YdExtractorConfig* cfg, ydorb_extractor_t** out) {

@@ -12,6 +12,7 @@
 
 #include "../../include/ydorb/c_api.h"
 #include "match_kernels.hip.h"
+#include "stereo_kernels.hip.h"
 #include "ydorb_host.h"
 
 using namespace ydorb;
@@ -58,7 +59,7 @@ struct ydorb_matcher {
   int device = 0;
   hipStream_t stream = nullptr;
   Buf kps, desc, rightX, queries, qdesc, taken, assigned, matchQ, qInfo, cellStart, cellIdx, pool, frames, calls, misc, kps2,
-      desc2, feat, valid, qFeat, qRange, qAngle, sf, heads, sortedKp, sortedDesc, kps1, good1, good2;
+      desc2, feat, valid, qFeat, qRange, qAngle, sf, heads, sortedKp, sortedDesc, kps1, good1, good2, stereoPar, stereoCnt, stereoOut;
   size_t poolRecords = 1u << 20;
   // cached descriptors of the last batched launch (re-uploaded only when they change)
   std::vector<FrameDev> hFrames;
@@ -156,7 +157,8 @@ void ydorb_matcher_destroy(ydorb_matcher_t* m) {
   (void)hipStreamSynchronize(m->stream);
   for (Buf* b : {&m->kps, &m->desc, &m->rightX, &m->queries, &m->qdesc, &m->taken, &m->assigned, &m->matchQ, &m->qInfo, &m->cellStart,
                  &m->cellIdx, &m->pool, &m->frames, &m->calls, &m->misc, &m->kps2, &m->desc2, &m->feat, &m->valid, &m->qFeat, &m->qRange,
-                 &m->qAngle, &m->sf, &m->heads, &m->sortedKp, &m->sortedDesc})
+                 &m->qAngle, &m->sf, &m->heads, &m->sortedKp, &m->sortedDesc, &m->kps1, &m->good1, &m->good2, &m->stereoPar, &m->stereoCnt,
+                 &m->stereoOut})
     b->release();
   for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(m->stream);
@@ -482,6 +484,92 @@ int ydorb_search_for_triangulation(ydorb_matcher_t* m, const YdTriSide* A, const
   if (hmisc[1] != 0) { set_error("bow record pool overflow"); return YDORB_ERR_CAPACITY; }
   for (int q = 0; q < nq; q++) out[qFeat[q]] = res[q];
   *nMatches = hmisc[2];
+  return YDORB_OK;
+}
+
+int ydorb_stereo_matches(ydorb_matcher_t* m, const YdStereoSide* L, const YdStereoSide* R, int32_t nPairs, float bf, float b, int32_t flags,
+                         float* rightX, float* depth, int32_t* nKept, int32_t* status, void* stream) {
+  if (!m || !L || !R || !L->extractor || !R->extractor || !L->kps || !L->desc || !L->n || !R->kps || !R->desc || !R->n || !rightX || !depth ||
+      nPairs < 1 || L->cap < 1 || R->cap < 1 || !(bf > 0.f) || !(b > 0.f)) {
+    set_error("invalid argument");
+    return YDORB_ERR_INVALID_ARG;
+  }
+  if (R->cap > kStereoMaxRight) { set_error("right cap %d > %d", R->cap, kStereoMaxRight); return YDORB_ERR_CAPACITY; }
+  PyramidView vl, vr;
+  int rc;
+  if ((rc = extractor_pyramid_view(L->extractor, &vl)) || (rc = extractor_pyramid_view(R->extractor, &vr))) return rc;
+  if (vl.device != m->device || vr.device != m->device) { set_error("extractors and matcher live on different devices"); return YDORB_ERR_INVALID_ARG; }
+  if (vl.nLevels != vr.nLevels) { set_error("left and right pyramids differ in depth"); return YDORB_ERR_INVALID_ARG; }
+  for (int l = 0; l < vl.nLevels; l++)
+    if (vl.w[l] != vr.w[l] || vl.h[l] != vr.h[l] || vl.scale[l] != vr.scale[l]) { set_error("left and right pyramids differ at level %d", l); return YDORB_ERR_INVALID_ARG; }
+  const int lastL = L->first_frame + (nPairs - 1) * L->frame_step, lastR = R->first_frame + (nPairs - 1) * R->frame_step;
+  if (L->first_frame < 0 || lastL < 0 || L->first_frame >= vl.frames || lastL >= vl.frames || R->first_frame < 0 || lastR < 0 ||
+      R->first_frame >= vr.frames || lastR >= vr.frames) {
+    set_error("pair frames outside the extractors' last call (%d / %d frames)", vl.frames, vr.frames);
+    return YDORB_ERR_INVALID_ARG;
+  }
+  HIPCHK(hipSetDevice(m->device));
+  const bool dev = flags & YDORB_STEREO_DEVICE_POINTERS;
+  hipStream_t s = stream ? (hipStream_t)stream : m->stream;
+  const size_t nl = (size_t)nPairs * L->cap, nr = (size_t)nPairs * R->cap;
+  if ((rc = m->stereoPar.ensure(sizeof(StereoDev))) || (rc = m->stereoCnt.ensure(sizeof(int) * 4 * nPairs)) ||
+      (rc = m->stereoOut.ensure(sizeof(int) * 2 * nPairs)))
+    return rc;
+  StereoDev P{};
+  if (dev) {
+    P.kpsL = reinterpret_cast<const KeyPointDev*>(L->kps); P.descL = L->desc; P.nL = L->n;
+    P.kpsR = reinterpret_cast<const KeyPointDev*>(R->kps); P.descR = R->desc; P.nR = R->n;
+    P.rightX = rightX; P.depth = depth;
+  } else {
+    // the pyramids must be complete before the kernels read them from another stream
+    HIPCHK(hipStreamSynchronize((hipStream_t)vl.stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)vr.stream));
+    if ((rc = m->kps1.ensure(sizeof(YdKeyPoint) * nl)) || (rc = m->desc.ensure(32 * nl)) || (rc = m->kps2.ensure(sizeof(YdKeyPoint) * nr)) ||
+        (rc = m->desc2.ensure(32 * nr)) || (rc = m->qRange.ensure(sizeof(int) * 2 * nPairs)) || (rc = m->rightX.ensure(sizeof(float) * 2 * nl)))
+      return rc;
+    HIPCHK(hipMemcpyAsync(m->kps1.p, L->kps, sizeof(YdKeyPoint) * nl, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(m->desc.p, L->desc, 32 * nl, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(m->kps2.p, R->kps, sizeof(YdKeyPoint) * nr, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(m->desc2.p, R->desc, 32 * nr, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(m->qRange.p, L->n, sizeof(int) * nPairs, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(m->qRange.as<int>() + nPairs, R->n, sizeof(int) * nPairs, hipMemcpyHostToDevice, s));
+    P.kpsL = m->kps1.as<KeyPointDev>(); P.descL = m->desc.as<uint8_t>(); P.nL = m->qRange.as<int>();
+    P.kpsR = m->kps2.as<KeyPointDev>(); P.descR = m->desc2.as<uint8_t>(); P.nR = m->qRange.as<int>() + nPairs;
+    P.rightX = m->rightX.as<float>(); P.depth = m->rightX.as<float>() + nl;
+  }
+  for (int l = 0; l < vl.nLevels; l++) {
+    P.pyrL[l] = vl.roi[l]; P.pyrR[l] = vr.roi[l];
+    P.w[l] = vl.w[l]; P.h[l] = vl.h[l]; P.pitchL[l] = vl.pitch[l]; P.pitchR[l] = vr.pitch[l];
+    P.scale[l] = vl.scale[l]; P.invScale[l] = vl.invScale[l];
+  }
+  P.frameStrideL = vl.frameStride; P.frameStrideR = vr.frameStride;
+  P.capL = L->cap; P.capR = R->cap; P.frameL0 = L->first_frame; P.frameLStep = L->frame_step; P.frameR0 = R->first_frame; P.frameRStep = R->frame_step;
+  P.nLevels = vl.nLevels; P.flags = flags; P.bf = bf; P.maxD = bf / b;   // :382
+  P.counters = m->stereoCnt.as<int>(); P.keptOut = m->stereoOut.as<int>(); P.statusOut = m->stereoOut.as<int>() + nPairs;
+  HIPCHK(hipMemcpyAsync(m->stereoPar.p, &P, sizeof(P), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemsetAsync(m->stereoCnt.p, 0, sizeof(int) * 4 * nPairs, s));
+  const size_t lds = (size_t)R->cap * 8;
+  if (flags & YDORB_STEREO_INDEX_BY_KEYPOINT) {
+    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stereo<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_stereo<false>, dim3((L->cap + kStereoChunk - 1) / kStereoChunk, nPairs), dim3(256), lds, s, m->stereoPar.as<StereoDev>());
+  } else {
+    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stereo<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_stereo<true>, dim3(1, nPairs), dim3(256), lds, s, m->stereoPar.as<StereoDev>());
+  }
+  hipLaunchKernelGGL(k_stereo_outliers, dim3(nPairs), dim3(256), 0, s, m->stereoPar.as<StereoDev>());
+  HIPCHK(hipGetLastError());
+  if (dev) {
+    if (nKept) HIPCHK(hipMemcpyAsync(nKept, P.keptOut, sizeof(int) * nPairs, hipMemcpyDeviceToDevice, s));
+    if (status) HIPCHK(hipMemcpyAsync(status, P.statusOut, sizeof(int) * nPairs, hipMemcpyDeviceToDevice, s));
+    // the parameter block is read by the kernels after this call returns: it lives in the handle, the next call on the same
+    // handle overwrites it in stream order
+    return YDORB_OK;
+  }
+  HIPCHK(hipMemcpyAsync(rightX, P.rightX, sizeof(float) * nl, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(depth, P.depth, sizeof(float) * nl, hipMemcpyDeviceToHost, s));
+  if (nKept) HIPCHK(hipMemcpyAsync(nKept, P.keptOut, sizeof(int) * nPairs, hipMemcpyDeviceToHost, s));
+  if (status) HIPCHK(hipMemcpyAsync(status, P.statusOut, sizeof(int) * nPairs, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
   return YDORB_OK;
 }
 

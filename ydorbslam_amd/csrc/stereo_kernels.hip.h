@@ -1,0 +1,203 @@
+// Stereo association of one rectified pair: Frame::computeStereoMatches (reference src/frame.cpp:362-477).
+//
+// Per left keypoint: best right descriptor among the right keypoints whose row band covers the left row (:368-402), an
+// 11x11 L1 block match over 11 column shifts at the keypoint's pyramid level (:406-436), a parabola through the three
+// distances round the best shift (:441-446) and disparity -> depth (:448-459); per pair: the outlier rule on the sorted
+// block-match minima (:464-472).
+//
+// The reference indexes the left descriptor and the output slot with a counter that only advances when a keypoint reaches
+// the end of the loop body (:462), which makes the result a serial chain over the keypoints.  k_stereo<true> replays that
+// chain exactly (one wave per pair walks the keypoints, the 64 lanes share each keypoint's candidate scan and block match);
+// k_stereo<false> is the per-keypoint form (descriptor and slot = the keypoint's own index, YDORB_STEREO_INDEX_BY_KEYPOINT)
+// with one wave per keypoint.  Everything else is the same device function, restated in oracle/stereo_oracle.cpp.
+//
+// Row bands: instead of the reference's per-row index lists the kernel keeps one (lo, hi, octave, x) record per right
+// keypoint in LDS and scans them in index order — the same candidates in the same order (the lists are filled in keypoint
+// order, :373-379), so "first minimum" is the minimum of (distance << 16 | index).
+#pragma once
+#include "match_kernels.hip.h"
+
+#pragma clang fp contract(off)
+
+namespace ydorb {
+
+constexpr int kStereoChunk = 32;       // left keypoints per workgroup in the per-keypoint form
+constexpr int kStereoMaxRight = 8192;  // right keypoints per pair (LDS table: 8 bytes each)
+constexpr int kStereoOrbDist = (100 + 50) / 2;   // (m_int_highThd + m_int_lowThd) / 2, frame.cpp:365
+
+struct StereoDev {
+  const KeyPointDev* kpsL; const uint8_t* descL; const int* nL;
+  const KeyPointDev* kpsR; const uint8_t* descR; const int* nR;
+  const uint8_t* pyrL[8]; const uint8_t* pyrR[8];   // ROI origin of each level in frame 0 of the extractor's last call
+  long long frameStrideL, frameStrideR;
+  int capL, capR, frameL0, frameLStep, frameR0, frameRStep;
+  int w[8], h[8], pitchL[8], pitchR[8];
+  float scale[8], invScale[8];
+  int nLevels, flags;
+  float bf, maxD;
+  float* rightX; float* depth;
+  int* counters;   // per pair: [0] measurements kept, [1] of those with block-match minimum 0, [2] status bits, [3] unused
+  int* keptOut; int* statusOut;
+};
+
+struct StereoAcc { int kept, zeros, status; };
+
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// One left keypoint k matched with descriptor / written to slot s.  Wave-uniform control flow; returns whether the
+// reference's loop body reaches `leftIdx++` (:462).
+__device__ bool stereo_one(const StereoDev& P, int pair, int k, int s, int nR, const float* __restrict__ rx,
+                           const unsigned* __restrict__ rinfo, int lane, StereoAcc& A) {
+  const KeyPointDev* kl = P.kpsL + (size_t)pair * P.capL;
+  const float kx = kl[k].x, ky = kl[k].y;
+  const int o = kl[k].octave;
+  const int row = (int)ky;
+  if (!(ky >= 0.0f) || row >= P.h[0]) { A.status |= 1; return false; }   // out-of-range row index at :389 (undefined in the reference)
+  const uint8_t* dl = P.descL + ((size_t)pair * P.capL + s) * 32;
+  const uint4 a0 = *reinterpret_cast<const uint4*>(dl), a1 = *reinterpret_cast<const uint4*>(dl + 16);
+  const uint8_t* dr = P.descR + (size_t)pair * P.capR * 32;
+  const float xlo = kx - P.maxD, xhi = kx;   // :395 (minD = 0)
+  unsigned best = 0xFFFFFFFFu;
+  bool any = false;
+  for (int j0 = 0; j0 < nR; j0 += 64) {
+    const int j = j0 + lane;
+    if (j < nR) {
+      const unsigned inf = rinfo[j];
+      const int lo = inf & 0xFFF, hi = (inf >> 12) & 0xFFF, oc = (int)(inf >> 24);
+      if (row >= lo && row <= hi) {
+        any = true;
+        const float x = rx[j];
+        if (oc >= o - 1 && oc <= o + 1 && x >= xlo && x <= xhi) {
+          const uint4 b0 = *reinterpret_cast<const uint4*>(dr + (size_t)j * 32), b1 = *reinterpret_cast<const uint4*>(dr + (size_t)j * 32 + 16);
+          const int d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
+                        __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+          best = min(best, ((unsigned)d << 16) | (unsigned)j);
+        }
+      }
+    }
+  }
+  if (!__any(any) || !(kx >= 0.0f)) return false;   // :389
+  best = wave_min_u32(best);
+  const int bestDist = best == 0xFFFFFFFFu ? 256 : (int)(best >> 16);
+  if (bestDist < kStereoOrbDist) {   // :406
+    const int bestRight = (int)(best & 0xFFFFu);
+    const float inv = P.invScale[o];
+    const int lx = (int)roundf(kx * inv), ly = (int)roundf(ky * inv), rsx = (int)roundf(rx[bestRight] * inv);   // :408-410
+    const int W = P.w[o], H = P.h[o];
+    if (ly - 5 < 0 || ly + 6 >= H || lx - 5 < 0 || lx + 6 >= W) return false;   // :414-416
+    if (rsx < 0 || rsx + 11 >= W) return false;                                  // :424-426
+    if (rsx - 10 < 0) { A.status |= 2; return false; }                           // negative colRange at :427 (cv::Exception in the reference)
+    const int pL = P.pitchL[o], pR = P.pitchR[o];
+    const uint8_t* Lp = P.pyrL[o] + (long long)(P.frameL0 + pair * P.frameLStep) * P.frameStrideL + (long long)ly * pL + lx;
+    const uint8_t* Rp = P.pyrR[o] + (long long)(P.frameR0 + pair * P.frameRStep) * P.frameStrideR + (long long)ly * pR + rsx;
+    int acc[11];
+#pragma unroll
+    for (int i = 0; i < 11; i++) acc[i] = 0;
+    const int lc = Lp[0];
+    for (int t = lane; t < 121; t += 64) {   // 11x11 window, centre-subtracted L1 distance for the 11 shifts (:416-434)
+      const int dy = t / 11 - 5, dx = t % 11 - 5;
+      const int a = (int)Lp[dy * pL + dx] - lc;
+      const uint8_t* rr = Rp + dy * pR + dx;
+#pragma unroll
+      for (int i = 0; i < 11; i++) {
+        const int b = (int)rr[i - 5] - (int)Rp[i - 5];
+        acc[i] += abs(a - b);
+      }
+    }
+    int sadBest = 256, bestCol = 0;   // :419-420: an int minimum that starts at 256
+#pragma unroll
+    for (int i = 0; i < 11; i++) {
+      acc[i] = wave_sum_i32(acc[i]);
+      if (acc[i] < sadBest) { sadBest = acc[i]; bestCol = i - 5; }
+    }
+    if (bestCol == -5 || bestCol == 5) return false;   // :437-439
+    float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 11; i++) {
+      if (i == bestCol + 4) d1 = (float)acc[i];
+      if (i == bestCol + 5) d2 = (float)acc[i];
+      if (i == bestCol + 6) d3 = (float)acc[i];
+    }
+    const float delta = (float)((double)(d1 - d3) / (2.0 * ((double)(d1 + d3) - 2.0 * (double)d2)));   // :441-443
+    if (delta < -1 || delta > 1) return false;                                                           // :444-446
+    float bestRightX = __fmul_rn(P.scale[o], __fadd_rn(__fadd_rn((float)rsx, delta), (float)bestCol));  // :448
+    float disparity = __fsub_rn(kx, bestRightX);
+    if (disparity >= 0.0f && disparity < P.maxD) {
+      if (disparity <= 0) {
+        disparity = 0.01f;
+        bestRightX = (float)((double)kx - 0.01);
+      }
+      if (lane == 0) {
+        P.depth[(size_t)pair * P.capL + s] = __fdiv_rn(P.bf, disparity);   // :455-457
+        P.rightX[(size_t)pair * P.capL + s] = bestRightX;
+      }
+      A.kept++;
+      A.zeros += sadBest == 0;
+    }
+  }
+  return true;
+}
+
+// grid (REPLAY ? 1 : ceil(capL / kStereoChunk), pairs), 256 threads, dynamic LDS = capR * 8 bytes
+template <bool REPLAY>
+__global__ __launch_bounds__(256) void k_stereo(const StereoDev* __restrict__ Pp) {
+  extern __shared__ unsigned char stereoLds[];
+  const StereoDev& P = *Pp;
+  const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nL = min(P.nL[pair], P.capL), nR = min(P.nR[pair], P.capR);
+  float* rx = reinterpret_cast<float*>(stereoLds);
+  unsigned* rinfo = reinterpret_cast<unsigned*>(rx + P.capR);
+  const int k0 = REPLAY ? 0 : blockIdx.x * kStereoChunk, k1 = REPLAY ? P.capL : min(k0 + kStereoChunk, P.capL);
+  for (int i = k0 + tid; i < k1; i += 256) {   // :363-364
+    P.rightX[(size_t)pair * P.capL + i] = -1.0f;
+    P.depth[(size_t)pair * P.capL + i] = -1.0f;
+  }
+  const float lastRow = (float)P.h[0] - 1.0f;
+  for (int j = tid; j < nR; j += 256) {   // row band of each right keypoint, :373-379
+    const KeyPointDev kp = P.kpsR[(size_t)pair * P.capR + j];
+    const float r = 2.0f * P.scale[kp.octave & 7];
+    int lo = (int)fmaxf(floorf(kp.y - r), 0.0f);
+    int hi = (int)fminf(ceilf(kp.y + r), lastRow);
+    if (lo > hi || hi < 0) { lo = 4095; hi = 0; }
+    rx[j] = kp.x;
+    rinfo[j] = (unsigned)lo | ((unsigned)hi << 12) | ((unsigned)kp.octave << 24);
+  }
+  __syncthreads();
+  StereoAcc A{0, 0, 0};
+  if (REPLAY) {
+    if (wave != 0) return;
+    int s = 0;
+    for (int k = 0; k < nL; k++) s += stereo_one(P, pair, k, s, nR, rx, rinfo, lane, A) ? 1 : 0;
+  } else {
+    for (int k = k0 + wave; k < min(k1, nL); k += 4) (void)stereo_one(P, pair, k, k, nR, rx, rinfo, lane, A);
+  }
+  if (lane == 0) {
+    if (A.kept) atomicAdd(&P.counters[pair * 4 + 0], A.kept);
+    if (A.zeros) atomicAdd(&P.counters[pair * 4 + 1], A.zeros);
+    if (A.status) atomicOr(&P.counters[pair * 4 + 2], A.status);
+  }
+}
+
+// :464-472.  The sorted list is walked from its smallest entry and left at the first one below 2.1 x the median, so the
+// loop removes every measurement when the median block-match minimum is 0 and none otherwise.
+__global__ __launch_bounds__(256) void k_stereo_outliers(const StereoDev* __restrict__ Pp) {
+  const StereoDev& P = *Pp;
+  const int pair = blockIdx.x;
+  const int kept = P.counters[pair * 4 + 0], zeros = P.counters[pair * 4 + 1];
+  if (threadIdx.x == 0) {
+    P.keptOut[pair] = kept;
+    P.statusOut[pair] = P.counters[pair * 4 + 2];
+  }
+  if (kept > 0 && zeros >= kept / 2 + 1) {
+    for (int i = threadIdx.x; i < P.capL; i += 256) {
+      const size_t at = (size_t)pair * P.capL + i;
+      if (P.depth[at] > 0.0f) { P.depth[at] = -2.0f; P.rightX[at] = -2.0f; }
+    }
+  }
+}
+
+}  // namespace ydorb

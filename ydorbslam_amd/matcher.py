@@ -145,6 +145,27 @@ class OrbMatcher:
                                                      len(s1), int(stereo_only), int(self.check_orientation), _p(out), C.byref(n)))
         return n.value, out
 
+    def stereo_matches(self, left_ext, right_ext, kps_l, desc_l, n_l, kps_r, desc_r, n_r, bf, b, index_by_keypoint=False,
+                       left_frames=(0, 1), right_frames=(0, 1)):
+        """Frame::computeStereoMatches (frame.cpp:362-477) for a batch of rectified pairs.
+
+        kps_*: [pairs, cap] KP_DTYPE, desc_*: [pairs, cap, 32], n_*: [pairs].  *_frames = (first_frame, frame_step) into the
+        pyramids of the extractors' last call.  Returns (right_x[pairs, cap], depth[pairs, cap], n_kept[pairs], status[pairs])."""
+        from ._lib import YdStereoSide, STEREO_INDEX_BY_KEYPOINT
+        kl = np.ascontiguousarray(kps_l, KP_DTYPE); kr = np.ascontiguousarray(kps_r, KP_DTYPE)
+        dl = np.ascontiguousarray(desc_l, np.uint8); dr = np.ascontiguousarray(desc_r, np.uint8)
+        nl = np.ascontiguousarray(n_l, np.int32); nr = np.ascontiguousarray(n_r, np.int32)
+        pairs, cap_l = kl.shape
+        cap_r = kr.shape[1]
+        assert kr.shape[0] == pairs and dl.shape == (pairs, cap_l, 32) and dr.shape == (pairs, cap_r, 32) and len(nl) == pairs == len(nr)
+        A = YdStereoSide(left_ext._h, left_frames[0], left_frames[1], _p(kl), _p(dl), _p(nl), cap_l, 0)
+        B = YdStereoSide(right_ext._h, right_frames[0], right_frames[1], _p(kr), _p(dr), _p(nr), cap_r, 0)
+        rx = np.zeros((pairs, cap_l), np.float32); depth = np.zeros((pairs, cap_l), np.float32)
+        kept = np.zeros(pairs, np.int32); status = np.zeros(pairs, np.int32)
+        check(self._L.ydorb_stereo_matches(self._h, C.byref(A), C.byref(B), pairs, float(bf), float(b),
+                                           STEREO_INDEX_BY_KEYPOINT if index_by_keypoint else 0, _p(rx), _p(depth), _p(kept), _p(status), None))
+        return rx, depth, kept, status
+
     def match_consecutive_device(self, d_kps, d_desc, d_n, cap, n_frames, width, height, th, scale_factors, d_assigned, d_counts,
                                  d_affine=None, stream=None):
         sf = np.ascontiguousarray(scale_factors, np.float32)

@@ -36,6 +36,23 @@ def synth_frame(w=640, h=480, index=0, n_rects=None, n_blobs=200):
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
 
+def synth_stereo_pair(w=640, h=480, index=0, disparities=(7, 15, 26), noise=1.5):
+    """Rectified pair: the right image is the left one moved left by a per-band disparity (three horizontal bands), plus
+    independent N(0, noise^2) on the right.  Returns (left, right, disparity_of_row[h])."""
+    rng = np.random.default_rng(7000 + index)
+    pad = int(max(disparities)) + 1
+    base = synth_frame(w + pad, h, 300 + index).astype(np.float32)
+    left = base[:, :w]
+    right = np.empty_like(left)
+    drow = np.zeros(h, np.int32)
+    bands = np.linspace(0, h, len(disparities) + 1).astype(int)
+    for b, d in enumerate(disparities):
+        right[bands[b]:bands[b + 1]] = base[bands[b]:bands[b + 1], d:d + w]
+        drow[bands[b]:bands[b + 1]] = d
+    right = right + rng.normal(0, noise, right.shape)
+    return left.astype(np.uint8), np.clip(np.rint(right), 0, 255).astype(np.uint8), drow
+
+
 def synth_batch(w, h, n, start=0):
     return np.stack([synth_frame(w, h, start + i) for i in range(n)])
 
