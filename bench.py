@@ -357,6 +357,32 @@ def main():
                                 "frames_per_launch": NPF, "value": NPF / tp, "unit": "frames/s", "ms_per_launch": tp * 1e3,
                                 "mean_inliers": float(np.mean([r_["inliers"] for r_ in pres]))}
 
+    # ---- stereo association (Frame::computeStereoMatches): a batch of rectified pairs per call ----------------
+    if not args.no_ba and world == 1:
+        from ydorbslam_amd.synth import synth_stereo_pair
+        NSP, SDIST = 64, 8
+        spairs = [synth_stereo_pair(W, H, i) for i in range(SDIST)]
+        sex = y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, max_batch=2 * NSP)
+        sres = sex.extract_batch(np.stack([spairs[p % SDIST][i] for p in range(NSP) for i in (0, 1)]))
+        scap = max(len(k_) for k_, _ in sres)
+        skl = np.zeros((NSP, scap), y.KP_DTYPE); skr = np.zeros((NSP, scap), y.KP_DTYPE)
+        sdl = np.zeros((NSP, scap, 32), np.uint8); sdr = np.zeros((NSP, scap, 32), np.uint8)
+        snl = np.zeros(NSP, np.int32); snr = np.zeros(NSP, np.int32)
+        for p in range(NSP):
+            (ka_, da_), (kb_, db_) = sres[2 * p], sres[2 * p + 1]
+            skl[p, :len(ka_)], sdl[p, :len(ka_)], snl[p] = ka_, da_, len(ka_)
+            skr[p, :len(kb_)], sdr[p, :len(kb_)], snr[p] = kb_, db_, len(kb_)
+        sm = y.OrbMatcher()
+        out["stereo"] = {"metric": "computeStereoMatches pairs/sec (640x480, 1000 features per image, host keypoints in, depth out)",
+                         "pairs_per_call": NSP}
+        for name, by_kp in (("reference_replay", False), ("index_by_keypoint", True)):
+            sm.stereo_matches(sex, sex, skl, sdl, snl, skr, sdr, snr, 40.0, 0.1, by_kp, (0, 2), (1, 2))
+            ts = time.perf_counter()
+            for _ in range(5):
+                sout = sm.stereo_matches(sex, sex, skl, sdl, snl, skr, sdr, snr, 40.0, 0.1, by_kp, (0, 2), (1, 2))
+            ts = (time.perf_counter() - ts) / 5
+            out["stereo"][name] = {"value": NSP / ts, "unit": "pairs/s", "ms_per_call": ts * 1e3, "measurements_per_pair": float(np.mean(sout[2]))}
+
     # ---- CPU baseline: the oracle (port of the reference algorithm), one thread, bounded sample -------------------------
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle.orb_oracle import FrameOracle, OrbExtractorOracle, QUERY_DTYPE, ba_solve
@@ -394,6 +420,20 @@ def main():
                 oracle_pose_optimize(pprobs[i])
             tpc = (time.perf_counter() - tpc) / 32
             out["pose_optimize"]["cpu_baseline"] = {"value": 1.0 / tpc, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "32 of the same frames"}
+            from oracle.orb_oracle import stereo_matches as oracle_stereo
+            oel, oer = OrbExtractorOracle(NFEAT, 1.2, 8, 20, 7), OrbExtractorOracle(NFEAT, 1.2, 8, 20, 7)
+            tsc, nsc = 0.0, 0
+            for p in range(4):
+                kl_, dl_ = oel.extract(spairs[p][0]); kr_, dr_ = oer.extract(spairs[p][1])
+                lvl_ = [oel.level_padded(l)[19:19 + oel.level_dims(l)[1], 19:19 + oel.level_dims(l)[0]] for l in range(8)]
+                lvr_ = [oer.level_padded(l)[19:19 + oer.level_dims(l)[1], 19:19 + oer.level_dims(l)[0]] for l in range(8)]
+                tb_ = oel.tables()
+                for by_kp in (False, True):
+                    t0_ = time.perf_counter()
+                    oracle_stereo(kl_, dl_, kr_, dr_, lvl_, lvr_, tb_["scale"], tb_["inv_scale"], 40.0, 0.1, by_kp)
+                    tsc += time.perf_counter() - t0_; nsc += 1
+            out["stereo"]["cpu_baseline"] = {"value": nsc / tsc, "unit": "pairs/s", "cores": 1, "kind": "port",
+                                             "sample": "4 of the same pairs, both index forms, association only (pyramids and keypoints given)"}
         out["vs_cpu"] = value / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))

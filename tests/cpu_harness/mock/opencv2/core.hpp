@@ -17,7 +17,7 @@ struct _OutputArray;
 struct Mat {
   Mat(); Mat(int, int, int); Mat(const MatExpr&);
   int rows, cols; unsigned char* data; size_t step;
-  int type() const; bool empty() const; size_t total() const;
+  int type() const; bool empty() const; size_t total() const; bool isContinuous() const; Mat clone() const;
   Mat rowRange(int, int) const; Mat colRange(int, int) const; Mat col(int) const; Mat row(int) const; MatExpr t() const;
   Mat operator()(const Rect&) const;
   template <class T> T& at(int); template <class T> const T& at(int) const;
