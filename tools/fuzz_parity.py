@@ -12,7 +12,7 @@ from helpers import bow_nodes, feature_vector, projection_queries
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 t0 = time.time()
-n_ex = n_ma = n_ba = n_po = 0
+n_ex = n_ma = n_ba = n_po = n_st = 0
 while time.time() - t0 < budget:
     # ---- extractor
     w, h = int(rng.integers(60, 1400)), int(rng.integers(60, 800))
@@ -56,6 +56,32 @@ while time.time() - t0 < budget:
                 p = y.OrbMatcher(0.75, True).search_by_bow(m_, ck, cd, va, y.FeatureVector(*fa), kb, db, vb if m_ == 4 else None, y.FeatureVector(*fb))
                 assert p[0] == r[0] and np.array_equal(p[1], r[1]), ("bow", m_)
             n_ma += 1
+    # ---- stereo association on this frame vs a copy moved left by a random disparity (second handle = the right extractor)
+    if len(gk) > 30 and w > 120 and rng.random() < 0.5:
+        dsp = int(rng.integers(0, 40))
+        right = np.clip(np.roll(img, -dsp, 1).astype(np.int16) + rng.integers(-3, 4, img.shape), 0, 255).astype(np.uint8)
+        g2 = y.OrbExtractor(nf, sf, nl, thr, 7); c2 = oo.OrbExtractorOracle(nf, sf, nl, thr, 7)
+        rk, rd = g2.extract(right); ork, ord_ = c2.extract(right)
+        c.extract(img)   # the matcher section left the shifted copy's pyramid in the left oracle
+        assert rk.tobytes() == ork.tobytes()
+        if 0 < len(rk) <= 8192:
+            lk = gk.copy()
+            if rng.random() < 0.3 and len(lk) > 5:   # rows outside the table / negative x
+                lk["y"][int(rng.integers(0, len(lk)))] = float(h) + 0.5
+                lk["x"][int(rng.integers(0, len(lk)))] = -1.0
+            lv_l = [c.level_padded(l)[19:19 + c.level_dims(l)[1], 19:19 + c.level_dims(l)[0]] for l in range(nl)]
+            lv_r = [c2.level_padded(l)[19:19 + c2.level_dims(l)[1], 19:19 + c2.level_dims(l)[0]] for l in range(nl)]
+            tb = c.tables(); bf = float(rng.choice([20.0, 40.0, 386.0])); bl = float(rng.choice([0.05, 0.1, 0.54]))
+            for by_kp in (False, True):
+                o_ = oo.stereo_matches(lk, gd, rk, rd, lv_l, lv_r, tb["scale"], tb["inv_scale"], bf, bl, by_kp)
+                p_ = y.OrbMatcher().stereo_matches(g, g2, lk[None], gd[None], [len(lk)], rk[None], rd[None], [len(rk)], bf, bl, by_kp)
+                if not (p_[2][0] == o_[2] and p_[3][0] == o_[3] and p_[0][0].tobytes() == o_[0].tobytes() and p_[1][0].tobytes() == o_[1].tobytes()):
+                    bad = np.flatnonzero((p_[0][0].view(np.uint32) != o_[0].view(np.uint32)) | (p_[1][0].view(np.uint32) != o_[1].view(np.uint32)))
+                    print("stereo mismatch: kept", p_[2][0], o_[2], "status", p_[3][0], o_[3], "n", len(lk), len(rk), "bad slots", bad[:10], len(bad))
+                    for i in bad[:5]:
+                        print("  slot", i, "gpu", p_[0][0][i], p_[1][0][i], "oracle", o_[0][i], o_[1][i], "kp", lk[i])
+                    raise AssertionError(("stereo", w, h, nf, sf, nl, thr, dsp, by_kp, bf, bl))
+            n_st += 1
     # ---- BA + pose
     if rng.random() < 0.3:
         prob = synth_ba_problem(int(rng.integers(3, 40)), int(rng.integers(30, 1500)), int(rng.integers(2, 8)), seed=int(rng.integers(0, 1 << 30)),
@@ -70,4 +96,4 @@ while time.time() - t0 < budget:
             r_ = oo.pose_optimize(p_)
             assert g_["inliers"] == r_["inliers"] and np.array_equal(g_["outlier"], r_["outlier"]), ("pose", len(p_["info"]))
             n_po += 1
-print("fuzz ok: %d extractor configs, %d matcher scenes, %d BA problems, %d pose problems in %.0f s" % (n_ex, n_ma, n_ba, n_po, time.time() - t0))
+print("fuzz ok: %d extractor configs, %d matcher scenes, %d stereo pairs, %d BA problems, %d pose problems in %.0f s" % (n_ex, n_ma, n_st, n_ba, n_po, time.time() - t0))
