@@ -231,6 +231,13 @@ int ydorb_search_for_triangulation(ydorb_matcher_t* h, const YdTriSide* first, c
                                    int32_t n_levels, int32_t stereo_only, int32_t check_orientation, int32_t* matched_second,
                                    int32_t* n_matches);
 
+/* MapPoint::computeDistinctiveDescriptors(), src/mapPoint.cpp:169-218, for a batch of map points.  Point p's descriptors (the
+ * rows the member function collects at :183-187, in that order) are desc[offsets[p] .. offsets[p+1]); offsets[0] = 0.
+ * best[p] = bestMedianIdx (:203-213): the first descriptor whose sorted distance row has the least entry at (int)(0.5 m);
+ * -1 for a point without descriptors (the reference returns early, :188).  One map point per call is far below launch
+ * latency - hand over all points of a LocalMapping / LoopClosing pass at once. */
+int ydorb_distinctive_descriptors(ydorb_matcher_t* h, const uint8_t* desc, const int32_t* offsets, int32_t n_points, int32_t* best);
+
 /* Frame::computeStereoMatches(), src/frame.cpp:362-477: for every left keypoint the best right descriptor among the right
  * keypoints whose row band covers its row, an 11x11 block match over 11 column shifts at the keypoint's pyramid level,
  * parabola refinement, disparity -> depth, and the final outlier rule.  One call handles n_pairs rectified pairs.

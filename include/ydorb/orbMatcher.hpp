@@ -34,6 +34,24 @@ inline ydorb_matcher_t* matcher(int device = 0) {  // one matcher per calling th
   return m;
 }
 
+// MapPoint::computeDistinctiveDescriptors(), src/mapPoint.cpp:191-213: index of the distinctive descriptor of every map point of
+// a batch.  groups[p] = the rows the member function collects at :183-187 (1 x 32 CV_8U each, in that order); an empty group
+// gives -1.  In src/mapPoint.cpp the member function keeps its gathering (:170-190) and its clone under the mutex (:214-217) and
+// takes bestMedianIdx from distinctiveDescriptorIndices({vDescriptors})[0]; a LocalMapping / LoopClosing pass that refreshes many
+// map points gathers them all and makes ONE call (a single point is far below launch latency).
+inline std::vector<int> distinctiveDescriptorIndices(const std::vector<std::vector<cv::Mat>>& groups, ydorb_matcher_t* m = nullptr) {
+  std::vector<int32_t> offsets(groups.size() + 1, 0);
+  for (size_t p = 0; p < groups.size(); p++) offsets[p + 1] = offsets[p] + (int32_t)groups[p].size();
+  std::vector<uint8_t> desc((size_t)offsets.back() * 32 + 32);
+  size_t at = 0;
+  for (const std::vector<cv::Mat>& g : groups)
+    for (const cv::Mat& row : g) { std::memcpy(desc.data() + at, row.ptr<uint8_t>(), 32); at += 32; }
+  std::vector<int> best(groups.size(), -1);
+  if (!groups.empty() && ydorb_distinctive_descriptors(m ? m : matcher(), desc.data(), offsets.data(), (int32_t)groups.size(), best.data()) != YDORB_OK)
+    throw std::runtime_error(std::string("ydorb: ") + ydorb_last_error());
+  return best;
+}
+
 // static int OrbMatcher::computeDescriptorsDistance(const cv::Mat&, const cv::Mat&), src/orbMatcher.cpp:11-23
 inline int computeDescriptorsDistance(const cv::Mat& a, const cv::Mat& b) { return ydorb_descriptor_distance(a.ptr<uint8_t>(), b.ptr<uint8_t>()); }
 

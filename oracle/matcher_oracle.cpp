@@ -11,6 +11,7 @@
 // PARITY STATUS: no reference test pins any matcher result and the reference cannot be
 // built here (needs OpenCV + DBoW3): "parity unpinned" beyond the line-by-line restatement; M0 is
 // cross-checked against a numpy popcount in tests/test_oracle_matcher.py.
+#include <climits>
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -123,6 +124,32 @@ struct Query {
 extern "C" {
 
 int yo_descriptor_distance(const uint8_t* a, const uint8_t* b) { return descriptorDistance(a, b); }
+
+// MapPoint::computeDistinctiveDescriptors (reference src/mapPoint.cpp:191-213) for one map point: m descriptors in the order the
+// member function collected them (:183-187).  Returns bestMedianIdx (0 when m == 0 never happens: the caller returns early, :188).
+int yo_distinctive_descriptor(const uint8_t* desc, int m) {
+  if (m <= 0) return -1;
+  std::vector<float> distances((size_t)m * m);   // float distances[m][m], :193
+  for (int i = 0; i < m; i++) {
+    distances[(size_t)i * m + i] = 0;
+    for (int j = i + 1; j < m; j++) {
+      const int dij = descriptorDistance(desc + (size_t)i * 32, desc + (size_t)j * 32);
+      distances[(size_t)i * m + j] = (float)dij;
+      distances[(size_t)j * m + i] = (float)dij;
+    }
+  }
+  int bestMedian = INT_MAX, bestMedianIdx = 0;   // :203-213
+  for (int i = 0; i < m; i++) {
+    std::vector<int> v(distances.begin() + (size_t)i * m, distances.begin() + (size_t)(i + 1) * m);
+    std::sort(v.begin(), v.end());
+    const int median = v[(size_t)(0.5 * m)];
+    if (median < bestMedian) {
+      bestMedian = median;
+      bestMedianIdx = i;
+    }
+  }
+  return bestMedianIdx;
+}
 
 void* yo_frame_create(const void* kps, int n, const uint8_t* desc, const float* rightX, float minX, float maxX, float minY,
                       float maxY) {

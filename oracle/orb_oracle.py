@@ -86,6 +86,8 @@ def lib():
         L.yo_ba_chol_solve.restype = C.c_int
         L.yo_ba_chol_solve.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.yo_ba_huber.argtypes = [C.c_double, C.c_double, C.c_void_p]
+        L.yo_distinctive_descriptor.restype = C.c_int
+        L.yo_distinctive_descriptor.argtypes = [C.c_void_p, C.c_int]
         L.yo_stereo_matches.restype = C.c_int
         L.yo_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + \
             [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -367,3 +369,9 @@ def stereo_matches(kps_l, desc_l, kps_r, desc_r, levels_l, levels_r, scale, inv_
                                _p(sl), _p(sr), nlv, _p(sc), _p(isc), float(bf), float(b), 1 if index_by_keypoint else 0, _p(rx), _p(depth),
                                C.byref(st))
     return rx[:len(kl)], depth[:len(kl)], kept, st.value
+
+
+def distinctive_descriptor(desc):
+    """MapPoint::computeDistinctiveDescriptors (mapPoint.cpp:191-213): index of the descriptor with the least median distance."""
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    return lib().yo_distinctive_descriptor(_p(d), len(d))

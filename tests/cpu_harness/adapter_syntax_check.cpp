@@ -57,6 +57,7 @@ int check(Frame& a, Frame& b, std::shared_ptr<KeyFrame> kf, std::shared_ptr<KeyF
   n += ya::searchByBowInTwoKeyFrames(ya::matcher(), kf, kf2, mps, 0.75f, true);
   n += ya::computeDescriptorsDistance(a.m_cvMat_descriptors, b.m_cvMat_descriptors);
   std::vector<std::pair<int, int>> pairs;
+  n += ya::distinctiveDescriptorIndices({{a.m_cvMat_descriptors.row(0), b.m_cvMat_descriptors.row(1)}})[0];
   n += ya::fuseByProjection<std::shared_ptr<KeyFrame>, std::shared_ptr<MapPoint>, Frame>(ya::matcher(), kf, mps, 3.0f);
   n += ya::fuseBySim3<std::shared_ptr<KeyFrame>, std::shared_ptr<MapPoint>, Frame>(ya::matcher(), kf, a.m_cvMat_T_c2w, mps, 4.0f);
   n += ya::searchBySim3<std::shared_ptr<KeyFrame>, std::shared_ptr<MapPoint>, Frame>(ya::matcher(), kf, kf2, mps, 7.5f);

@@ -224,3 +224,17 @@ def test_search_by_projection_in_sim_and_fuse_by_sim3(oracle_lib, scene):
             assert nh_gpu == nh_ref >= nf_ref and np.array_equal(h_gpu, h_ref)
             total += n_ref + nf_ref
     assert total > 50
+
+
+def test_distinctive_descriptors_batch(oracle_lib):
+    """MapPoint::computeDistinctiveDescriptors (mapPoint.cpp:169-218) for a batch of map points, including an empty one."""
+    import ydorbslam_amd as y
+    from test_oracle_matcher import _distinctive_groups
+    groups = []
+    for seed in range(6):
+        groups += _distinctive_groups(seed)
+    groups.insert(5, np.zeros((0, 32), np.uint8))
+    got = y.OrbMatcher().distinctive_descriptors(groups)
+    want = [oracle_lib.distinctive_descriptor(g) if len(g) else -1 for g in groups]
+    assert list(got) == want
+    assert len(y.OrbMatcher().distinctive_descriptors([])) == 0

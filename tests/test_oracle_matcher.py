@@ -209,3 +209,27 @@ def test_fuse_search_matches_brute_force_statement(oracle_lib):
         if bd <= 50:
             exp[i] = bi
     assert np.array_equal(best, exp) and n == (exp >= 0).sum() > 10
+
+
+def _distinctive_groups(seed=0):
+    rng = np.random.default_rng(seed)
+    groups = []
+    for m in [1, 2, 3, 4, 5, 8, 13, 20, 20, 33, 64, 65, 130]:
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        g = np.repeat(base[None], m, 0)
+        flips = rng.random((m, 256)) < rng.uniform(0.02, 0.3)
+        g = np.packbits(np.unpackbits(g, axis=1) ^ flips.astype(np.uint8), axis=1)
+        if m >= 4 and seed % 2 == 0:
+            g[m // 2] = g[0]      # duplicated rows: equal medians, the first row must win
+        groups.append(g)
+    return groups
+
+
+def test_distinctive_descriptor_numpy_statement(oracle_lib):
+    """mapPoint.cpp:191-213: least median of the sorted distance rows, median = sorted[(int)(0.5 m)], first winner kept."""
+    for seed in range(4):
+        for g in _distinctive_groups(seed):
+            m = len(g)
+            d = np.unpackbits(g[:, None, :] ^ g[None, :, :], axis=2).sum(axis=2)
+            med = np.sort(d, axis=1)[:, int(0.5 * m)]
+            assert oracle_lib.distinctive_descriptor(g) == int(np.argmin(med)), (seed, m)

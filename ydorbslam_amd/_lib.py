@@ -62,6 +62,7 @@ SYMBOLS = {
     "ydorb_fuse_search": (C.c_int, [_VP, _VP, _VP, _VP, _I, _VP, _I, _VP, C.POINTER(_I)]),
     "ydorb_window_search": (C.c_int, [_VP, _VP, _VP, _VP, _I, _VP, _I, _I, _VP, C.POINTER(_I)]),
     "ydorb_search_for_triangulation": (C.c_int, [_VP, _VP, _VP, _VP, C.c_float, C.c_float, _VP, _VP, _I, _I, _I, _VP, C.POINTER(_I)]),
+    "ydorb_distinctive_descriptors": (C.c_int, [_VP, _VP, _VP, _I, _VP]),
     "ydorb_stereo_matches": (C.c_int, [_VP, _VP, _VP, _I, C.c_float, C.c_float, _I, _VP, _VP, _VP, _VP, _VP]),
     "ydorb_match_consecutive_device": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, C.c_float, _VP, _I, _VP, _I, _VP, _VP, _VP]),
     "ydorb_matcher_synchronize": (C.c_int, [_VP]),

@@ -329,6 +329,45 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// MapPoint::computeDistinctiveDescriptors (reference src/mapPoint.cpp:191-213), a batch of map points: one wave per point.
+// Lane = descriptor row i (rows beyond 64 in further rounds).  The median the reference takes after sorting a row of the
+// distance matrix, v[(int)(0.5 m)], is the smallest t with #{j : d(i,j) <= t} > (int)(0.5 m): nine bisection steps over
+// t in [0, 256], each a pass over the other rows — whose addresses are wave-uniform, so they arrive as scalar loads.  The
+// winner is the first row with the least median: wave-min of (median << 16 | row).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_distinctive(const uint8_t* __restrict__ desc, const int* __restrict__ offsets, int nPoints,
+                                                     int* __restrict__ best) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (p >= nPoints) return;
+  const int o0 = __builtin_amdgcn_readfirstlane(offsets[p]), m = __builtin_amdgcn_readfirstlane(offsets[p + 1]) - o0;
+  if (m <= 0) { if (lane == 0) best[p] = -1; return; }
+  const uint8_t* D = desc + (size_t)o0 * 32;
+  const int kth = (int)(0.5 * m);
+  unsigned win = 0xFFFFFFFFu;
+  for (int i0 = 0; i0 < m; i0 += 64) {
+    const int i = i0 + lane;
+    if (i < m) {
+      const uint4 a0 = *reinterpret_cast<const uint4*>(D + (size_t)i * 32), a1 = *reinterpret_cast<const uint4*>(D + (size_t)i * 32 + 16);
+      int lo = 0, hi = 256;   // smallest t with count(d <= t) > kth
+      while (lo < hi) {
+        const int t = (lo + hi) >> 1;
+        int cnt = 0;
+        for (int j = 0; j < m; j++) {
+          const uint4 b0 = *reinterpret_cast<const uint4*>(D + (size_t)j * 32), b1 = *reinterpret_cast<const uint4*>(D + (size_t)j * 32 + 16);
+          const int d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
+                        __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+          cnt += d <= t;
+        }
+        if (cnt > kth) hi = t; else lo = t + 1;
+      }
+      win = min(win, ((unsigned)lo << 16) | (unsigned)min(i, 65535));
+    }
+  }
+  win = wave_min_u32(win);
+  if (lane == 0) best[p] = (int)(win & 0xFFFFu);
+}
+
 constexpr int kResolveWindow = 2048;  // queries whose (base,count) are staged in LDS at a time
 
 __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ calls, const FrameDev* __restrict__ frames,

@@ -190,6 +190,29 @@ int ydorb_descriptor_distance_rows(ydorb_matcher_t* m, const uint8_t* a, const u
   return YDORB_OK;
 }
 
+int ydorb_distinctive_descriptors(ydorb_matcher_t* m, const uint8_t* desc, const int32_t* offsets, int32_t nPoints, int32_t* best) {
+  if (!m || !offsets || !best || nPoints < 0) { set_error("invalid argument"); return YDORB_ERR_INVALID_ARG; }
+  if (nPoints == 0) return YDORB_OK;
+  const int total = offsets[nPoints];
+  if (offsets[0] != 0 || total < 0 || (total > 0 && !desc)) { set_error("invalid offsets"); return YDORB_ERR_INVALID_ARG; }
+  for (int p = 0; p < nPoints; p++) {
+    const int cnt = offsets[p + 1] - offsets[p];
+    if (cnt < 0 || cnt > 65535) { set_error("map point %d holds %d descriptors (0..65535 supported)", p, cnt); return YDORB_ERR_INVALID_ARG; }
+  }
+  HIPCHK(hipSetDevice(m->device));
+  int rc;
+  if ((rc = m->desc.ensure((size_t)32 * std::max(total, 1))) || (rc = m->qRange.ensure(sizeof(int) * (nPoints + 1))) ||
+      (rc = m->assigned.ensure(sizeof(int) * nPoints)))
+    return rc;
+  if (total) HIPCHK(hipMemcpyAsync(m->desc.p, desc, (size_t)32 * total, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(m->qRange.p, offsets, sizeof(int) * (nPoints + 1), hipMemcpyHostToDevice, m->stream));
+  hipLaunchKernelGGL(k_distinctive, dim3((nPoints + 3) / 4), dim3(256), 0, m->stream, m->desc.as<uint8_t>(), m->qRange.as<int>(), nPoints, m->assigned.as<int>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(best, m->assigned.p, sizeof(int) * nPoints, hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  return YDORB_OK;
+}
+
 static int searchProjectionImpl(ydorb_matcher_t* m, int32_t mode, const YdFrameView* fv, const YdQuery* queries, const uint8_t* qdesc,
                                 int32_t nq, float ratio, int32_t orbDist, int32_t checkOri, uint8_t* taken, int32_t* assigned,
                                 int32_t* nMatches, std::vector<uint32_t>* recordsOut, const float* invSigma2 = nullptr, int nLevels = 0,

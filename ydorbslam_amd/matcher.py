@@ -145,6 +145,16 @@ class OrbMatcher:
                                                      len(s1), int(stereo_only), int(self.check_orientation), _p(out), C.byref(n)))
         return n.value, out
 
+    def distinctive_descriptors(self, groups):
+        """MapPoint::computeDistinctiveDescriptors (mapPoint.cpp:169-218) for a list of [m_i, 32] uint8 arrays -> best index per group."""
+        groups = [np.ascontiguousarray(g, np.uint8).reshape(-1, 32) for g in groups]
+        offsets = np.zeros(len(groups) + 1, np.int32)
+        offsets[1:] = np.cumsum([len(g) for g in groups])
+        desc = np.concatenate(groups) if offsets[-1] else np.zeros((1, 32), np.uint8)
+        best = np.zeros(max(len(groups), 1), np.int32)
+        check(self._L.ydorb_distinctive_descriptors(self._h, _p(desc), _p(offsets), len(groups), _p(best)))
+        return best[:len(groups)]
+
     def stereo_matches(self, left_ext, right_ext, kps_l, desc_l, n_l, kps_r, desc_r, n_r, bf, b, index_by_keypoint=False,
                        left_frames=(0, 1), right_frames=(0, 1)):
         """Frame::computeStereoMatches (frame.cpp:362-477) for a batch of rectified pairs.
