@@ -115,3 +115,26 @@ def test_argument_checks():
         m.stereo_matches(ex, ex, k, d, [0], k, d, [0], BF, B, right_frames=(1, 1))
     rx, depth, kept, status = m.stereo_matches(ex, ex, k, d, [0], k, d, [0], BF, B)
     assert kept[0] == 0 and np.all(rx == -1) and np.all(depth == -1)
+
+
+@pytest.mark.parametrize("w,h,nf", [(1241, 376, 2000), (752, 480, 1000)])
+def test_baseline_stereo_configurations(oracle_lib, w, h, nf):
+    """BASELINE.json configs 3 and 4 (KITTI-00-size and EuRoC-MH-size stereo): extraction of both images and the stereo
+    association, bit-exact against the oracle in both index forms."""
+    import ydorbslam_amd as y
+    left, right, drow = synth_stereo_pair(w, h, 11)
+    ex = y.OrbExtractor(nf, 1.2, 8, 20, 7, max_batch=2)
+    (kl, dl), (kr, dr) = ex.extract_batch(np.stack([left, right]))
+    m = y.OrbMatcher()
+    for by_kp in (False, True):
+        rx, depth, kept, status = m.stereo_matches(ex, ex, kl[None], dl[None], [len(kl)], kr[None], dr[None], [len(kr)], BF, B,
+                                                   index_by_keypoint=by_kp, left_frames=(0, 1), right_frames=(1, 1))
+        (okl, odl, okr, odr), (orx, odepth, okept, ostatus) = _oracle_pair(oracle_lib, left, right, nf, by_kp=by_kp)
+        assert okl.tobytes() == kl.tobytes() and okr.tobytes() == kr.tobytes() and np.array_equal(odl, dl) and np.array_equal(odr, dr)
+        assert kept[0] == okept and status[0] == ostatus == 0
+        assert np.array_equal(rx[0].view(np.uint32), orx.view(np.uint32)) and np.array_equal(depth[0].view(np.uint32), odepth.view(np.uint32))
+        if by_kp:
+            ok = depth[0] > 0
+            assert ok.sum() > 0.3 * len(kl)
+            disp = kl["x"][ok] - rx[0][ok]
+            assert np.mean(np.abs(disp - drow[kl["y"][ok].astype(int)]) < 1.5 * 1.2 ** kl["octave"][ok]) > 0.9
