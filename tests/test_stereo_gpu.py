@@ -138,3 +138,28 @@ def test_baseline_stereo_configurations(oracle_lib, w, h, nf):
             assert ok.sum() > 0.3 * len(kl)
             disp = kl["x"][ok] - rx[0][ok]
             assert np.mean(np.abs(disp - drow[kl["y"][ok].astype(int)]) < 1.5 * 1.2 ** kl["octave"][ok]) > 0.9
+
+
+def test_index_chain_that_depends_on_the_descriptor_history(oracle_lib):
+    """Every other left descriptor is noise and a third are copies of one right descriptor, so whether a keypoint reaches
+    `leftIdx++` depends on which descriptor the lagging index hands it."""
+    import ydorbslam_amd as y
+    nf = 700
+    rng = np.random.default_rng(3)
+    pairs = []
+    for p in range(2):
+        left, right, _ = synth_stereo_pair(640, 480, 20 + p, disparities=(9, 9, 9))
+        pairs.append((left, right))
+    ex = y.OrbExtractor(nf, 1.2, 8, 20, 7, max_batch=4)
+    res = ex.extract_batch(np.stack([im for pr in pairs for im in pr]))
+    m = y.OrbMatcher()
+    for p, (left, right) in enumerate(pairs):
+        (kl, dl), (kr, dr) = res[2 * p], res[2 * p + 1]
+        dl = dl.copy()
+        dl[1::2] = rng.integers(0, 256, dl[1::2].shape, dtype=np.uint8)
+        dl[::3] = dr[len(dr) // 2]
+        _, (orx, odepth, okept, ostatus) = _oracle_pair(oracle_lib, left, right, nf, dl=dl)
+        rx, depth, kept, status = m.stereo_matches(ex, ex, kl[None], dl[None], [len(kl)], kr[None], dr[None], [len(kr)], BF, B,
+                                                   left_frames=(2 * p, 1), right_frames=(2 * p + 1, 1))
+        assert kept[0] == okept and status[0] == ostatus
+        assert np.array_equal(rx[0].view(np.uint32), orx.view(np.uint32)) and np.array_equal(depth[0].view(np.uint32), odepth.view(np.uint32))

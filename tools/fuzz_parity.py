@@ -72,6 +72,8 @@ while time.time() - t0 < budget:
             lv_l = [c.level_padded(l)[19:19 + c.level_dims(l)[1], 19:19 + c.level_dims(l)[0]] for l in range(nl)]
             lv_r = [c2.level_padded(l)[19:19 + c2.level_dims(l)[1], 19:19 + c2.level_dims(l)[0]] for l in range(nl)]
             tb = c.tables(); bf = float(rng.choice([20.0, 40.0, 386.0])); bl = float(rng.choice([0.05, 0.1, 0.54]))
+            if rng.random() < 0.3:   # descriptor-dependent index chains
+                gd = gd.copy(); gd[1::2] = rng.integers(0, 256, gd[1::2].shape, dtype=np.uint8)
             for by_kp in (False, True):
                 o_ = oo.stereo_matches(lk, gd, rk, rd, lv_l, lv_r, tb["scale"], tb["inv_scale"], bf, bl, by_kp)
                 p_ = y.OrbMatcher().stereo_matches(g, g2, lk[None], gd[None], [len(lk)], rk[None], rd[None], [len(rk)], bf, bl, by_kp)

@@ -571,14 +571,18 @@ int ydorb_stereo_matches(ydorb_matcher_t* m, const YdStereoSide* L, const YdSter
   P.counters = m->stereoCnt.as<int>(); P.keptOut = m->stereoOut.as<int>(); P.statusOut = m->stereoOut.as<int>() + nPairs;
   HIPCHK(hipMemcpyAsync(m->stereoPar.p, &P, sizeof(P), hipMemcpyHostToDevice, s));
   HIPCHK(hipMemsetAsync(m->stereoCnt.p, 0, sizeof(int) * 4 * nPairs, s));
+  HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(P.rightX), 0xBF800000u, nl, s));   // -1.0f, :363-364
+  HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(P.depth), 0xBF800000u, nl, s));
   const size_t lds = (size_t)R->cap * 8;
-  if (flags & YDORB_STEREO_INDEX_BY_KEYPOINT) {
-    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stereo<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_stereo<false>, dim3((L->cap + kStereoChunk - 1) / kStereoChunk, nPairs), dim3(256), lds, s, m->stereoPar.as<StereoDev>());
-  } else {
-    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stereo<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_stereo<true>, dim3(1, nPairs), dim3(256), lds, s, m->stereoPar.as<StereoDev>());
+  const StereoDev* dP = m->stereoPar.as<StereoDev>();
+  if (lds > 48 * 1024) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stereo<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stereo<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
+  if (flags & YDORB_STEREO_INDEX_BY_KEYPOINT)
+    hipLaunchKernelGGL(k_stereo<false>, dim3((L->cap + kStereoChunk - 1) / kStereoChunk, nPairs), dim3(256), lds, s, dP);
+  else
+    hipLaunchKernelGGL(k_stereo<true>, dim3(1, nPairs), dim3(256), lds, s, dP);
   hipLaunchKernelGGL(k_stereo_outliers, dim3(nPairs), dim3(256), 0, s, m->stereoPar.as<StereoDev>());
   HIPCHK(hipGetLastError());
   if (dev) {

@@ -6,8 +6,12 @@
 // block-match minima (:464-472).
 //
 // The reference indexes the left descriptor and the output slot with a counter that only advances when a keypoint reaches
-// the end of the loop body (:462), which makes the result a serial chain over the keypoints.  k_stereo<true> replays that
-// chain exactly (one wave per pair walks the keypoints, the 64 lanes share each keypoint's candidate scan and block match);
+// the end of the loop body (:462), which makes the result a serial chain over the keypoints: s(k+1) = s(k) + c(k, s(k)), where
+// c says whether keypoint k, matched with descriptor s(k), reaches `leftIdx++`.  k_stereo<true> replays that chain exactly: one
+// wave per pair walks the keypoints, the 64 lanes share each keypoint's candidate scan and block match, and the loads a step
+// depends on (the next keypoint, the descriptor rows s and s + 1) are issued one step ahead.  (Solving the chain as a fixed
+// point of parallel evaluation rounds was measured and dropped: with a lagging index ~3 % of the evaluations still end in a
+// `continue`, each depending on s, so the settled prefix grows by only 10-50 keypoints per round - DESIGN.md.)
 // k_stereo<false> is the per-keypoint form (descriptor and slot = the keypoint's own index, YDORB_STEREO_INDEX_BY_KEYPOINT)
 // with one wave per keypoint.  Everything else is the same device function, restated in oracle/stereo_oracle.cpp.
 //
@@ -41,6 +45,7 @@ struct StereoDev {
 };
 
 struct StereoAcc { int kept, zeros, status; };
+struct StereoRes { bool complete, kept, zero; int status; float rx, depth; };
 
 __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll
@@ -48,39 +53,64 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
   return v;
 }
 
-// One left keypoint k matched with descriptor / written to slot s.  Wave-uniform control flow; returns whether the
-// reference's loop body reaches `leftIdx++` (:462).
-__device__ bool stereo_one(const StereoDev& P, int pair, int k, int s, int nR, const float* __restrict__ rx,
-                           const unsigned* __restrict__ rinfo, int lane, StereoAcc& A) {
-  const KeyPointDev* kl = P.kpsL + (size_t)pair * P.capL;
-  const float kx = kl[k].x, ky = kl[k].y;
-  const int o = kl[k].octave;
+// One left keypoint (kx, ky, octave o) matched with the left descriptor row (a0, a1).  Wave-uniform control flow; `complete`
+// says whether the reference's loop body reaches `leftIdx++` (:462).
+__device__ StereoRes stereo_one(const StereoDev& P, int pair, float kx, float ky, int o, uint4 a0, uint4 a1, int nR,
+                                const float* __restrict__ rx, const unsigned* __restrict__ rinfo, unsigned short* cand, int lane) {
+  StereoRes Rz{false, false, false, 0, -1.0f, -1.0f};
   const int row = (int)ky;
-  if (!(ky >= 0.0f) || row >= P.h[0]) { A.status |= 1; return false; }   // out-of-range row index at :389 (undefined in the reference)
-  const uint8_t* dl = P.descL + ((size_t)pair * P.capL + s) * 32;
-  const uint4 a0 = *reinterpret_cast<const uint4*>(dl), a1 = *reinterpret_cast<const uint4*>(dl + 16);
+  if (!(ky >= 0.0f) || row >= P.h[0]) { Rz.status = 1; return Rz; }   // out-of-range row index at :389 (undefined in the reference)
   const uint8_t* dr = P.descR + (size_t)pair * P.capR * 32;
   const float xlo = kx - P.maxD, xhi = kx;   // :395 (minD = 0)
   unsigned best = 0xFFFFFFFFu;
   bool any = false;
-  for (int j0 = 0; j0 < nR; j0 += 64) {
-    const int j = j0 + lane;
-    if (j < nR) {
-      const unsigned inf = rinfo[j];
-      const int lo = inf & 0xFFF, hi = (inf >> 12) & 0xFFF, oc = (int)(inf >> 24);
-      if (row >= lo && row <= hi) {
-        any = true;
-        const float x = rx[j];
-        if (oc >= o - 1 && oc <= o + 1 && x >= xlo && x <= xhi) {
-          const uint4 b0 = *reinterpret_cast<const uint4*>(dr + (size_t)j * 32), b1 = *reinterpret_cast<const uint4*>(dr + (size_t)j * 32 + 16);
-          const int d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
-                        __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
-          best = min(best, ((unsigned)d << 16) | (unsigned)j);
+  // Two phases so that the descriptor rows of all candidates are in flight together: the scan (LDS only) compacts the indices
+  // that pass the static tests into the wave's list, then lane i takes candidate i.  A full list (64) is drained in between.
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int cnt = 0;
+  auto drain = [&](int n) {
+    if (lane < n) {
+      const int j = cand[lane];
+      const uint4 b0 = *reinterpret_cast<const uint4*>(dr + (size_t)j * 32), b1 = *reinterpret_cast<const uint4*>(dr + (size_t)j * 32 + 16);
+      const int d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
+                    __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+      best = min(best, ((unsigned)d << 16) | (unsigned)j);
+    }
+  };
+  for (int j0 = 0; j0 < nR; j0 += 256) {   // four table rows per lane and trip: their LDS reads are in flight together
+    unsigned inf[4];
+    float x[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = min(j0 + 64 * u + lane, nR - 1);
+      inf[u] = rinfo[j];
+      x[u] = rx[j];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = j0 + 64 * u + lane;
+      const int lo = inf[u] & 0xFFF, hi = (inf[u] >> 12) & 0xFFF, oc = (int)(inf[u] >> 24);
+      const bool inRow = j < nR && row >= lo && row <= hi;
+      any |= inRow;
+      const bool pass = inRow && oc >= o - 1 && oc <= o + 1 && x[u] >= xlo && x[u] <= xhi;
+      const unsigned long long m = __ballot(pass);
+      if (m) {
+        if (pass) cand[cnt + __popcll(m & below)] = (unsigned short)j;
+        cnt += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (cnt >= 64) {
+          drain(64);
+          const unsigned short keep = cand[64 + lane];
+          __builtin_amdgcn_wave_barrier();
+          cand[lane] = keep;
+          __builtin_amdgcn_wave_barrier();
+          cnt -= 64;
         }
       }
     }
   }
-  if (!__any(any) || !(kx >= 0.0f)) return false;   // :389
+  drain(cnt);
+  if (!__any(any) || !(kx >= 0.0f)) return Rz;   // :389
   best = wave_min_u32(best);
   const int bestDist = best == 0xFFFFFFFFu ? 256 : (int)(best >> 16);
   if (bestDist < kStereoOrbDist) {   // :406
@@ -88,9 +118,9 @@ __device__ bool stereo_one(const StereoDev& P, int pair, int k, int s, int nR, c
     const float inv = P.invScale[o];
     const int lx = (int)roundf(kx * inv), ly = (int)roundf(ky * inv), rsx = (int)roundf(rx[bestRight] * inv);   // :408-410
     const int W = P.w[o], H = P.h[o];
-    if (ly - 5 < 0 || ly + 6 >= H || lx - 5 < 0 || lx + 6 >= W) return false;   // :414-416
-    if (rsx < 0 || rsx + 11 >= W) return false;                                  // :424-426
-    if (rsx - 10 < 0) { A.status |= 2; return false; }                           // negative colRange at :427 (cv::Exception in the reference)
+    if (ly - 5 < 0 || ly + 6 >= H || lx - 5 < 0 || lx + 6 >= W) return Rz;   // :414-416
+    if (rsx < 0 || rsx + 11 >= W) return Rz;                                  // :424-426
+    if (rsx - 10 < 0) { Rz.status = 2; return Rz; }                           // negative colRange at :427 (cv::Exception in the reference)
     const int pL = P.pitchL[o], pR = P.pitchR[o];
     const uint8_t* Lp = P.pyrL[o] + (long long)(P.frameL0 + pair * P.frameLStep) * P.frameStrideL + (long long)ly * pL + lx;
     const uint8_t* Rp = P.pyrR[o] + (long long)(P.frameR0 + pair * P.frameRStep) * P.frameStrideR + (long long)ly * pR + rsx;
@@ -114,7 +144,7 @@ __device__ bool stereo_one(const StereoDev& P, int pair, int k, int s, int nR, c
       acc[i] = wave_sum_i32(acc[i]);
       if (acc[i] < sadBest) { sadBest = acc[i]; bestCol = i - 5; }
     }
-    if (bestCol == -5 || bestCol == 5) return false;   // :437-439
+    if (bestCol == -5 || bestCol == 5) return Rz;   // :437-439
     float d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
     for (int i = 0; i < 11; i++) {
@@ -123,7 +153,7 @@ __device__ bool stereo_one(const StereoDev& P, int pair, int k, int s, int nR, c
       if (i == bestCol + 6) d3 = (float)acc[i];
     }
     const float delta = (float)((double)(d1 - d3) / (2.0 * ((double)(d1 + d3) - 2.0 * (double)d2)));   // :441-443
-    if (delta < -1 || delta > 1) return false;                                                           // :444-446
+    if (delta < -1 || delta > 1) return Rz;                                                           // :444-446
     float bestRightX = __fmul_rn(P.scale[o], __fadd_rn(__fadd_rn((float)rsx, delta), (float)bestCol));  // :448
     float disparity = __fsub_rn(kx, bestRightX);
     if (disparity >= 0.0f && disparity < P.maxD) {
@@ -131,33 +161,20 @@ __device__ bool stereo_one(const StereoDev& P, int pair, int k, int s, int nR, c
         disparity = 0.01f;
         bestRightX = (float)((double)kx - 0.01);
       }
-      if (lane == 0) {
-        P.depth[(size_t)pair * P.capL + s] = __fdiv_rn(P.bf, disparity);   // :455-457
-        P.rightX[(size_t)pair * P.capL + s] = bestRightX;
-      }
-      A.kept++;
-      A.zeros += sadBest == 0;
+      Rz.kept = true;
+      Rz.zero = sadBest == 0;
+      Rz.depth = __fdiv_rn(P.bf, disparity);   // :455-457
+      Rz.rx = bestRightX;
     }
   }
-  return true;
+  Rz.complete = true;
+  return Rz;
 }
 
-// grid (REPLAY ? 1 : ceil(capL / kStereoChunk), pairs), 256 threads, dynamic LDS = capR * 8 bytes
-template <bool REPLAY>
-__global__ __launch_bounds__(256) void k_stereo(const StereoDev* __restrict__ Pp) {
-  extern __shared__ unsigned char stereoLds[];
-  const StereoDev& P = *Pp;
-  const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nL = min(P.nL[pair], P.capL), nR = min(P.nR[pair], P.capR);
-  float* rx = reinterpret_cast<float*>(stereoLds);
-  unsigned* rinfo = reinterpret_cast<unsigned*>(rx + P.capR);
-  const int k0 = REPLAY ? 0 : blockIdx.x * kStereoChunk, k1 = REPLAY ? P.capL : min(k0 + kStereoChunk, P.capL);
-  for (int i = k0 + tid; i < k1; i += 256) {   // :363-364
-    P.rightX[(size_t)pair * P.capL + i] = -1.0f;
-    P.depth[(size_t)pair * P.capL + i] = -1.0f;
-  }
+// row band of each right keypoint (:373-379) as an LDS record; all threads of the workgroup, ends with a barrier
+__device__ __forceinline__ void stereo_right_table(const StereoDev& P, int pair, int nR, float* rx, unsigned* rinfo) {
   const float lastRow = (float)P.h[0] - 1.0f;
-  for (int j = tid; j < nR; j += 256) {   // row band of each right keypoint, :373-379
+  for (int j = threadIdx.x; j < nR; j += blockDim.x) {
     const KeyPointDev kp = P.kpsR[(size_t)pair * P.capR + j];
     const float r = 2.0f * P.scale[kp.octave & 7];
     int lo = (int)fmaxf(floorf(kp.y - r), 0.0f);
@@ -167,13 +184,51 @@ __global__ __launch_bounds__(256) void k_stereo(const StereoDev* __restrict__ Pp
     rinfo[j] = (unsigned)lo | ((unsigned)hi << 12) | ((unsigned)kp.octave << 24);
   }
   __syncthreads();
+}
+
+// grid (REPLAY ? 1 : ceil(capL / kStereoChunk), pairs), 256 threads, dynamic LDS = capR * 8 bytes.  Outputs were set to -1
+// (:363-364) by the host's fill.
+template <bool REPLAY>
+__global__ __launch_bounds__(256) void k_stereo(const StereoDev* __restrict__ Pp) {
+  extern __shared__ unsigned char stereoLds[];
+  __shared__ unsigned short candList[4][128];   // per wave: indices of the right keypoints that passed the static tests
+  const StereoDev& P = *Pp;
+  const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nL = min(P.nL[pair], P.capL), nR = min(P.nR[pair], P.capR);
+  float* rx = reinterpret_cast<float*>(stereoLds);
+  unsigned* rinfo = reinterpret_cast<unsigned*>(rx + P.capR);
+  const int k0 = REPLAY ? 0 : blockIdx.x * kStereoChunk, k1 = REPLAY ? P.capL : min(k0 + kStereoChunk, P.capL);
+  if (!REPLAY && k0 >= nL) return;
+  stereo_right_table(P, pair, nR, rx, rinfo);
   StereoAcc A{0, 0, 0};
+  const KeyPointDev* kl = P.kpsL + (size_t)pair * P.capL;
+  const uint4* dl = reinterpret_cast<const uint4*>(P.descL + (size_t)pair * P.capL * 32);
+  float* outRx = P.rightX + (size_t)pair * P.capL;
+  float* outDepth = P.depth + (size_t)pair * P.capL;
   if (REPLAY) {
-    if (wave != 0) return;
+    if (wave != 0 || nL == 0) return;
     int s = 0;
-    for (int k = 0; k < nL; k++) s += stereo_one(P, pair, k, s, nR, rx, rinfo, lane, A) ? 1 : 0;
+    // one step ahead: keypoint k + 1 and descriptor row s + 1 (the row the next step needs is s or s + 1)
+    float kx = kl[0].x, ky = kl[0].y;
+    int o = kl[0].octave;
+    uint4 a0 = dl[0], a1 = dl[1];
+    for (int k = 0; k < nL; k++) {
+      const int kn = min(k + 1, nL - 1), sn = min(s + 1, nL - 1);
+      const float nkx = kl[kn].x, nky = kl[kn].y;
+      const int no = kl[kn].octave;
+      const uint4 n0 = dl[2 * sn], n1 = dl[2 * sn + 1];
+      const StereoRes r = stereo_one(P, pair, kx, ky, o, a0, a1, nR, rx, rinfo, candList[wave], lane);
+      if (r.kept && lane == 0) { outRx[s] = r.rx; outDepth[s] = r.depth; }
+      A.kept += r.kept; A.zeros += r.zero; A.status |= r.status;
+      if (r.complete) { s++; a0 = n0; a1 = n1; }
+      kx = nkx; ky = nky; o = no;
+    }
   } else {
-    for (int k = k0 + wave; k < min(k1, nL); k += 4) (void)stereo_one(P, pair, k, k, nR, rx, rinfo, lane, A);
+    for (int k = k0 + wave; k < min(k1, nL); k += 4) {
+      const StereoRes r = stereo_one(P, pair, kl[k].x, kl[k].y, kl[k].octave, dl[2 * k], dl[2 * k + 1], nR, rx, rinfo, candList[wave], lane);
+      if (r.kept && lane == 0) { outRx[k] = r.rx; outDepth[k] = r.depth; }
+      A.kept += r.kept; A.zeros += r.zero; A.status |= r.status;
+    }
   }
   if (lane == 0) {
     if (A.kept) atomicAdd(&P.counters[pair * 4 + 0], A.kept);
