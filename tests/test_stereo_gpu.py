@@ -163,3 +163,41 @@ def test_index_chain_that_depends_on_the_descriptor_history(oracle_lib):
                                                    left_frames=(2 * p, 1), right_frames=(2 * p + 1, 1))
         assert kept[0] == okept and status[0] == ostatus
         assert np.array_equal(rx[0].view(np.uint32), orx.view(np.uint32)) and np.array_equal(depth[0].view(np.uint32), odepth.view(np.uint32))
+
+
+def test_device_resident_form_equals_the_host_form():
+    """extract_batch_device -> stereo with YDORB_STEREO_DEVICE_POINTERS: nothing leaves HBM between the two calls."""
+    import torch
+    import ydorbslam_amd as y
+    pairs, W, H, nf = 3, 640, 480, 800
+    imgs = np.stack([im for p in range(pairs) for im in synth_stereo_pair(W, H, 30 + p)[:2]])
+    ex = y.OrbExtractor(nf, max_batch=2 * pairs)
+    cap = ex.max_keypoints
+    dev = torch.device("cuda:0")
+    d_img = torch.from_numpy(imgs).to(dev)
+    d_kps = torch.zeros((2 * pairs, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((2 * pairs, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(2 * pairs, dtype=torch.int32, device=dev)
+    ex.extract_batch_device(d_img.data_ptr(), W, H, W, W * H, 2 * pairs, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr())
+    ex.synchronize()
+    # de-interleave on the device: the stereo call takes [pairs][cap] arrays per side
+    kl, kr = d_kps[0::2].contiguous(), d_kps[1::2].contiguous()
+    dl, dr = d_desc[0::2].contiguous(), d_desc[1::2].contiguous()
+    nl, nr = d_n[0::2].contiguous(), d_n[1::2].contiguous()
+    torch.cuda.synchronize()
+    m = y.OrbMatcher()
+    to_kp = lambda t: t.cpu().numpy().view(np.uint8).reshape(pairs, cap, 28).view(y.KP_DTYPE).reshape(pairs, cap)
+    for by_kp in (False, True):
+        d_rx = torch.zeros((pairs, cap), dtype=torch.float32, device=dev)
+        d_depth = torch.zeros((pairs, cap), dtype=torch.float32, device=dev)
+        d_kept = torch.zeros(pairs, dtype=torch.int32, device=dev)
+        d_status = torch.full((pairs,), 7, dtype=torch.int32, device=dev)
+        m.stereo_matches_device(ex, ex, kl.data_ptr(), dl.data_ptr(), nl.data_ptr(), cap, kr.data_ptr(), dr.data_ptr(), nr.data_ptr(), cap, pairs, BF, B,
+                                d_rx.data_ptr(), d_depth.data_ptr(), d_kept.data_ptr(), d_status.data_ptr(), index_by_keypoint=by_kp,
+                                left_frames=(0, 2), right_frames=(1, 2))
+        m.synchronize()
+        rx, depth, kept, status = m.stereo_matches(ex, ex, to_kp(kl), dl.cpu().numpy(), nl.cpu().numpy(), to_kp(kr), dr.cpu().numpy(), nr.cpu().numpy(),
+                                                   BF, B, index_by_keypoint=by_kp, left_frames=(0, 2), right_frames=(1, 2))
+        assert np.array_equal(d_rx.cpu().numpy().view(np.uint32), rx.view(np.uint32))
+        assert np.array_equal(d_depth.cpu().numpy().view(np.uint32), depth.view(np.uint32))
+        assert np.array_equal(d_kept.cpu().numpy(), kept) and np.array_equal(d_status.cpu().numpy(), status) and kept.sum() > 0

@@ -176,6 +176,17 @@ class OrbMatcher:
                                            STEREO_INDEX_BY_KEYPOINT if index_by_keypoint else 0, _p(rx), _p(depth), _p(kept), _p(status), None))
         return rx, depth, kept, status
 
+    def stereo_matches_device(self, left_ext, right_ext, d_kps_l, d_desc_l, d_n_l, cap_l, d_kps_r, d_desc_r, d_n_r, cap_r, n_pairs, bf, b,
+                              d_right_x, d_depth, d_kept=None, d_status=None, index_by_keypoint=False, left_frames=(0, 1),
+                              right_frames=(0, 1), stream=None):
+        """Device-resident form of stereo_matches (raw HBM addresses, asynchronous on `stream` or the matcher's stream)."""
+        from ._lib import YdStereoSide, STEREO_INDEX_BY_KEYPOINT, STEREO_DEVICE_POINTERS
+        A = YdStereoSide(left_ext._h, left_frames[0], left_frames[1], d_kps_l, d_desc_l, d_n_l, cap_l, 0)
+        B = YdStereoSide(right_ext._h, right_frames[0], right_frames[1], d_kps_r, d_desc_r, d_n_r, cap_r, 0)
+        check(self._L.ydorb_stereo_matches(self._h, C.byref(A), C.byref(B), n_pairs, float(bf), float(b),
+                                           STEREO_DEVICE_POINTERS | (STEREO_INDEX_BY_KEYPOINT if index_by_keypoint else 0), d_right_x, d_depth,
+                                           d_kept, d_status, stream))
+
     def match_consecutive_device(self, d_kps, d_desc, d_n, cap, n_frames, width, height, th, scale_factors, d_assigned, d_counts,
                                  d_affine=None, stream=None):
         sf = np.ascontiguousarray(scale_factors, np.float32)
