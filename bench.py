@@ -205,6 +205,21 @@ def main():
     value = kp_total * args.steps / dt / 1e6
     ms_per_step = dt / args.steps * 1e3
 
+    # ---- extract only (both figures): the same launches without the matcher, after the timed region ------------------
+    def extract_step():
+        for i, (f0, f1) in enumerate(parts):
+            exs[i].extract_batch_device(d_img[f0].data_ptr(), W, H, W, W * H, f1 - f0, d_kps[0][f0].data_ptr(), d_desc[0][f0].data_ptr(), cap,
+                                        d_n[0][f0:].data_ptr(), sAs[i].cuda_stream)
+    extract_step()
+    torch.cuda.synchronize()
+    te = time.perf_counter()
+    for _ in range(max(args.steps // 2, 2)):
+        extract_step()
+    torch.cuda.synchronize()
+    te = (time.perf_counter() - te) / max(args.steps // 2, 2)
+    extract_only = {"value": kp_local / te / 1e6 * world, "unit": "Mkeypoints/s", "ms_per_step": te * 1e3,
+                    "note": "rank 0's clock; extraction launches only, same handles and streams"}
+
     # ---- roofline of the dominant kernel: per-stage device time, HIP events on the launch stream -------------------
     FL = parts[0][1] - parts[0][0]   # frames per extractor launch in the timed run
     ex2 = y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=FL)
@@ -281,6 +296,7 @@ def main():
            "roofline": roofline}
 
     # ---- local BA (config 5) ------------------------------------------------------------------------------------------
+    out["extract_only"] = extract_only
     if not args.no_ba:
         prob = synth_ba_problem(100, 10000, 8, seed=1)
         if world > 1:  # shard landmarks (and their edges) across ranks; every rank holds all poses
