@@ -282,6 +282,37 @@ int ydorb_matcher_set_profiling(ydorb_matcher_t* h, int32_t on);
 int ydorb_matcher_stage_times(ydorb_matcher_t* h, int32_t max_stages, const char** names, float* ms, int32_t* n_stages);
 
 /* ------------------------------------------------------------------------------------------
+ * Vocabulary.  Replaces DBoW3::Vocabulary::transform(features, BowVector&, FeatureVector&, levelsup)
+ * (thirdParty/DBow3/src/Vocabulary.cpp:752-824; descent :836-874) as called by Frame::computeBoW / KeyFrame::computeBoW
+ * (src/frame.cpp:265-272, levelsup = 4).  The tree crosses the boundary once, as flat arrays (the adapter flattens
+ * Vocabulary::m_nodes): node 0 is the root, node i's children are child_ids[child_begin[i] .. child_begin[i+1]) in the order of
+ * Node::children (that order breaks distance ties: first minimum, :858-865); a node without children is a word.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct YdVocabularyTree {
+  int32_t n_nodes;
+  int32_t levels;              /* m_L */
+  const int32_t* child_begin;  /* [n_nodes + 1] */
+  const int32_t* child_ids;    /* [child_begin[n_nodes]] */
+  const uint8_t* node_desc;    /* [n_nodes][32]  Node::descriptor (the root's row is not read) */
+  const double* node_weight;   /* [n_nodes]      Node::weight (read for words) */
+  const int32_t* node_word;    /* [n_nodes]      Node::word_id (read for words) */
+  int32_t weighting;           /* WeightingType: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY */
+  int32_t norm;                /* what the scoring object's mustNormalize() asks for: 0 none, 1 L1, 2 L2 */
+} YdVocabularyTree;
+typedef struct ydorb_vocabulary ydorb_vocabulary_t;
+int ydorb_vocabulary_create(const YdVocabularyTree* tree, int32_t device, ydorb_vocabulary_t** out);
+void ydorb_vocabulary_destroy(ydorb_vocabulary_t* h);
+/* One call transforms n_frames descriptor sets (frame f: n[f] <= cap rows at desc + f*cap*32; cap <= 8192).
+ * BowVector of frame f: bow_word / bow_value [f*cap .. + n_words[f]) in ascending word id (std::map order), values exactly as the
+ * reference's sequence of additions and its normalisation produce them (doubles).  FeatureVector of frame f as the CSR that
+ * YdFeatureVector takes: fv_node [f*cap .. + n_fv_nodes[f]) ascending, fv_start [f*(cap+1) ..] offsets into fv_feat [f*cap ..].
+ * status[f] (may be NULL) bit0: a descent ended above level L - levelsup, where the reference reads its `nid` uninitialised
+ * (Vocabulary.cpp:777,868); such a feature is filed under the leaf's own node id. */
+int ydorb_vocabulary_transform(ydorb_vocabulary_t* h, const uint8_t* desc, const int32_t* n, int32_t n_frames, int32_t cap, int32_t levelsup,
+                               int32_t* bow_word, double* bow_value, int32_t* n_words, int32_t* fv_node, int32_t* fv_start, int32_t* fv_feat,
+                               int32_t* n_fv_nodes, int32_t* status);
+
+/* ------------------------------------------------------------------------------------------
  * Local bundle adjustment.  Replaces the g2o work inside
  *   static void Optimizer::localBundleAdjust(shared_ptr<KeyFrame>, shared_ptr<Map>, bool& stop)   src/optimizer.cpp:138-352
  * (and the shared BA kernel of Optimizer::bundleAdjust, :7-137).  The covisibility walk that collects local /

@@ -88,6 +88,8 @@ def lib():
         L.yo_ba_huber.argtypes = [C.c_double, C.c_double, C.c_void_p]
         L.yo_distinctive_descriptor.restype = C.c_int
         L.yo_distinctive_descriptor.argtypes = [C.c_void_p, C.c_int]
+        L.yo_bow_transform.restype = C.c_int
+        L.yo_bow_transform.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7
         L.yo_stereo_matches.restype = C.c_int
         L.yo_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + \
             [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -375,3 +377,19 @@ def distinctive_descriptor(desc):
     """MapPoint::computeDistinctiveDescriptors (mapPoint.cpp:191-213): index of the descriptor with the least median distance."""
     d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
     return lib().yo_distinctive_descriptor(_p(d), len(d))
+
+
+def bow_transform(tree, desc, levelsup=4, weighting=0, norm=1):
+    """DBoW3::Vocabulary::transform (Vocabulary.cpp:752-824) for one descriptor set -> (bow_word, bow_value, fv_node, fv_start, fv_feat, status)."""
+    L = lib()
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    n = len(d)
+    cb = np.ascontiguousarray(tree["child_begin"], np.int32); ci = np.ascontiguousarray(tree["child_ids"], np.int32)
+    nd = np.ascontiguousarray(tree["node_desc"], np.uint8); nw = np.ascontiguousarray(tree["node_weight"], np.float64)
+    wd = np.ascontiguousarray(tree["node_word"], np.int32)
+    bw = np.zeros(max(n, 1), np.int32); bv = np.zeros(max(n, 1), np.float64); fn = np.zeros(max(n, 1), np.int32)
+    fs = np.zeros(n + 2, np.int32); ff = np.zeros(max(n, 1), np.int32)
+    k1, k2 = C.c_int32(0), C.c_int32(0)
+    st = L.yo_bow_transform(int(tree["levels"]), _p(cb), _p(ci), _p(nd), _p(nw), _p(wd), _p(d), n, int(levelsup), int(weighting), int(norm),
+                            _p(bw), _p(bv), C.byref(k1), _p(fn), _p(fs), _p(ff), C.byref(k2))
+    return bw[:k1.value], bv[:k1.value], fn[:k2.value], fs[:k2.value + 1], ff[:fs[k2.value]], st

@@ -10,6 +10,7 @@ from ._lib import YdorbError, lib, library_path, build_library  # noqa: F401
 from .extractor import OrbExtractor, KP_DTYPE  # noqa: F401
 from .matcher import OrbMatcher, FrameView, FeatureVector, QUERY_DTYPE  # noqa: F401
 from .optimizer import Optimizer  # noqa: F401
+from .vocabulary import Vocabulary  # noqa: F401
 
 __all__ = ["YdorbError", "lib", "library_path", "build_library", "OrbExtractor", "KP_DTYPE", "OrbMatcher", "FrameView",
-           "FeatureVector", "QUERY_DTYPE", "Optimizer"]
+           "FeatureVector", "QUERY_DTYPE", "Optimizer", "Vocabulary"]

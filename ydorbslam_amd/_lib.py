@@ -63,6 +63,9 @@ SYMBOLS = {
     "ydorb_window_search": (C.c_int, [_VP, _VP, _VP, _VP, _I, _VP, _I, _I, _VP, C.POINTER(_I)]),
     "ydorb_search_for_triangulation": (C.c_int, [_VP, _VP, _VP, _VP, C.c_float, C.c_float, _VP, _VP, _I, _I, _I, _VP, C.POINTER(_I)]),
     "ydorb_distinctive_descriptors": (C.c_int, [_VP, _VP, _VP, _I, _VP]),
+    "ydorb_vocabulary_create": (C.c_int, [_VP, _I, C.POINTER(_VP)]),
+    "ydorb_vocabulary_destroy": (None, [_VP]),
+    "ydorb_vocabulary_transform": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "ydorb_stereo_matches": (C.c_int, [_VP, _VP, _VP, _I, C.c_float, C.c_float, _I, _VP, _VP, _VP, _VP, _VP]),
     "ydorb_match_consecutive_device": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, C.c_float, _VP, _I, _VP, _I, _VP, _VP, _VP]),
     "ydorb_matcher_synchronize": (C.c_int, [_VP]),
@@ -120,6 +123,11 @@ class YdBowSide(C.Structure):
 
 class YdTriSide(C.Structure):
     _fields_ = [("kps", _VP), ("desc", _VP), ("right_x", _VP), ("has_map_point", _VP), ("n", _I), ("fv", YdFeatureVector)]
+
+
+class YdVocabularyTree(C.Structure):
+    _fields_ = [("n_nodes", _I), ("levels", _I), ("child_begin", _VP), ("child_ids", _VP), ("node_desc", _VP), ("node_weight", _VP),
+                ("node_word", _VP), ("weighting", _I), ("norm", _I)]
 
 
 class YdStereoSide(C.Structure):

@@ -142,3 +142,47 @@ def synth_pose_problem(n_pts=400, seed=1, outlier_frac=0.1, mono_frac=0.3, pose_
     truth = np.concatenate([tt, _rot_to_quat(Rt)])
     return dict(pose=pose, points=Xw, meas=meas, info=info, camera=np.array([fx, fy, cx, cy, bf], np.float64), truth_pose=truth,
                 is_gross_outlier=bad)
+
+
+# ---------------------------------------------------------------------------------------------
+# Synthetic vocabulary tree (the reference's ORB vocabulary is a missing blob): k children per inner node, L levels, node
+# descriptors = parent's descriptor with a level-dependent share of flipped bits (so that a descent is decided by real distance
+# differences, with occasional ties), idf-like positive weights with a share of stopped (zero-weight) words, and optionally
+# branches that end early.  Node ids in breadth-first order as DBoW3 assigns them while clustering; word ids in leaf creation order.
+# ---------------------------------------------------------------------------------------------
+def synth_vocabulary(k=10, levels=3, seed=0, early_leaf_frac=0.0, stopped_frac=0.05):
+    rng = np.random.default_rng(9000 + seed)
+    desc = [rng.integers(0, 256, 32, dtype=np.uint8)]
+    depth = [0]
+    children = [[]]
+    frontier = [0]
+    for lvl in range(1, levels + 1):
+        nxt = []
+        for u in frontier:
+            if lvl > 1 and rng.random() < early_leaf_frac:
+                continue                      # u stays a leaf above the bottom level
+            kk = k if rng.random() > 0.2 else int(rng.integers(2, k + 1))
+            for _ in range(kk):
+                flips = rng.random(256) < 0.5 / (lvl + 0.5)
+                d = np.packbits(np.unpackbits(desc[u]) ^ flips.astype(np.uint8))
+                desc.append(d); depth.append(lvl); children.append([])
+                children[u].append(len(desc) - 1)
+                nxt.append(len(desc) - 1)
+        frontier = nxt
+    n = len(desc)
+    child_begin = np.zeros(n + 1, np.int32)
+    child_ids = []
+    for u in range(n):
+        order = list(children[u])
+        if len(order) > 2 and rng.random() < 0.3:
+            order = [order[i] for i in rng.permutation(len(order))]   # Node::children need not be ascending
+        child_ids += order
+        child_begin[u + 1] = len(child_ids)
+    word = np.full(n, 0, np.int32)
+    weight = np.zeros(n, np.float64)
+    leaves = [u for u in range(n) if child_begin[u + 1] == child_begin[u]]
+    for wid, u in enumerate(leaves):
+        word[u] = wid
+        weight[u] = 0.0 if rng.random() < stopped_frac else float(np.log(1.0 + rng.uniform(0.5, 200.0)))
+    return dict(levels=levels, child_begin=child_begin, child_ids=np.array(child_ids, np.int32), node_desc=np.stack(desc),
+                node_weight=weight, node_word=word, n_words=len(leaves))
