@@ -399,6 +399,24 @@ def main():
             ts = (time.perf_counter() - ts) / 5
             out["stereo"][name] = {"value": NSP / ts, "unit": "pairs/s", "ms_per_call": ts * 1e3, "measurements_per_pair": float(np.mean(sout[2]))}
 
+    # ---- vocabulary transform (DBoW3::Vocabulary::transform): BowVector + FeatureVector per frame ----------------
+    if not args.no_ba and world == 1:
+        from ydorbslam_amd.synth import synth_vocabulary
+        vtree = synth_vocabulary(10, 5, seed=1)   # k = 10 like the ORB vocabulary, one level less (L = 6 would be 35 MB of synthetic nodes)
+        voc = y.Vocabulary(vtree)
+        NBF = min(256, F)
+        hn = d_n[0][:NBF].cpu().numpy()
+        hdesc = d_desc[0][:NBF].cpu().numpy()
+        bdescs = [hdesc[f, :hn[f]] for f in range(NBF)]
+        voc.transform(bdescs, 3)
+        tv = time.perf_counter()
+        for _ in range(3):
+            bout = voc.transform(bdescs, 3)
+        tv = (time.perf_counter() - tv) / 3
+        out["bow_transform"] = {"metric": "Vocabulary::transform frames/sec (1000 descriptors per frame, k=10 L=5 synthetic tree, levelsup 3; host descriptors in, host vectors out)",
+                                "frames_per_call": NBF, "tree_nodes": int(len(vtree["node_word"])), "value": NBF / tv, "unit": "frames/s",
+                                "ms_per_call": tv * 1e3, "mean_words_per_frame": float(np.mean([len(b[0]) for b in bout]))}
+
     # ---- CPU baseline: the oracle (port of the reference algorithm), one thread, bounded sample -------------------------
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle.orb_oracle import FrameOracle, OrbExtractorOracle, QUERY_DTYPE, ba_solve
@@ -450,6 +468,12 @@ def main():
                     tsc += time.perf_counter() - t0_; nsc += 1
             out["stereo"]["cpu_baseline"] = {"value": nsc / tsc, "unit": "pairs/s", "cores": 1, "kind": "port",
                                              "sample": "4 of the same pairs, both index forms, association only (pyramids and keypoints given)"}
+            from oracle.orb_oracle import bow_transform as oracle_bow
+            tvc = time.perf_counter()
+            for f in range(16):
+                oracle_bow(vtree, bdescs[f], 3, 0, 1)
+            tvc = (time.perf_counter() - tvc) / 16
+            out["bow_transform"]["cpu_baseline"] = {"value": 1.0 / tvc, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "16 of the same frames"}
         out["vs_cpu"] = value / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))

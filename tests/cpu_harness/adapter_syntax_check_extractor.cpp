@@ -16,3 +16,14 @@ struct StereoFrame {
   static float m_flt_baseLineTimesFx, m_flt_baseLine;
 };
 int checkStereo(StereoFrame& f) { return ydorb::adapter::computeStereoMatchesImpl(f) + ydorb::adapter::computeStereoMatchesImpl(f, YDORB_STEREO_INDEX_BY_KEYPOINT); }
+
+// DBoW3::Vocabulary subclass (include/ydorb/vocabulary.hpp) against the DBoW3 members it touches
+#include "../../include/ydorb/vocabulary.hpp"
+int checkVocabulary(const std::vector<cv::Mat>& features) {
+  ydorb::adapter::GpuVocabulary voc("orbvoc.dbow3");
+  DBoW3::BowVector v; DBoW3::FeatureVector fv;
+  std::shared_ptr<DBoW3::Vocabulary> base = std::make_shared<ydorb::adapter::GpuVocabulary>("orbvoc.dbow3");
+  base->transform(features, v, fv, 4);
+  voc.transform(features, v, fv, 4);
+  return (int)v.size() + (int)fv.size();
+}
