@@ -6,13 +6,13 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import numpy as np
 import ydorbslam_amd as y
 from oracle import orb_oracle as oo
-from ydorbslam_amd.synth import synth_frame, synth_ba_problem, synth_pose_problem
+from ydorbslam_amd.synth import synth_frame, synth_ba_problem, synth_pose_problem, synth_vocabulary
 from helpers import bow_nodes, feature_vector, projection_queries
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 t0 = time.time()
-n_ex = n_ma = n_ba = n_po = n_st = 0
+n_ex = n_ma = n_ba = n_po = n_st = n_bw = 0
 while time.time() - t0 < budget:
     # ---- extractor
     w, h = int(rng.integers(60, 1400)), int(rng.integers(60, 800))
@@ -84,6 +84,24 @@ while time.time() - t0 < budget:
                         print("  slot", i, "gpu", p_[0][0][i], p_[1][0][i], "oracle", o_[0][i], o_[1][i], "kp", lk[i])
                     raise AssertionError(("stereo", w, h, nf, sf, nl, thr, dsp, by_kp, bf, bl))
             n_st += 1
+    # ---- vocabulary transform + distinctive descriptors on this frame's descriptors
+    if len(gk) > 0 and len(gk) <= 8192 and rng.random() < 0.4:
+        wgt, nrm = int(rng.integers(0, 4)), int(rng.integers(0, 3))
+        tree = synth_vocabulary(int(rng.integers(2, 11)), int(rng.integers(1, 6)), seed=int(rng.integers(0, 1 << 30)),
+                                early_leaf_frac=float(rng.choice([0.0, 0.2, 0.5])), stopped_frac=float(rng.choice([0.0, 0.1, 0.5])))
+        leaves = np.flatnonzero(np.diff(tree["child_begin"]) == 0)
+        dd = np.where(rng.random((len(gd), 1)) < 0.5, gd, tree["node_desc"][rng.choice(leaves, len(gd))])   # half of them close to words
+        lup = int(rng.integers(0, 7))
+        voc = y.Vocabulary(tree, ["TF_IDF", "TF", "IDF", "BINARY"][wgt], ["none", "L1", "L2"][nrm])
+        got = voc.transform([dd, dd[: len(dd) // 3]], lup)
+        for d_, g_ in zip([dd, dd[: len(dd) // 3]], got):
+            o_ = oo.bow_transform(tree, d_, lup, wgt, nrm)
+            assert all(np.array_equal(np.asarray(a_).view(np.uint8) if hasattr(a_, "view") else a_, np.asarray(b_).view(np.uint8) if hasattr(b_, "view") else b_)
+                       for a_, b_ in zip(g_, o_)), ("bow", wgt, nrm, lup)
+        groups = [gd[int(a_):int(a_) + int(m_)] for a_, m_ in zip(rng.integers(0, max(len(gd) - 70, 1), 40), rng.integers(0, 70, 40))]
+        bi = y.OrbMatcher().distinctive_descriptors(groups)
+        assert list(bi) == [oo.distinctive_descriptor(g_) if len(g_) else -1 for g_ in groups], "distinctive"
+        n_bw += 1
     # ---- BA + pose
     if rng.random() < 0.3:
         prob = synth_ba_problem(int(rng.integers(3, 40)), int(rng.integers(30, 1500)), int(rng.integers(2, 8)), seed=int(rng.integers(0, 1 << 30)),
@@ -98,4 +116,4 @@ while time.time() - t0 < budget:
             r_ = oo.pose_optimize(p_)
             assert g_["inliers"] == r_["inliers"] and np.array_equal(g_["outlier"], r_["outlier"]), ("pose", len(p_["info"]))
             n_po += 1
-print("fuzz ok: %d extractor configs, %d matcher scenes, %d stereo pairs, %d BA problems, %d pose problems in %.0f s" % (n_ex, n_ma, n_st, n_ba, n_po, time.time() - t0))
+print("fuzz ok: %d extractor configs, %d matcher scenes, %d stereo pairs, %d vocabulary / distinctive-descriptor cases, %d BA problems, %d pose problems in %.0f s" % (n_ex, n_ma, n_st, n_bw, n_ba, n_po, time.time() - t0))
