@@ -209,19 +209,32 @@ __global__ __launch_bounds__(256) void k_pyr_borders(uint8_t* __restrict__ pyr, 
   t -= P.borderBegin[level];
   const LevelDev L = P.lv[level];
   const int wd = L.pitch >> 2, rightStart = (kPad + L.w) >> 2;
+  // The list of a level is ordered so that waves are (nearly) pure: first the dwords of the 38 pad rows that lie entirely over
+  // interior columns - a straight dword copy of the reflected row - then the pad rows' end dwords, then the interior rows' ends.
+  constexpr int xdLo = (kPad + 3) / 4;                       // first dword whose 4 columns are all >= 0
+  const int xdEnd = min(rightStart, wd);                     // first dword with a column >= w
+  const int nFast = max(xdEnd - xdLo, 0), nEdge = wd - nFast;
+  uint8_t* base = pyr + (size_t)f * pyrFrameStride + L.padOff;
+  if (t < 2 * kPad * nFast) {
+    const int r = t / nFast, xf = xdLo + t - r * nFast;
+    const int yy = r < kPad ? r : L.h + r;
+    const int rr = reflect101(yy - kPad, L.h);
+    reinterpret_cast<uint32_t*>(base + (size_t)yy * L.pitch)[xf] = reinterpret_cast<const uint32_t*>(base + (size_t)(rr + kPad) * L.pitch)[xf];
+    return;
+  }
+  t -= 2 * kPad * nFast;
   int y, xd;
-  if (t < 2 * kPad * wd) {
-    const int r = t / wd;
-    xd = t - r * wd;
+  if (t < 2 * kPad * nEdge) {
+    const int r = t / nEdge, k = t - r * nEdge;
+    xd = nFast == 0 ? k : (k < xdLo ? k : xdEnd + k - xdLo);
     y = r < kPad ? r : L.h + r;                  // rows 0..18 and h+19 .. h+37
   } else {
-    const int u = t - 2 * kPad * wd, row = u / 12, j = u - row * 12;
+    const int u = t - 2 * kPad * nEdge, row = u / 12, j = u - row * 12;
     if (row >= L.h) return;
     y = kPad + row;
     xd = j < 6 ? j : rightStart + j - 6;
     if (xd >= wd || (j < 6 && (4 * xd >= kPad || xd >= rightStart))) return;   // left: dwords 0..4; tiny levels: the right end wins
   }
-  uint8_t* base = pyr + (size_t)f * pyrFrameStride + L.padOff;
   uint32_t* dw = reinterpret_cast<uint32_t*>(base + (size_t)y * L.pitch) + xd;
   const int Y = y - kPad, ry = reflect101(Y, L.h);
   const bool rowInside = Y >= 0 && Y < L.h;
