@@ -417,6 +417,21 @@ def main():
                                 "frames_per_call": NBF, "tree_nodes": int(len(vtree["node_word"])), "value": NBF / tv, "unit": "frames/s",
                                 "ms_per_call": tv * 1e3, "mean_words_per_frame": float(np.mean([len(b[0]) for b in bout]))}
 
+    # ---- distinctive descriptors (MapPoint::computeDistinctiveDescriptors): a batch of map points per call -----------
+    if not args.no_ba and world == 1:
+        rngd = np.random.default_rng(5)
+        NMP = 50000
+        pool_d = np.concatenate(bdescs[:64])
+        sizes = rngd.integers(2, 21, NMP)
+        groups_d = [pool_d[a:a + m_] for a, m_ in zip(rngd.integers(0, len(pool_d) - 21, NMP), sizes)]
+        mm_d = y.OrbMatcher()
+        mm_d.distinctive_descriptors(groups_d[:100])
+        td = time.perf_counter()
+        best_d = mm_d.distinctive_descriptors(groups_d)
+        td = time.perf_counter() - td
+        out["distinctive_descriptors"] = {"metric": "computeDistinctiveDescriptors map points/sec (2-20 observations each, one batched call, host in / host out incl. Python packing)",
+                                          "points_per_call": NMP, "value": NMP / td, "unit": "points/s", "ms_per_call": td * 1e3}
+
     # ---- CPU baseline: the oracle (port of the reference algorithm), one thread, bounded sample -------------------------
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle.orb_oracle import FrameOracle, OrbExtractorOracle, QUERY_DTYPE, ba_solve
@@ -474,6 +489,12 @@ def main():
                 oracle_bow(vtree, bdescs[f], 3, 0, 1)
             tvc = (time.perf_counter() - tvc) / 16
             out["bow_transform"]["cpu_baseline"] = {"value": 1.0 / tvc, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "16 of the same frames"}
+            from oracle.orb_oracle import distinctive_descriptor as oracle_dd
+            tdc = time.perf_counter()
+            ok_d = all(oracle_dd(groups_d[i]) == best_d[i] for i in range(5000))
+            tdc = (time.perf_counter() - tdc) / 5000
+            out["distinctive_descriptors"]["cpu_baseline"] = {"value": 1.0 / tdc, "unit": "points/s", "cores": 1, "kind": "port",
+                                                              "sample": "5000 of the same points (results equal: %s)" % ok_d}
         out["vs_cpu"] = value / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))
