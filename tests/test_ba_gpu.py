@@ -145,3 +145,15 @@ def test_pose_only_optimisation_batch(oracle_lib):
     assert got[4]["inliers"] == 0 and np.array_equal(got[4]["pose"], probs[4]["pose"])      # < 3 correspondences: untouched
     one = y.Optimizer.optimize_poses(probs[:1])[0]                                            # batch position does not matter
     assert one["pose"].tobytes() == got[0]["pose"].tobytes() and np.array_equal(one["outlier"], got[0]["outlier"])
+
+
+def test_solve_is_bit_reproducible_run_to_run():
+    """Every reduction has a fixed order (pose-pair buckets are sorted by landmark up to 2048 observations per pose), so two
+    solves of the same problem give identical bits - which is what lets kernel changes be checked for exact equality."""
+    import ydorbslam_amd as y
+    from ydorbslam_amd.synth import synth_ba_problem
+    p = synth_ba_problem(30, 3000, 8, seed=4)
+    a = y.Optimizer.local_bundle_adjust(p)
+    b = y.Optimizer.local_bundle_adjust(p)
+    assert a["poses"].tobytes() == b["poses"].tobytes() and a["points"].tobytes() == b["points"].tobytes()
+    assert a["log"].tobytes() == b["log"].tobytes()

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void k_pair_fill(EdgeSoA Ed, const int* __rest
 }
 // order every bucket by its first edge index (== by landmark): rank sort from LDS, one wave per bucket, out of place.
 // Buckets with more than kSortCap entries are copied unsorted (their summation order is then not reproducible run to run).
-constexpr int kSortCap = 512;
+constexpr int kSortCap = 2048;   // 32 KB of LDS keys per workgroup; C5 has 800 observations per pose (its diagonal buckets)
 __global__ __launch_bounds__(256) void k_pair_sort(const int* __restrict__ start, int nBuckets, const int2* __restrict__ in,
                                                    int2* __restrict__ out) {
   __shared__ int keys[4][kSortCap];
@@ -629,6 +629,63 @@ __device__ __forceinline__ bool potrf_wave(R (*D)[NBP], R (*Lp)[NB][4], R* rdiag
   return ok;
 }
 
+// The same factorisation on the whole 256-thread workgroup: wave w keeps columns 8w .. 8w+7 of every row (row per lane, as above),
+// the wave that owns a 4-column block factors it and publishes it through LDS, then ALL waves apply the block's rank-4 update to
+// their own columns side by side.  One wave did 112 column updates in sequence between the 8 block factorisations; here at most 8
+// follow each block before the next owner can start.  Same operations in the same order per element (k ascending), so the factor
+// is bit-identical to potrf_wave's.  One workgroup barrier per block; *okFlag (pre-set to 1) is cleared on a non-positive pivot.
+__device__ __forceinline__ void potrf_block(R (*D)[NBP], R (*Lp)[NB][4], R* rdiag, int* okFlag, int tid) {
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 31;
+  R a[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) a[c] = D[i][8 * wv + c];
+  bool ok = true;
+#pragma unroll
+  for (int b = 0; b < NB / 4; b++) {
+    const int owner = b >> 1, cb = 4 * (b & 1);
+    R (*buf)[4] = Lp[b & 1];
+    if (wv == owner) {
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) {
+        const int j = 4 * b + jj;
+        const R d = bcast_lane(a[cb + jj], j);     // pivot: element (j, j) lives in lane j
+        if (!(d > 0)) ok = false;
+        const R inv = rsqrt_nr(d);
+        const R lij = a[cb + jj] * inv;            // rows i < j hold stale values; they are never used again
+        a[cb + jj] = lij;
+        if (lane == j) rdiag[j] = inv;
+#pragma unroll
+        for (int c = jj + 1; c < 4; c++) a[cb + c] -= lij * bcast_lane(lij, 4 * b + c);   // L(c, j) lives in lane c
+      }
+      if (b < NB / 4 - 1 && lane < NB) {
+        *reinterpret_cast<double2*>(&buf[i][0]) = make_double2(a[cb], a[cb + 1]);
+        *reinterpret_cast<double2*>(&buf[i][2]) = make_double2(a[cb + 2], a[cb + 3]);
+      }
+    }
+    if (b < NB / 4 - 1) {
+      __syncthreads();
+      if (8 * wv + 7 >= 4 * b + 4) {   // this wave still has columns behind the block
+        const double2 m01 = *reinterpret_cast<const double2*>(&buf[i][0]), m23 = *reinterpret_cast<const double2*>(&buf[i][2]);   // L(i, block)
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          const int gc = 8 * wv + c;
+          if (gc >= 4 * b + 4) {
+            const double2 l01 = *reinterpret_cast<const double2*>(&buf[gc][0]), l23 = *reinterpret_cast<const double2*>(&buf[gc][2]);
+            R v = a[c];
+            v -= m01.x * l01.x; v -= m01.y * l01.y; v -= m23.x * l23.x; v -= m23.y * l23.y;
+            a[c] = v;
+          }
+        }
+      }
+    }
+  }
+  if (!ok && lane == 0) *okFlag = 0;
+  if (lane < NB) {
+#pragma unroll
+    for (int c = 0; c < 8; c++) D[i][8 * wv + c] = 8 * wv + c <= i ? a[c] : 0.0;
+  }
+}
+
 __device__ __forceinline__ int tri_index(int t, int* row) {  // t -> (row, col) of a packed lower triangle, row-major
   int r = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
   while ((r + 1) * (r + 2) / 2 <= t) r++;
@@ -723,13 +780,18 @@ __global__ __launch_bounds__(256) void k_chol_step(R* __restrict__ S, R* __restr
   }
 #pragma unroll
   for (int c = 0; c < 4; c++) { Ta[tr][tc4 + c] = acc[c]; Dg[tr][tc4 + c] = accD[c]; }
+  if (tid == 0) sOk = 1;
   __syncthreads();
   CH_CLK(4);
 #ifndef CHOL_SKIP_POTRF
+#ifdef CHOL_POTRF_ONE_WAVE
   if (tid < 64) {
     const bool ok = potrf_wave(Dg, Lp, rdiag, tid);
     if (tid == 0) sOk = ok ? 1 : 0;
   }
+#else
+  potrf_block(Dg, Lp, rdiag, &sOk, tid);
+#endif
 #else
   if (tid == 0) sOk = 1;
   if (tid < NB) rdiag[tid] = 1.0;
