@@ -307,7 +307,8 @@ void ydorb_vocabulary_destroy(ydorb_vocabulary_t* h);
  * reference's sequence of additions and its normalisation produce them (doubles).  FeatureVector of frame f as the CSR that
  * YdFeatureVector takes: fv_node [f*cap .. + n_fv_nodes[f]) ascending, fv_start [f*(cap+1) ..] offsets into fv_feat [f*cap ..].
  * status[f] (may be NULL) bit0: a descent ended above level L - levelsup, where the reference reads its `nid` uninitialised
- * (Vocabulary.cpp:777,868); such a feature is filed under the leaf's own node id. */
+ * (Vocabulary.cpp:777,868); such a feature is filed under the leaf's own node id.  Calls on one handle from several threads are
+ * serialised inside (the reference shares one vocabulary between its tracking, local-mapping and loop-closing threads). */
 int ydorb_vocabulary_transform(ydorb_vocabulary_t* h, const uint8_t* desc, const int32_t* n, int32_t n_frames, int32_t cap, int32_t levelsup,
                                int32_t* bow_word, double* bow_value, int32_t* n_words, int32_t* fv_node, int32_t* fv_start, int32_t* fv_feat,
                                int32_t* n_fv_nodes, int32_t* status);

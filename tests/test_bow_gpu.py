@@ -77,3 +77,26 @@ def test_argument_checks():
     voc = y.Vocabulary(tree)
     with pytest.raises(y.YdorbError):
         voc.transform([np.zeros((8193, 32), np.uint8)])
+
+
+def test_one_vocabulary_shared_by_threads(oracle_lib):
+    """Tracking, local mapping and loop closing call computeBoW on the same vocabulary (frame.cpp:265-272, keyFrame): concurrent
+    transforms on one handle must not disturb each other."""
+    import threading
+    import ydorbslam_amd as y
+    tree = synth_vocabulary(8, 4, seed=11)
+    voc = y.Vocabulary(tree)
+    sets = [_descriptors(tree, 600 + 50 * i, 200 + i) for i in range(6)]
+    want = [oracle_lib.bow_transform(tree, d, 2, 0, 1) for d in sets]
+    bad = []
+
+    def work(i):
+        for _ in range(10):
+            bw, bv, fn, fs, ff, st = voc.transform([sets[i]], 2)[0]
+            if not (np.array_equal(bw, want[i][0]) and np.array_equal(bv.view(np.uint64), want[i][1].view(np.uint64)) and np.array_equal(ff, want[i][4])):
+                bad.append(i)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not bad

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/ydorb/c_api.h"
@@ -203,6 +204,7 @@ struct ydorb_vocabulary {
   hipStream_t stream = nullptr;
   DBuf childBegin, childIds, nodeDesc, nodeWeight, nodeWord;   // the tree
   DBuf desc, nFeat, word, node, weight, status, out;           // per-call scratch
+  std::mutex mu;   // Frame::computeBoW and KeyFrame::computeBoW reach one vocabulary from the tracking, mapping and loop-closing threads
 };
 
 extern "C" {
@@ -277,6 +279,7 @@ int ydorb_vocabulary_transform(ydorb_vocabulary_t* v, const uint8_t* desc, const
   if (cap > kBowMaxFeatures) { set_error("more than %d features per frame are not supported", kBowMaxFeatures); return YDORB_ERR_UNSUPPORTED; }
   for (int f = 0; f < nFrames; f++)
     if (n[f] < 0 || n[f] > cap) { set_error("frame %d: %d features, capacity %d", f, n[f], cap); return YDORB_ERR_INVALID_ARG; }
+  std::lock_guard<std::mutex> lock(v->mu);
   HIPCHK(hipSetDevice(v->device));
   const size_t tot = (size_t)nFrames * cap;
   // out: bowWord | fvNode | fvFeat | fvStart (cap + 1 per frame) | nWords | nFvNodes (ints), then bowValue (doubles)
