@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic frames (tiled to --frames)")
     ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the CPU-oracle baseline sample")
     ap.add_argument("--extractors", type=int, default=2, help="extractor handles (each with its own stream) the frames of a step are split over")
+    ap.add_argument("--ba-threads", type=int, default=8, help="host threads of the concurrent local-BA figure (the library pools 8 contexts per device)")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -341,7 +342,7 @@ def main():
             # GIL; the library keeps a pool of per-device contexts).  One solve is a latency chain that leaves the GPU mostly
             # idle, so concurrent maps / sessions overlap almost freely.
             import threading
-            NT = 6
+            NT = args.ba_threads
             probs = [synth_ba_problem(100, 10000, 8, seed=1) for _ in range(NT)]
             res = [0] * NT
 
