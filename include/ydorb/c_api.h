@@ -376,6 +376,11 @@ void ydorb_ba_default_options(YdBaOptions* opt);
  * sessions — may solve at once; a ninth concurrent caller waits.  Results do not depend on what else runs (fixed summation
  * orders).  The reference itself calls localBundleAdjust from one thread (localMapping.cpp:29). */
 int ydorb_ba_solve(const YdBaProblem* prob, const YdBaOptions* opt, YdBaResult* res);
+/* n independent problems (several maps / sessions / replayed windows) solved concurrently: up to `threads` host threads (0 = the
+ * library's 8 pooled contexts per device), each problem on its own stream and scratch.  One solve is a latency chain that leaves most
+ * of the GPU idle, so the aggregate rate grows almost freely with the number in flight.  res[i] / rc_each[i] (may be NULL) per
+ * problem; returns the first non-zero status.  Same results as n calls of ydorb_ba_solve. */
+int ydorb_ba_solve_batch(const YdBaProblem* probs, int32_t n, const YdBaOptions* opt, YdBaResult* res, int32_t threads, int32_t* rc_each);
 
 /* ------------------------------------------------------------------------------------------
  * Pose-only optimisation.  Replaces YDORBSLAM::Optimizer::optimizePose (src/optimizer.cpp:358-501) — the

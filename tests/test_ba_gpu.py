@@ -157,3 +157,17 @@ def test_solve_is_bit_reproducible_run_to_run():
     b = y.Optimizer.local_bundle_adjust(p)
     assert a["poses"].tobytes() == b["poses"].tobytes() and a["points"].tobytes() == b["points"].tobytes()
     assert a["log"].tobytes() == b["log"].tobytes()
+
+
+def test_batched_solve_equals_single_solves():
+    """ydorb_ba_solve_batch: independent problems on pooled contexts, concurrently; each result identical to its own single solve."""
+    import ydorbslam_amd as y
+    from ydorbslam_amd.synth import synth_ba_problem
+    probs = [synth_ba_problem(8 + 3 * i, 200 + 150 * i, 4 + i % 3, seed=20 + i, outlier_frac=0.05) for i in range(11)]
+    single = [y.Optimizer.local_bundle_adjust(p) for p in probs]
+    for threads in (0, 3):
+        batch = y.Optimizer.local_bundle_adjust_batch(probs, threads=threads)
+        for a, b in zip(single, batch):
+            assert a["poses"].tobytes() == b["poses"].tobytes() and a["points"].tobytes() == b["points"].tobytes()
+            assert np.array_equal(a["outlier"], b["outlier"]) and a["trials"] == b["trials"] and a["log"].tobytes() == b["log"].tobytes()
+    assert y.Optimizer.local_bundle_adjust_batch([]) == []

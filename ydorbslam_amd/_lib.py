@@ -73,6 +73,7 @@ SYMBOLS = {
     "ydorb_matcher_stage_times": (C.c_int, [_VP, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_I)]),
     "ydorb_ba_default_options": (None, [_VP]),
     "ydorb_ba_solve": (C.c_int, [_VP, _VP, _VP]),
+    "ydorb_ba_solve_batch": (C.c_int, [_VP, _I, _VP, _VP, _I, _VP]),
     "ydorb_ba_dense_solve": (C.c_int, [_I, _VP, _I, _VP, _VP, C.POINTER(_I)]),
     "ydorb_pose_optimize": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
 }

@@ -8,6 +8,9 @@
 #include <chrono>
 
 #include <algorithm>
+#include <string>
+#include <thread>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -578,6 +581,31 @@ int ydorb_pose_optimize(const YdPoseBatch* B, uint8_t* outlier, int32_t* n_inlie
   return YDORB_OK;
 }
 
+
+int ydorb_ba_solve_batch(const YdBaProblem* probs, int32_t n, const YdBaOptions* opt, YdBaResult* res, int32_t threads, int32_t* rcEach) {
+  if (n < 0 || (n > 0 && (!probs || !res))) { set_error("invalid argument"); return YDORB_ERR_INVALID_ARG; }
+  if (opt && opt->world > 1) { set_error("the batched form solves whole problems: no landmark sharding"); return YDORB_ERR_INVALID_ARG; }
+  const int nt = std::max(1, std::min<int>(std::min<int>(threads > 0 ? threads : kCtxPool, kCtxPool), n));
+  std::atomic<int> next{0}, firstRc{0};
+  std::mutex errMu;
+  std::string errText;
+  auto worker = [&]() {
+    for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+      const int rc = ydorb_ba_solve(&probs[i], opt, &res[i]);
+      if (rcEach) rcEach[i] = rc;
+      if (rc != YDORB_OK) {
+        int expected = 0;
+        if (firstRc.compare_exchange_strong(expected, rc)) { std::lock_guard<std::mutex> g(errMu); errText = ydorb_last_error(); }
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nt; t++) pool.emplace_back(worker);
+  worker();
+  for (std::thread& t : pool) t.join();
+  if (firstRc.load() != 0) { set_error("%s", errText.c_str()); return firstRc.load(); }
+  return YDORB_OK;
+}
 
 int ydorb_ba_dense_solve(int32_t device, const double* A, int32_t n0, const double* b, double* x, int32_t* ok) {
   if (!A || !b || !x || !ok || n0 < 1 || device < 0 || device >= 16) { set_error("invalid argument"); return YDORB_ERR_INVALID_ARG; }

@@ -67,6 +67,42 @@ class Optimizer:
                             update=res.ms_update))
 
     @staticmethod
+    def local_bundle_adjust_batch(probs, options=None, threads=0):
+        """n independent problems in one ydorb_ba_solve_batch call (host threads inside the library, one pooled context each).
+        Returns a list of the dicts local_bundle_adjust returns."""
+        L = lib()
+        o = options if options is not None else Optimizer.default_options()
+        n = len(probs)
+        if n == 0:
+            return []
+        P = (YdBaProblem * n)()
+        R = (YdBaResult * n)()
+        keep = []
+        for i, prob in enumerate(probs):
+            poses = np.ascontiguousarray(prob["poses"], np.float64).copy()
+            points = np.ascontiguousarray(prob["points"], np.float64).copy()
+            fixed = np.ascontiguousarray(prob["fixed"], np.uint8)
+            ep = np.ascontiguousarray(prob["edge_pose"], np.int32)
+            eq = np.ascontiguousarray(prob["edge_point"], np.int32)
+            meas = np.ascontiguousarray(prob["meas"], np.float64)
+            info = np.ascontiguousarray(prob["info"], np.float64)
+            outlier = np.zeros(max(len(ep), 1), np.uint8)
+            cam = [float(v) for v in prob["camera"]]
+            P[i] = YdBaProblem(len(poses), len(points), len(ep), _p(poses), _p(fixed), _p(points), _p(ep), _p(eq), _p(meas), _p(info), *cam, None)
+            R[i].edge_outlier = outlier.ctypes.data_as(C.c_void_p).value
+            keep.append((poses, points, fixed, ep, eq, meas, info, outlier))
+        check(L.ydorb_ba_solve_batch(P, n, C.byref(o), R, int(threads), None))
+        out = []
+        for i in range(n):
+            res, (poses, points, _, ep, _, _, _, outlier) = R[i], keep[i]
+            k = res.n_log
+            log = np.stack([np.array(res.log_chi2[:k]), np.array(res.log_lambda[:k]), np.array(res.log_trials[:k], np.float64),
+                            np.array(res.log_stage[:k], np.float64)], axis=1) if k else np.zeros((0, 4))
+            out.append(dict(poses=poses, points=points, outlier=outlier[:len(ep)], log=log, trials=res.n_trials, iterations=res.n_iterations,
+                            stopped=bool(res.stopped)))
+        return out
+
+    @staticmethod
     def optimize_poses(probs, device=0):
         """Optimizer::optimizePose (optimizer.cpp:358-501) for a batch of frames in one launch.  probs: list of dicts as
         ydorbslam_amd.synth.synth_pose_problem (pose[7], points[E,3], meas[E,3], info[E], camera[5] — the camera of probs[0] is used).
