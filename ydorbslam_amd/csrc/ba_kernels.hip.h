@@ -884,8 +884,10 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const R* __restrict__ L, co
     for (int o = 16; o >= 1; o >>= 1) p += __shfl_xor(p, o, 64);
     if (k == 0) y[(nb - 1) * NB + r] = p;
   }
+  R invNext = diagInv[(size_t)(nb - 1) * NB * NB + tid];
   for (int kb = nb - 1; kb >= 0; kb--) {
-    const R invReg = diagInv[(size_t)kb * NB * NB + tid];          // element (r, c) = (tid / 32, tid % 32)
+    const R invReg = invNext;                                       // element (r, c) = (tid / 32, tid % 32); fetched one step ahead:
+    if (kb > 0) invNext = diagInv[(size_t)(kb - 1) * NB * NB + tid];   // the step needs it right after its first barrier
     R lrow[NB];
     const bool upd = tid < kb * NB;                                 // this thread's column of the update
 #pragma unroll
