@@ -802,28 +802,46 @@ __global__ __launch_bounds__(256) void k_chol_step(R* __restrict__ S, R* __restr
     if (tid == 0) atomicMax(status, 1);
     return;
   }
-  // inverse of the diagonal factor (column c by lane c: forward substitution on e_c), kept in LDS: the panel solve
-  // X L_kk^T = T then is a 32x32x32 product X = T * Linv^T on all 256 threads instead of 32 serial substitutions
-  // Linv by 2x2 blocks of 16: L = [A 0; B C]  ->  Linv = [A^-1 0; -C^-1 B A^-1  C^-1].  The two 16x16 inverses run side by side
-  // (lanes 0-15 / 16-31, one column each: a 120-term chain instead of the 528-term chain of a direct 32x32 inverse, which
-  // measured 9 us), the off-diagonal block is two 16x16x16 products on all 256 threads.
+  // inverse of the diagonal factor, kept in LDS: the panel solve X L_kk^T = T then is a 32x32x32 product X = T * Linv^T on all 256
+  // threads instead of 32 serial substitutions.  Linv is built bottom-up by 2x2 blocks, L = [A 0; B C] -> Linv = [A^-1 0; -C^-1 B A^-1  C^-1]:
+  // the four 8x8 diagonal blocks by forward substitution (one column per lane on 32 lanes: a 28-term dependent chain; a direct
+  // 32x32 inverse is a 528-term chain and measured 9 us, two 16x16 ones 2.0 us), then the two 16x16 blocks and the 32x32 block by
+  // two small products each on the whole workgroup.
   if (tid < NB) {
-    const int off = (tid >> 4) * 16, c = tid & 15;
-    R z[16];
+    const int off = (tid >> 3) * 8, c = tid & 7;
+    R z[8];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
+    for (int r = 0; r < 8; r++) {
       R sres = r == c ? 1.0 : 0.0;
 #pragma unroll
-      for (int k = 0; k < 16; k++) if (k < r) sres -= Dg[off + r][off + k] * z[k];
+      for (int k = 0; k < 8; k++) if (k < r) sres -= Dg[off + r][off + k] * z[k];
       z[r] = r < c ? 0.0 : sres * rdiag[off + r];
     }
 #pragma unroll
-    for (int r = 0; r < 16; r++) La[off + r][off + c] = z[r];   // La is free after the update: La = Linv
+    for (int r = 0; r < 8; r++) La[off + r][off + c] = z[r];   // La is free after the update: La = Linv
   }
   CH_CLK(6);
   {
-    const int r = tid >> 4, c = tid & 15;
-    La[r][16 + c] = 0.0;   // upper-right block
+    const int r = tid >> 3, c0 = (tid & 7) * 4;   // zeros above the 8x8 diagonal blocks
+#pragma unroll
+    for (int c = c0; c < c0 + 4; c++) if ((c >> 3) > (r >> 3)) La[r][c] = 0.0;
+  }
+  __syncthreads();
+  {  // 16x16 level, both diagonal blocks at once: p = which block, (r, c) in the 8x8 off-diagonal part
+    const int p16 = (tid >> 6) & 1, r = (tid >> 3) & 7, c = tid & 7, o = 16 * p16;
+    R t1 = 0;
+    if (tid < 128) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) t1 += Dg[o + 8 + r][o + k] * La[o + k][o + c];   // T1 = B A^-1
+      Lb[o + r][c] = t1;
+    }
+    __syncthreads();
+    if (tid < 128) {
+      R m = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) m -= La[o + 8 + r][o + 8 + k] * Lb[o + k][c];     // M = -C^-1 T1
+      La[o + 8 + r][o + c] = m;
+    }
   }
   __syncthreads();
   {
