@@ -201,3 +201,21 @@ def test_device_resident_form_equals_the_host_form():
         assert np.array_equal(d_rx.cpu().numpy().view(np.uint32), rx.view(np.uint32))
         assert np.array_equal(d_depth.cpu().numpy().view(np.uint32), depth.view(np.uint32))
         assert np.array_equal(d_kept.cpu().numpy(), kept) and np.array_equal(d_status.cpu().numpy(), status) and kept.sum() > 0
+
+
+def test_replay_with_and_without_row_lists(oracle_lib, monkeypatch):
+    """The replay kernel reads per-row candidate lists from LDS when they fit and scans every right keypoint's band otherwise
+    (large scale factors, many keypoints); YDORB_STEREO_NO_ROW_LISTS forces the second form.  Same bits either way."""
+    import ydorbslam_amd as y
+    left, right, _ = synth_stereo_pair(640, 480, 41)
+    ex = y.OrbExtractor(1000, max_batch=2)
+    (kl, dl), (kr, dr) = ex.extract_batch(np.stack([left, right]))
+    args = (ex, ex, kl[None], dl[None], [len(kl)], kr[None], dr[None], [len(kr)], BF, B)
+    a = y.OrbMatcher().stereo_matches(*args, left_frames=(0, 1), right_frames=(1, 1))
+    monkeypatch.setenv("YDORB_STEREO_NO_ROW_LISTS", "1")
+    b = y.OrbMatcher().stereo_matches(*args, left_frames=(0, 1), right_frames=(1, 1))
+    monkeypatch.delenv("YDORB_STEREO_NO_ROW_LISTS")
+    _, (orx, odepth, okept, ostatus) = _oracle_pair(oracle_lib, left, right, 1000)
+    for got in (a, b):
+        assert got[2][0] == okept and got[3][0] == ostatus
+        assert np.array_equal(got[0][0].view(np.uint32), orx.view(np.uint32)) and np.array_equal(got[1][0].view(np.uint32), odepth.view(np.uint32))

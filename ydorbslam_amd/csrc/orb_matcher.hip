@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -569,20 +571,26 @@ int ydorb_stereo_matches(ydorb_matcher_t* m, const YdStereoSide* L, const YdSter
   P.capL = L->cap; P.capR = R->cap; P.frameL0 = L->first_frame; P.frameLStep = L->frame_step; P.frameR0 = R->first_frame; P.frameRStep = R->frame_step;
   P.nLevels = vl.nLevels; P.flags = flags; P.bf = bf; P.maxD = bf / b;   // :382
   P.counters = m->stereoCnt.as<int>(); P.keptOut = m->stereoOut.as<int>(); P.statusOut = m->stereoOut.as<int>() + nPairs;
+  // replay form: room for the per-row candidate lists in LDS: every right keypoint covers at most 2*ceil(2*scale)+1 rows
+  size_t ldsReplay = (size_t)R->cap * 8;
+  {
+    const int band = 2 * (int)std::ceil(2.0f * vl.scale[vl.nLevels - 1]) + 2;
+    const size_t entries = (size_t)R->cap * band, bytes = (size_t)R->cap * 8 + sizeof(int) * (2 * (size_t)vl.h[0] + 1) + 2 * entries + 16;
+    const bool noLists = getenv("YDORB_STEREO_NO_ROW_LISTS") != nullptr;   // diagnostic: force the scan form (tests compare the two)
+    if (!noLists && !(flags & YDORB_STEREO_INDEX_BY_KEYPOINT) && bytes <= 120 * 1024 && entries < (1u << 30)) { P.rowLists = (int)entries; ldsReplay = bytes; }
+  }
   HIPCHK(hipMemcpyAsync(m->stereoPar.p, &P, sizeof(P), hipMemcpyHostToDevice, s));
   HIPCHK(hipMemsetAsync(m->stereoCnt.p, 0, sizeof(int) * 4 * nPairs, s));
   HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(P.rightX), 0xBF800000u, nl, s));   // -1.0f, :363-364
   HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(P.depth), 0xBF800000u, nl, s));
   const size_t lds = (size_t)R->cap * 8;
   const StereoDev* dP = m->stereoPar.as<StereoDev>();
-  if (lds > 48 * 1024) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stereo<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stereo<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
+  if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stereo<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (ldsReplay > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stereo<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsReplay));
   if (flags & YDORB_STEREO_INDEX_BY_KEYPOINT)
     hipLaunchKernelGGL(k_stereo<false>, dim3((L->cap + kStereoChunk - 1) / kStereoChunk, nPairs), dim3(256), lds, s, dP);
   else
-    hipLaunchKernelGGL(k_stereo<true>, dim3(1, nPairs), dim3(256), lds, s, dP);
+    hipLaunchKernelGGL(k_stereo<true>, dim3(1, nPairs), dim3(256), ldsReplay, s, dP);
   hipLaunchKernelGGL(k_stereo_outliers, dim3(nPairs), dim3(256), 0, s, m->stereoPar.as<StereoDev>());
   HIPCHK(hipGetLastError());
   if (dev) {

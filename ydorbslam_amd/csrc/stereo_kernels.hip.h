@@ -42,6 +42,7 @@ struct StereoDev {
   float* rightX; float* depth;
   int* counters;   // per pair: [0] measurements kept, [1] of those with block-match minimum 0, [2] status bits, [3] unused
   int* keptOut; int* statusOut;
+  int rowLists;   // replay kernel: LDS entries reserved for per-row candidate lists (0 = scan all right keypoints per step)
 };
 
 struct StereoAcc { int kept, zeros, status; };
@@ -56,7 +57,8 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 // One left keypoint (kx, ky, octave o) matched with the left descriptor row (a0, a1).  Wave-uniform control flow; `complete`
 // says whether the reference's loop body reaches `leftIdx++` (:462).
 __device__ StereoRes stereo_one(const StereoDev& P, int pair, float kx, float ky, int o, uint4 a0, uint4 a1, int nR,
-                                const float* __restrict__ rx, const unsigned* __restrict__ rinfo, unsigned short* cand, int lane) {
+                                const float* __restrict__ rx, const unsigned* __restrict__ rinfo, unsigned short* cand, int lane,
+                                const int* __restrict__ rowStart = nullptr, const unsigned short* __restrict__ rowEnt = nullptr) {
   StereoRes Rz{false, false, false, 0, -1.0f, -1.0f};
   const int row = (int)ky;
   if (!(ky >= 0.0f) || row >= P.h[0]) { Rz.status = 1; return Rz; }   // out-of-range row index at :389 (undefined in the reference)
@@ -77,39 +79,57 @@ __device__ StereoRes stereo_one(const StereoDev& P, int pair, float kx, float ky
       best = min(best, ((unsigned)d << 16) | (unsigned)j);
     }
   };
-  for (int j0 = 0; j0 < nR; j0 += 256) {   // four table rows per lane and trip: their LDS reads are in flight together
-    unsigned inf[4];
-    float x[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int j = min(j0 + 64 * u + lane, nR - 1);
-      inf[u] = rinfo[j];
-      x[u] = rx[j];
+  if (rowStart) {
+    // per-row lists (the reference's vRowIndices, :368-379, built once per pair): the candidates of this row, 64 at a time; list order
+    // does not matter because the winner is the minimum of (distance << 16 | index)
+    const int e0 = rowStart[row], e1 = rowStart[row + 1];
+    any = e1 > e0;
+    for (int e = e0 + lane; e < e1; e += 64) {
+      const int j = rowEnt[e];
+      const int oc = (int)(rinfo[j] >> 24);
+      const float x = rx[j];
+      if (oc >= o - 1 && oc <= o + 1 && x >= xlo && x <= xhi) {
+        const uint4 b0 = *reinterpret_cast<const uint4*>(dr + (size_t)j * 32), b1 = *reinterpret_cast<const uint4*>(dr + (size_t)j * 32 + 16);
+        const int d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
+                      __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+        best = min(best, ((unsigned)d << 16) | (unsigned)j);
+      }
     }
+  } else {
+    for (int j0 = 0; j0 < nR; j0 += 256) {   // four table rows per lane and trip: their LDS reads are in flight together
+      unsigned inf[4];
+      float x[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int j = j0 + 64 * u + lane;
-      const int lo = inf[u] & 0xFFF, hi = (inf[u] >> 12) & 0xFFF, oc = (int)(inf[u] >> 24);
-      const bool inRow = j < nR && row >= lo && row <= hi;
-      any |= inRow;
-      const bool pass = inRow && oc >= o - 1 && oc <= o + 1 && x[u] >= xlo && x[u] <= xhi;
-      const unsigned long long m = __ballot(pass);
-      if (m) {
-        if (pass) cand[cnt + __popcll(m & below)] = (unsigned short)j;
-        cnt += __popcll(m);
-        __builtin_amdgcn_wave_barrier();
-        if (cnt >= 64) {
-          drain(64);
-          const unsigned short keep = cand[64 + lane];
+      for (int u = 0; u < 4; u++) {
+        const int j = min(j0 + 64 * u + lane, nR - 1);
+        inf[u] = rinfo[j];
+        x[u] = rx[j];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int j = j0 + 64 * u + lane;
+        const int lo = inf[u] & 0xFFF, hi = (inf[u] >> 12) & 0xFFF, oc = (int)(inf[u] >> 24);
+        const bool inRow = j < nR && row >= lo && row <= hi;
+        any |= inRow;
+        const bool pass = inRow && oc >= o - 1 && oc <= o + 1 && x[u] >= xlo && x[u] <= xhi;
+        const unsigned long long m = __ballot(pass);
+        if (m) {
+          if (pass) cand[cnt + __popcll(m & below)] = (unsigned short)j;
+          cnt += __popcll(m);
           __builtin_amdgcn_wave_barrier();
-          cand[lane] = keep;
-          __builtin_amdgcn_wave_barrier();
-          cnt -= 64;
+          if (cnt >= 64) {
+            drain(64);
+            const unsigned short keep = cand[64 + lane];
+            __builtin_amdgcn_wave_barrier();
+            cand[lane] = keep;
+            __builtin_amdgcn_wave_barrier();
+            cnt -= 64;
+          }
         }
       }
     }
+    drain(cnt);
   }
-  drain(cnt);
   if (!__any(any) || !(kx >= 0.0f)) return Rz;   // :389
   best = wave_min_u32(best);
   const int bestDist = best == 0xFFFFFFFFu ? 256 : (int)(best >> 16);
@@ -200,6 +220,53 @@ __global__ __launch_bounds__(256) void k_stereo(const StereoDev* __restrict__ Pp
   const int k0 = REPLAY ? 0 : blockIdx.x * kStereoChunk, k1 = REPLAY ? P.capL : min(k0 + kStereoChunk, P.capL);
   if (!REPLAY && k0 >= nL) return;
   stereo_right_table(P, pair, nR, rx, rinfo);
+  // Replay form: the reference's per-row lists (vRowIndices, :368-379) as a CSR in LDS when the host reserved room for them -
+  // a step of the serial walk then reads its row's ~15 candidates instead of scanning every right keypoint's band.
+  int* rowStart = nullptr;
+  unsigned short* rowEnt = nullptr;
+  if (REPLAY && P.rowLists > 0) {
+    const int rows = P.h[0];
+    int* rs = reinterpret_cast<int*>(rinfo + P.capR);          // [rows + 1]
+    int* cur = rs + rows + 1;                                   // [rows] counts, then fill cursors
+    unsigned short* ent = reinterpret_cast<unsigned short*>(cur + rows);
+    __shared__ int rlWave[4];
+    __shared__ int rlTotal;
+    for (int r = tid; r < rows; r += 256) cur[r] = 0;
+    __syncthreads();
+    for (int j = tid; j < nR; j += 256) {
+      const unsigned inf = rinfo[j];
+      const int lo = inf & 0xFFF, hi = (inf >> 12) & 0xFFF;
+      for (int r = lo; r <= hi; r++) atomicAdd(&cur[r], 1);
+    }
+    __syncthreads();
+    {  // exclusive scan of the row counts: contiguous chunk per thread + block scan of the chunk sums
+      const int per = (rows + 255) / 256, r0 = tid * per, r1 = min(r0 + per, rows);
+      int sum = 0;
+      for (int r = r0; r < r1; r++) sum += cur[r];
+      int x = sum;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+      if (lane == 63) rlWave[wave] = x;
+      __syncthreads();
+      int off = x - sum;
+      for (int w = 0; w < wave; w++) off += rlWave[w];
+      for (int r = r0; r < r1; r++) { rs[r] = off; off += cur[r]; }
+      if (tid == 255) { rs[rows] = off; rlTotal = off; }
+      __syncthreads();
+    }
+    if (rlTotal <= P.rowLists) {   // wave-uniform: the lists fit the reserved room (else: scan form)
+      for (int r = tid; r < rows; r += 256) cur[r] = 0;
+      __syncthreads();
+      for (int j = tid; j < nR; j += 256) {
+        const unsigned inf = rinfo[j];
+        const int lo = inf & 0xFFF, hi = (inf >> 12) & 0xFFF;
+        for (int r = lo; r <= hi; r++) ent[rs[r] + atomicAdd(&cur[r], 1)] = (unsigned short)j;
+      }
+      __syncthreads();
+      rowStart = rs;
+      rowEnt = ent;
+    }
+  }
   StereoAcc A{0, 0, 0};
   const KeyPointDev* kl = P.kpsL + (size_t)pair * P.capL;
   const uint4* dl = reinterpret_cast<const uint4*>(P.descL + (size_t)pair * P.capL * 32);
@@ -217,7 +284,7 @@ __global__ __launch_bounds__(256) void k_stereo(const StereoDev* __restrict__ Pp
       const float nkx = kl[kn].x, nky = kl[kn].y;
       const int no = kl[kn].octave;
       const uint4 n0 = dl[2 * sn], n1 = dl[2 * sn + 1];
-      const StereoRes r = stereo_one(P, pair, kx, ky, o, a0, a1, nR, rx, rinfo, candList[wave], lane);
+      const StereoRes r = stereo_one(P, pair, kx, ky, o, a0, a1, nR, rx, rinfo, candList[wave], lane, rowStart, rowEnt);
       if (r.kept && lane == 0) { outRx[s] = r.rx; outDepth[s] = r.depth; }
       A.kept += r.kept; A.zeros += r.zero; A.status |= r.status;
       if (r.complete) { s++; a0 = n0; a1 = n1; }
