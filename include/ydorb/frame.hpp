@@ -29,6 +29,7 @@ int computeStereoMatchesImpl(FrameT& f, int flags = 0, ydorb_matcher_t* m = matc
   f.m_v_rightXcords.assign(f.m_int_keyPointsNum, -1.0f);   // :363-364
   f.m_v_depth.assign(f.m_int_keyPointsNum, -1.0f);
   if (nl == 0 || nr == 0) return 0;
+  if (nl != f.m_int_keyPointsNum) throw std::runtime_error("ydorb: m_int_keyPointsNum differs from m_v_keyPoints.size()");   // frame.cpp:88 sets it so
   cv::Mat dl = f.m_cvMat_descriptors.isContinuous() ? f.m_cvMat_descriptors : f.m_cvMat_descriptors.clone();
   cv::Mat dr = f.m_cvMat_rightDescriptors.isContinuous() ? f.m_cvMat_rightDescriptors : f.m_cvMat_rightDescriptors.clone();
   const int32_t cl = nl, cr = nr;
