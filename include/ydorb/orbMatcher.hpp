@@ -1,5 +1,4 @@
-// Drop-in adapter for YDORBSLAM::OrbMatcher's search-by-projection / search-by-BoW entry points
-// (reference src/orbMatcher.hpp:32-46, src/orbMatcher.cpp:24-239,303-462) on top of the ydorb C ABI.
+// Drop-in adapter for YDORBSLAM::OrbMatcher (reference src/orbMatcher.hpp:24-66, src/orbMatcher.cpp:11-854) on top of the ydorb C ABI.
 //
 // The adapter is a set of templates over the reference's own Frame / KeyFrame / MapPoint types (included by the
 // translation unit that instantiates them), so Tracking / LocalMapping / LoopClosing keep calling
@@ -8,8 +7,8 @@
 //   { return ydorb::adapter::searchByProjectionInLastAndCurrentFrame(ydorb::adapter::matcher(), c, l, th, m_b_isToCheckOrientation); }
 // What stays on the host is exactly the float geometry the reference computes per map point with cv::Mat (projection,
 // radius, level window); the candidate search, Hamming distances, best/second-best, greedy assignment and the rotation
-// histogram run on the GPU.  searchForTriangulation / searchBySim3 / searchByProjectionInSim / fuse* are the "next" rows
-// of SURVEY.md 8(f) and keep the reference's CPU bodies.
+// histogram run on the GPU.  The same holds for the rest of the class: searchForTriangulation, fuseByProjection,
+// fuseBySim3, searchBySim3, searchByProjectionInSim, and for MapPoint::computeDistinctiveDescriptors (distinctiveDescriptorIndices).
 #ifndef YDORB_ADAPTER_ORBMATCHER_HPP
 #define YDORB_ADAPTER_ORBMATCHER_HPP
 
