@@ -9,10 +9,11 @@
 //     6x3 H_pl blocks of its observations in registers (no atomics);
 //   * one workgroup owns a free pose and reduces its 6x6 H_pp and b_p over that pose's observations;
 //   * the Schur complement  S = H_pp + lambda*I - sum_l W_l (H_ll + lambda*I)^-1 W_l^T  is formed directly in a
-//     dense (6K)^2 buffer (K = 100 keyframes -> 2.9 MB, L2-resident) by one thread per (landmark, pose)
-//     pair block, FP64 atomics into the lower triangle;
-//   * the reduced system is factorised by a blocked left-looking dense Cholesky (one launch per 32-column
-//     panel, one workgroup per 32x32 tile) and solved by a single-workgroup blocked substitution;
+//     dense (6K)^2 buffer (K = 100 keyframes -> 2.9 MB, L2-resident): the (landmark, pose pair) items are bucketed by pose pair
+//     once per solve and sorted by landmark, then one workgroup per 6x6 block sums its bucket on the FP64 matrix core - no atomics,
+//     fixed summation order (a solve is bit-reproducible run to run);
+//   * the reduced system is factorised by a blocked right-looking dense Cholesky (one launch per 32-column
+//     panel, one workgroup per 32x32 trailing tile) and solved by a single-workgroup blocked substitution;
 //   * LM control (lambda, accept/reject, chi2 cull) stays on the host exactly as
 //     core/optimization_algorithm_levenberg.cpp:57-148 sequences it.
 #pragma once
