@@ -1,6 +1,6 @@
 // TEST-ONLY: a plain C++ host (no Python, no OpenCV, no torch) on the C ABI of include/ydorb/c_api.h - what the reference's own
 // translation units do once src/orbExtractor.cpp / orbMatcher.cpp / optimizer.cpp forward to the library.
-//   host_roundtrip <in.raw> <w> <h> <out.bin>
+//   host_roundtrip <in.raw> <w> <h> <out.bin>      (and: host_roundtrip ba <problem.bin> <out.bin>, below)
 // reads an 8-bit gray image, extracts it (OrbExtractor(1000, 1.2, 8, 20, 7)), extracts a copy moved by (3, 2) px, matches the two frames
 // with the searchByProjectionInLastAndCurrentFrame rules and writes keypoints, descriptors and the assignment to <out.bin>;
 // tests/test_cpp_host.py compares that file with what the ctypes mirror returns for the same input.
@@ -20,7 +20,45 @@
     }                                                                            \
   } while (0)
 
+// host_roundtrip ba <problem.bin> <out.bin>: Optimizer::localBundleAdjust's flat problem (K, P, E, then poses K x 7 f64, fixed K u8,
+// points P x 3 f64, edge_pose E i32, edge_point E i32, meas E x 3 f64, inv_sigma2 E f64, camera 5 f64) -> poses, points, outlier mask.
+static int runBa(const char* in, const char* out) {
+  FILE* f = std::fopen(in, "rb");
+  if (!f) return 2;
+  int32_t dims[3];
+  if (std::fread(dims, sizeof(dims), 1, f) != 1) return 2;
+  const int K = dims[0], P = dims[1], E = dims[2];
+  std::vector<double> poses((size_t)K * 7), points((size_t)P * 3), meas((size_t)E * 3), info(E), cam(5);
+  std::vector<uint8_t> fixed(K), outlier(E ? E : 1);
+  std::vector<int32_t> ep(E), eq(E);
+  bool ok = std::fread(poses.data(), 8, poses.size(), f) == poses.size() && std::fread(fixed.data(), 1, K, f) == (size_t)K &&
+            std::fread(points.data(), 8, points.size(), f) == points.size() && std::fread(ep.data(), 4, E, f) == (size_t)E &&
+            std::fread(eq.data(), 4, E, f) == (size_t)E && std::fread(meas.data(), 8, meas.size(), f) == meas.size() &&
+            std::fread(info.data(), 8, E, f) == (size_t)E && std::fread(cam.data(), 8, 5, f) == 5;
+  std::fclose(f);
+  if (!ok) { std::fprintf(stderr, "short problem file\n"); return 2; }
+  YdBaProblem prob{K, P, E, poses.data(), fixed.data(), points.data(), ep.data(), eq.data(), meas.data(), info.data(),
+                   cam[0], cam[1], cam[2], cam[3], cam[4], nullptr};
+  YdBaOptions opt;
+  ydorb_ba_default_options(&opt);
+  YdBaResult res;
+  std::memset(&res, 0, sizeof(res));
+  res.edge_outlier = outlier.data();
+  CHECK(ydorb_ba_solve(&prob, &opt, &res));
+  FILE* o = std::fopen(out, "wb");
+  if (!o) return 2;
+  const int32_t head[2] = {res.n_trials, res.n_iterations};
+  std::fwrite(head, sizeof(head), 1, o);
+  std::fwrite(poses.data(), 8, poses.size(), o);
+  std::fwrite(points.data(), 8, points.size(), o);
+  std::fwrite(outlier.data(), 1, E, o);
+  std::fclose(o);
+  std::printf("host_roundtrip ba: %d LM trials, chi2 %.6f\n", res.n_trials, res.n_log ? res.log_chi2[res.n_log - 1] : 0.0);
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc == 4 && std::strcmp(argv[1], "ba") == 0) return runBa(argv[2], argv[3]);
   if (argc != 5) { std::fprintf(stderr, "usage: %s in.raw w h out.bin\n", argv[0]); return 2; }
   const int w = std::atoi(argv[2]), h = std::atoi(argv[3]);
   std::vector<uint8_t> img((size_t)w * h), moved((size_t)w * h);

@@ -61,3 +61,30 @@ def test_cpp_host_equals_ctypes_mirror(tmp_path):
     q["angle"], q["level"], q["flags"] = pka["angle"], pka["octave"], 3
     n, a, _ = y.OrbMatcher(0.9, True).search_by_projection(1, y.FrameView(pkb, pdb, (0.0, float(w), 0.0, float(h)), None), q, pda)
     assert n == nm and np.array_equal(a, assigned) and n > 20
+
+
+@pytest.mark.gpu
+def test_cpp_host_local_bundle_adjust(tmp_path):
+    """Optimizer::localBundleAdjust's flat problem solved from C++; the solver is bit-reproducible, so the result equals the ctypes call's."""
+    import ydorbslam_amd as y
+    from ydorbslam_amd.synth import synth_ba_problem
+    exe = _build(str(tmp_path))
+    p = synth_ba_problem(12, 600, 6, seed=9, outlier_frac=0.05)
+    K, P, E = len(p["poses"]), len(p["points"]), len(p["edge_pose"])
+    inp, out = str(tmp_path / "prob.bin"), str(tmp_path / "ba.bin")
+    with open(inp, "wb") as f:
+        f.write(np.array([K, P, E], np.int32).tobytes())
+        for key, dt in (("poses", np.float64), ("fixed", np.uint8), ("points", np.float64), ("edge_pose", np.int32), ("edge_point", np.int32),
+                        ("meas", np.float64), ("info", np.float64), ("camera", np.float64)):
+            f.write(np.ascontiguousarray(p[key], dt).tobytes())
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(__import__("torch").__file__), "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
+    subprocess.check_call([exe, "ba", inp, out], env=env)
+    buf = open(out, "rb").read()
+    trials, iters = np.frombuffer(buf, np.int32, 2)
+    poses = np.frombuffer(buf, np.float64, K * 7, 8).reshape(K, 7)
+    points = np.frombuffer(buf, np.float64, P * 3, 8 + 56 * K).reshape(P, 3)
+    outlier = np.frombuffer(buf, np.uint8, E, 8 + 56 * K + 24 * P)
+    r = y.Optimizer.local_bundle_adjust(p)
+    assert trials == r["trials"] and iters == r["iterations"]
+    assert poses.tobytes() == r["poses"].tobytes() and points.tobytes() == r["points"].tobytes() and np.array_equal(outlier, r["outlier"])
