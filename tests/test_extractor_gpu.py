@@ -170,3 +170,36 @@ def test_huge_quota_pass_kernel_uses_hbm_node_tables(oracle_lib, monkeypatch):
     ck, cd = OrbExtractorOracle(4000, 1.5, 2, 20, 7).extract(img)
     _same_kps(gk, ck)
     assert np.array_equal(gd, cd) and gpu.debug_read(3, 0) == 1
+
+
+def test_device_path_reports_capacity_errors_once():
+    """The device-resident entry point (ydorb_extract_batch_device, the one the headline bench drives) has no host read-back of its own,
+    so the quad-tree kernels' capacity status must surface in ydorb_extractor_synchronize — and be cleared once reported, so that one
+    overflow does not poison every later call.  Uniform noise gives ~10 % FAST corners: a 1200x1000 frame has > 65 535 candidates
+    on level 0, the limit of the packed 16-bit candidate indices."""
+    import torch
+    import ydorbslam_amd as y
+    rng = np.random.default_rng(0)
+    noise = rng.integers(0, 256, (1000, 1200), dtype=np.uint8)
+    ex = y.OrbExtractor(1000, 1.2, 8, 20, 7)
+    with pytest.raises(y.YdorbError, match="65535"):
+        ex.extract(noise)                                                    # host entry point: reported by the call itself
+    good = synth_frame(1200, 1000, 5)
+    k1, d1 = ex.extract(good)                                                # ... and not sticky
+    assert len(k1) > 500
+    cap = ex.max_keypoints
+    dev = torch.device("cuda", 0)
+    d_img = torch.from_numpy(noise).to(dev)
+    d_kps = torch.zeros((1, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((1, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(1, dtype=torch.int32, device=dev)
+    ex.extract_batch_device(d_img.data_ptr(), 1200, 1000, 1200, 1200 * 1000, 1, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr())
+    with pytest.raises(y.YdorbError, match="65535"):
+        ex.synchronize()
+    ex.synchronize()                                                         # reported once
+    d_img.copy_(torch.from_numpy(good).to(dev))
+    ex.extract_batch_device(d_img.data_ptr(), 1200, 1000, 1200, 1200 * 1000, 1, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr())
+    ex.synchronize()
+    n = int(d_n.item())
+    assert n == len(k1)
+    assert np.array_equal(d_desc[0, :n].cpu().numpy(), d1)

@@ -929,9 +929,30 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const R* __restrict__ L, co
       for (int r = 0; r < NB; r++) sres += lrow[r] * yk[r];
       y[tid] -= sres;
     }
+    // systems wider than the workgroup (n > 1024: global BA with > 170 free keyframes): the remaining columns of the update,
+    // strided, L read after the reduction (no prefetch registers for them)
+    for (int col = tid + 1024; col < kb * NB; col += 1024) {
+      R sres = 0;
+#pragma unroll 8
+      for (int r = 0; r < NB; r++) sres += L[(size_t)(kb * NB + r) * n + col] * yk[r];
+      y[col] -= sres;
+    }
   }
   __syncthreads();
   for (int i = tid; i < n; i += 1024) x[i] = y[i];
+}
+
+// Launch of k_chol_solve: y[n] sits in dynamic LDS, so n is bounded by the CU's 160 KiB (minus the kernel's 8.7 KiB of static LDS)
+// and anything above the 64 KiB default needs the attribute.  Returns false when the system is too wide.
+constexpr int kCholSolveMaxN = (160 * 1024 - 10 * 1024) / (int)sizeof(R) / NB * NB;   // 19 200 rows = 3 200 keyframes
+inline bool launch_chol_solve(hipStream_t s, const R* L, const R* diagInv, int n, const R* yin, const R* bvec, R* x) {
+  if (n > kCholSolveMaxN) return false;
+  const size_t dyn = sizeof(R) * (size_t)n;
+  if (dyn > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess)
+    return false;
+  hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), dyn, s, L, diagInv, n, yin, bvec, x);
+  return true;
 }
 
 // landmark step (block_solver.hpp:420-444): xl = D^-1 (b_l - sum_e Hpl_e^T xp[pose(e)])

@@ -282,10 +282,13 @@ int optimize(Run& R_, int iterations, int stage, bool reuse) {
 
   trace("optimize: pair buckets enqueued");
   double lambda = 0, ni = 2, currentChi = 0;
+  bool lastAccepted = true;
   for (int it = 0; it < iterations && !R_.stopped(); it++) {
     // computeActiveErrors + activeRobustChi2 at the top of an iteration: after the first iteration the state is the trial
     // that was just accepted, whose errors (c.err) and chi2 are already there — same kernel, same inputs, same bits.
-    if (it == 0 && (rc = computeChi2(R_.cur, &currentChi, false))) return rc;
+    // A trial can also end rejected without terminating the loop (rho = NaN: `rho < 0` and `rho == 0` are both false); then err
+    // and chi2 belong to the rejected state and are recomputed on the kept one, as g2o does at the top of every iteration.
+    if ((it == 0 || !lastAccepted) && (rc = computeChi2(R_.cur, &currentChi, false))) return rc;
     {  // buildSystem
       PhaseTimer t(R_, PH_BUILD);
       hipLaunchKernelGGL(k_build_points, dim3((nL + 127) / 128), dim3(128), 0, s, Ed, c.ptStart.as<int>(), nL, c.poses[R_.cur].as<double>(),
@@ -328,10 +331,14 @@ int optimize(Run& R_, int iterations, int stage, bool reuse) {
         for (int kb = 0; kb < nb; kb++)
           hipLaunchKernelGGL(k_chol_step, dim3((nb - kb) * (nb - kb + 1) / 2 + (kb > 0)), dim3(256), 0, s, dS, c.diagL.as<double>(), c.diagInv.as<double>(), n, kb,
                              c.status.as<int>(), dbs, c.yv.as<double>());
-        hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), sizeof(double) * n, s, dS, c.diagInv.as<double>(), n, c.yv.as<double>(), dbs, c.xp.as<double>());
+        if (!launch_chol_solve(s, dS, c.diagInv.as<double>(), n, c.yv.as<double>(), dbs, c.xp.as<double>())) {
+          set_error("reduced camera system of %d rows is wider than the solve kernel's LDS (max %d)", n, kCholSolveMaxN);
+          return YDORB_ERR_UNSUPPORTED;
+        }
         hipLaunchKernelGGL(k_backsub, dim3((nL + 127) / 128), dim3(128), 0, s, Ed, c.ptStart.as<int>(), nL, c.Hpl.as<double>(), c.Dinv.as<double>(),
                            c.bl.as<double>(), c.xp.as<double>(), c.xl.as<double>());
         t.stop();
+        HIPCHK(hipGetLastError());
       }
       {
         PhaseTimer t(R_, PH_UPDATE);
@@ -364,7 +371,9 @@ int optimize(Run& R_, int iterations, int stage, bool reuse) {
         ni = 2;
         currentChi = tempChi;
         R_.cur = nxt;  // discardTop(): keep the updated estimate
+        lastAccepted = true;
       } else {
+        lastAccepted = false;
         lambda *= ni;
         ni *= 2;  // pop(): the previous estimate is still in poses[cur]
         if (!std::isfinite(lambda)) { qmax++; R_.res->n_trials++; break; }
@@ -630,7 +639,11 @@ int ydorb_ba_dense_solve(int32_t device, const double* A, int32_t n0, const doub
   HIPCHK(hipMemcpy(db, hb.data(), sizeof(double) * n, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(dst, 0, sizeof(int) * 2));
   for (int kb = 0; kb < nb; kb++) hipLaunchKernelGGL(k_chol_step, dim3((nb - kb) * (nb - kb + 1) / 2 + (kb > 0)), dim3(256), 0, 0, dA, dD, dI, n, kb, dst, db, dy);
-  hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), sizeof(double) * n, 0, dA, dI, n, dy, db, dx);
+  if (!launch_chol_solve(0, dA, dI, n, dy, db, dx)) {
+    (void)hipFree(dA); (void)hipFree(dD); (void)hipFree(dI); (void)hipFree(db); (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dst);
+    set_error("system of %d rows is wider than the solve kernel's LDS (max %d)", n, kCholSolveMaxN);
+    return YDORB_ERR_UNSUPPORTED;
+  }
   HIPCHK(hipGetLastError());
   std::vector<double> hx(n);
   int hst[2];

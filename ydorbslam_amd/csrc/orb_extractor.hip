@@ -65,6 +65,7 @@ struct ydorb_extractor {
   uint8_t* d_nodeScratch = nullptr;  // HBM node tables of the levels whose quota does not fit the LDS (usually none)
   uint8_t* d_needPass = nullptr;   // [frame][level]: 1 = the flat quad-tree kernel left the unit to the pass kernel
   int *d_lvlCount = nullptr, *d_status = nullptr, *d_nOut = nullptr;
+  hipStream_t lastStream = nullptr;   // stream of the last enqueue (a caller's stream on the device-resident path)
   int *d_lvlMaxN = nullptr, *h_lvlMaxN = nullptr;   // largest candidate count seen per level (device max, copied back after every call)
   float* d_lvlAngle = nullptr;
   CellDev* d_cells = nullptr;
@@ -427,6 +428,7 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   HIPCHK(hipMemcpyAsync(e->h_lvlMaxN, e->d_lvlMaxN, sizeof(int) * kMaxLevels, hipMemcpyDeviceToHost, s));
   HIPCHK(hipGetLastError());
   e->lastFrames = nFrames;
+  e->lastStream = s;
   return YDORB_OK;
 }
 
@@ -570,8 +572,16 @@ int ydorb_extract_batch_device(ydorb_extractor_t* e, const uint8_t* d_img, int32
 
 int ydorb_extractor_synchronize(ydorb_extractor_t* e) {
   if (!e) { set_error("null handle"); return YDORB_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(e->cfg.device));
   HIPCHK(hipStreamSynchronize(e->stream));
-  return YDORB_OK;
+  if (e->lastStream && e->lastStream != e->stream) HIPCHK(hipStreamSynchronize(e->lastStream));
+  if (!e->d_status) return YDORB_OK;
+  // the device-resident entry point reports capacity errors of its quad-tree kernels here (the host entry point reads the
+  // same word itself): candidates > 65535 in a level, node-table overflow, a level the pass kernel cannot take
+  HIPCHK(hipMemcpy(e->h_status, e->d_status, sizeof(int), hipMemcpyDeviceToHost));
+  const int rc = checkStatus(e);
+  if (rc) HIPCHK(hipMemset(e->d_status, 0, sizeof(int)));   // reported once; later calls start clean
+  return rc;
 }
 
 int ydorb_extract_batch(ydorb_extractor_t* e, const uint8_t* img, int32_t w, int32_t h, int32_t stride, size_t frame_stride,
@@ -598,7 +608,10 @@ int ydorb_extract_batch(ydorb_extractor_t* e, const uint8_t* img, int32_t w, int
   HIPCHK(hipStreamSynchronize(e->stream));
   collectProfile(e);
   rc = checkStatus(e);
-  if (rc) return rc;
+  if (rc) {
+    HIPCHK(hipMemset(e->d_status, 0, sizeof(int)));   // reported once; the next call starts clean
+    return rc;
+  }
   for (int f = 0; f < n_frames; f++) {
     const int n = e->h_nOut[f];
     if (n > cap) { set_error("frame %d has %d keypoints, caller capacity %d", f, n, cap); return YDORB_ERR_CAPACITY; }

@@ -30,6 +30,17 @@ namespace {
     }                                                                                         \
   } while (0)
 
+// k_grid_build keeps one 16-bit cell id per keypoint in dynamic LDS beside ~12 KiB of static tables: frames with more than
+// ~26 k keypoints need the kernel's dynamic-LDS limit raised (the 16-bit index format allows up to 65 535).
+int launchGridBuild(int nFrames, int cap, hipStream_t s, const FrameDev* frames) {
+  const size_t dyn = sizeof(int16_t) * (size_t)std::max(cap, 0);
+  if (dyn > 48 * 1024)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+  hipLaunchKernelGGL(k_grid_build, dim3(nFrames), dim3(256), dyn, s, frames, cap);
+  HIPCHK(hipGetLastError());
+  return YDORB_OK;
+}
+
 struct Buf {
   void* p = nullptr;
   size_t cap = 0;
@@ -121,8 +132,7 @@ int uploadFrame(ydorb_matcher* m, const YdFrameView* fv, FrameDev* out) {
   *out = makeFrame(*fv, m->kps.as<KeyPointDev>(), m->desc.as<uint8_t>(), fv->right_x ? m->rightX.as<float>() : nullptr,
                    m->cellStart.as<int>(), m->cellIdx.as<int>(), m->sortedKp.as<float4>(), m->sortedDesc.as<uint8_t>());
   HIPCHK(hipMemcpyAsync(m->frames.p, out, sizeof(FrameDev), hipMemcpyHostToDevice, m->stream));
-  hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), sizeof(int16_t) * n, m->stream, m->frames.as<FrameDev>(), n);
-  return YDORB_OK;
+  return launchGridBuild(1, n, m->stream, m->frames.as<FrameDev>());
 }
 
 }  // namespace
@@ -675,7 +685,7 @@ int ydorb_match_consecutive_device(ydorb_matcher_t* m, const YdKeyPoint* d_kps, 
   if (prof) HIPCHK(hipEventRecord(m->ev[0], s));
   hipLaunchKernelGGL(k_queries_from_keypoints, dim3((cap + 255) / 256, nCalls), dim3(256), 0, s, reinterpret_cast<const KeyPointDev*>(d_kps), d_n, cap,
                      aff, th, m->sf.as<float>(), nLevels, minX, maxX, minY, maxY, m->queries.as<QueryDev>());
-  hipLaunchKernelGGL(k_grid_build, dim3(nFrames), dim3(256), sizeof(int16_t) * cap, s, m->frames.as<FrameDev>(), cap);
+  { const int rcg = launchGridBuild(nFrames, cap, s, m->frames.as<FrameDev>()); if (rcg) return rcg; }
   if (prof) HIPCHK(hipEventRecord(m->ev[1], s));
   hipLaunchKernelGGL(k_gather_projection, dim3((cap + 3) / 4, nCalls), dim3(256), 0, s, m->calls.as<CallDev>(), m->frames.as<FrameDev>(), cap,
                      m->pool.as<uint32_t>(), m->heads.as<unsigned>(), (unsigned)poolPerCall, m->misc.as<int>() + 1);
