@@ -276,6 +276,21 @@ int ydorb_match_consecutive_device(ydorb_matcher_t* h, const YdKeyPoint* d_kps, 
                                    int32_t cap, int32_t n_frames, int32_t width, int32_t height, float th,
                                    const float* scale_factors, int32_t n_levels, const float* d_affine, int32_t check_orientation,
                                    int32_t* d_assigned, int32_t* d_counts, void* stream);
+/* The same search for an explicit list of (query frame, target frame) pairs over two device-resident frame sets (which may be the
+ * same set): pair p searches the keypoints of queries[pairs[2p]] in targets[pairs[2p+1]].  This is the form the multi-GPU path
+ * uses after the all-gather of every rank's [keypoints | descriptors | count] records: targets = the gathered set of all ranks,
+ * queries = the frames whose successor this rank owns; greedy acceptance stays with the owner of the target frame.
+ * `pairs` is a host array; both sets must use the same cap.  d_assigned: int32 [n_pairs][cap] indexed by target keypoint,
+ * d_counts: int32 [n_pairs], d_affine: [n_pairs][6] or NULL.  Asynchronous on `stream` (or the matcher's own). */
+typedef struct YdFrameSetDev {
+  const YdKeyPoint* d_kps;  /* [n_frames][cap] */
+  const uint8_t* d_desc;    /* [n_frames][cap][32] */
+  const int32_t* d_n;       /* [n_frames] */
+  int32_t n_frames, cap;
+} YdFrameSetDev;
+int ydorb_match_pairs_device(ydorb_matcher_t* h, const YdFrameSetDev* queries, const YdFrameSetDev* targets, const int32_t* pairs,
+                             int32_t n_pairs, int32_t width, int32_t height, float th, const float* scale_factors, int32_t n_levels,
+                             const float* d_affine, int32_t check_orientation, int32_t* d_assigned, int32_t* d_counts, void* stream);
 int ydorb_matcher_synchronize(ydorb_matcher_t* h);
 /* average device ms of grid build / gather / resolve over calls since enabling (HIP events on the launch stream) */
 int ydorb_matcher_set_profiling(ydorb_matcher_t* h, int32_t on);

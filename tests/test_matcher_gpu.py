@@ -7,16 +7,22 @@ from helpers import bow_nodes, feature_vector, projection_queries, shifted_pair
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def scene(oracle_lib):
+# BASELINE.json configs 2, 3 and 4: the grid bounds, the number of keypoints per cell and the index ranges differ with the size
+SIZES = [(640, 480, 1000), (1241, 376, 2000), (752, 480, 1000)]
+
+
+@pytest.fixture(scope="module", params=SIZES, ids=["C2-640x480", "C3-1241x376-N2000", "C4-752x480"])
+def scene(oracle_lib, request):
     from oracle.orb_oracle import OrbExtractorOracle
-    ex = OrbExtractorOracle(1000)
+    w, h, nf = request.param
+    ex = OrbExtractorOracle(nf)
     out = []
     for idx, (dx, dy) in enumerate([(5, -3), (-7, 4)]):
-        a, b = shifted_pair(640, 480, 50 + idx, dx, dy)
+        a, b = shifted_pair(w, h, 50 + idx, dx, dy)
         ka, da = ex.extract(a)
         kb, db = ex.extract(b)
-        out.append(dict(ka=ka, da=da, kb=kb, db=db, dx=dx, dy=dy, sf=ex.tables()["scale"]))
+        out.append(dict(ka=ka, da=da, kb=kb, db=db, dx=dx, dy=dy, sf=ex.tables()["scale"], w=w, h=h,
+                        bounds=(0.0, float(w), 0.0, float(h))))
     return out
 
 
@@ -35,14 +41,14 @@ def test_descriptor_distance(oracle_lib, scene):
 def test_keypoints_in_area(oracle_lib, scene):
     import ydorbslam_amd as y
     s = scene[0]
-    bounds = (0.0, 640.0, 0.0, 480.0)
+    bounds = s["bounds"]
     fo = oracle_lib.FrameOracle(s["kb"], s["db"], bounds)
     fg = y.FrameView(s["kb"], s["db"], bounds)
     m = y.OrbMatcher()
     rng = np.random.default_rng(3)
     total = 0
     for _ in range(60):
-        x, yy, r = float(rng.uniform(-20, 660)), float(rng.uniform(-20, 500)), float(rng.uniform(2, 120))
+        x, yy, r = float(rng.uniform(-20, s["w"] + 20)), float(rng.uniform(-20, s["h"] + 20)), float(rng.uniform(2, 120))
         lo, hi = [(-1, -1), (0, 3), (2, -1), (1, 2)][int(rng.integers(0, 4))]
         ref = fo.keypoints_in_area(np.float32(x), np.float32(yy), np.float32(r), lo, hi)
         got = m.keypoints_in_area(fg, np.float32(x), np.float32(yy), np.float32(r), lo, hi)
@@ -56,7 +62,7 @@ def test_keypoints_in_area(oracle_lib, scene):
 def test_search_by_projection(oracle_lib, scene, mode, stereo):
     import ydorbslam_amd as y
     for si, s in enumerate(scene):
-        bounds = (0.0, 640.0, 0.0, 480.0)
+        bounds = s["bounds"]
         rng = np.random.default_rng(100 * mode + si)
         right = None
         if stereo:
@@ -94,15 +100,16 @@ def test_search_by_bow(oracle_lib, scene, mode):
         assert n_ref > 20
 
 
-def test_consecutive_device_matches_host_call(oracle_lib):
+@pytest.mark.parametrize("W,H,NF", SIZES)
+def test_consecutive_device_matches_host_call(oracle_lib, W, H, NF):
     """The device-resident streaming search equals per-pair mode-1 searches built on the host (and so the oracle)."""
     import torch
     import ydorbslam_amd as y
     from ydorbslam_amd.synth import synth_frame
-    F, W, H = 4, 640, 480
+    F = 4
     base = synth_frame(W + 32, H + 32, 60)
     imgs = np.stack([np.ascontiguousarray(base[16 + 2 * i:16 + 2 * i + H, 16 + 3 * i:16 + 3 * i + W]) for i in range(F)])
-    ex = y.OrbExtractor(1000, max_batch=F)
+    ex = y.OrbExtractor(NF, max_batch=F)
     cap = ex.max_keypoints
     dev = torch.device("cuda:0")
     d_img = torch.from_numpy(imgs).to(dev)
@@ -120,22 +127,50 @@ def test_consecutive_device_matches_host_call(oracle_lib):
     n = d_n.cpu().numpy()
     kps = d_kps.cpu().numpy().view(np.uint8).reshape(F, cap, 28).view(y.KP_DTYPE).reshape(F, cap)
     desc = d_desc.cpu().numpy()
-    assigned = d_assigned.cpu().numpy()
-    counts = d_counts.cpu().numpy()
     bounds = (0.0, float(W), 0.0, float(H))
-    for f in range(F - 1):
-        ka, kb = kps[f, :n[f]], kps[f + 1, :n[f + 1]]
-        q = np.zeros(n[f], y.QUERY_DTYPE)
-        q["u"], q["v"] = ka["x"], ka["y"]
-        q["r"] = (np.float32(15.0) * sf[ka["octave"]]).astype(np.float32)
-        q["min_level"], q["max_level"] = ka["octave"] - 1, ka["octave"] + 1
-        q["angle"], q["level"] = ka["angle"], ka["octave"]
-        q["flags"] = np.where((q["u"] >= 0) & (q["u"] < W) & (q["v"] >= 0) & (q["v"] < H), 3, 0)
-        fo = oracle_lib.FrameOracle(kb, desc[f + 1, :n[f + 1]], bounds)
-        n_ref, a_ref, _ = fo.search_by_projection(1, q, desc[f, :n[f]], 0.9, True)
-        assert counts[f] == n_ref
-        assert np.array_equal(assigned[f, :n[f + 1]], a_ref)
-        assert n_ref > 20  # (few survive: frame.cpp:353 offers only |dx| > r candidates, then the 3-bin histogram cull)
+
+    def check(pairs, assigned, counts, affine=None, floor=20):
+        for c, (qf, tf) in enumerate(pairs):
+            ka, kb = kps[qf, :n[qf]], kps[tf, :n[tf]]
+            q = np.zeros(n[qf], y.QUERY_DTYPE)
+            if affine is None:
+                q["u"], q["v"] = ka["x"], ka["y"]
+            else:   # single IEEE float operations in the kernel's order: (a0*x + a1*y) + a2
+                A = affine[c].astype(np.float32)
+                q["u"] = (A[0] * ka["x"] + A[1] * ka["y"]) + A[2]
+                q["v"] = (A[3] * ka["x"] + A[4] * ka["y"]) + A[5]
+            q["r"] = (np.float32(15.0) * sf[ka["octave"]]).astype(np.float32)
+            q["min_level"], q["max_level"] = ka["octave"] - 1, ka["octave"] + 1
+            q["angle"], q["level"] = ka["angle"], ka["octave"]
+            q["flags"] = np.where((q["u"] >= 0) & (q["u"] < W) & (q["v"] >= 0) & (q["v"] < H), 3, 0)
+            fo = oracle_lib.FrameOracle(kb, desc[tf, :n[tf]], bounds)
+            n_ref, a_ref, _ = fo.search_by_projection(1, q, desc[qf, :n[qf]], 0.9, True)
+            assert counts[c] == n_ref
+            assert np.array_equal(assigned[c, :n[tf]], a_ref)
+            assert n_ref > floor  # (few survive: frame.cpp:353 offers only |dx| > r candidates, then the 3-bin histogram cull)
+
+    check([(f, f + 1) for f in range(F - 1)], d_assigned.cpu().numpy(), d_counts.cpu().numpy())
+    # explicit pair list over two frame sets (the multi-GPU form: targets = an all-gathered set): any order, a frame used twice,
+    # backward pairs, and a per-pair position prediction
+    pairs = [(2, 0), (0, 3), (3, 1), (1, 2), (0, 1)]
+    rng = np.random.default_rng(5)
+    aff = np.tile(np.array([1, 0, 0, 0, 1, 0], np.float32), (len(pairs), 1))
+    aff[:, 2] = rng.uniform(-6, 6, len(pairs)); aff[:, 5] = rng.uniform(-6, 6, len(pairs))
+    aff[:, 1] = rng.uniform(-0.02, 0.02, len(pairs)); aff[:, 3] = -aff[:, 1]
+    d_aff = torch.from_numpy(aff).to(dev)
+    d_assigned2 = torch.zeros((len(pairs), cap), dtype=torch.int32, device=dev)
+    d_counts2 = torch.zeros(len(pairs), dtype=torch.int32, device=dev)
+    fs = (d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), F, cap)
+    m.match_pairs_device(fs, fs, pairs, W, H, 15.0, sf, d_assigned2.data_ptr(), d_counts2.data_ptr(), d_aff.data_ptr())
+    m.synchronize()
+    check(pairs, d_assigned2.cpu().numpy(), d_counts2.cpu().numpy(), aff, floor=0)
+    # queries and targets in different buffers (a copy of the set): same answers
+    t_kps, t_desc, t_n = d_kps.clone(), d_desc.clone(), d_n.clone()
+    d_assigned3 = torch.zeros_like(d_assigned2); d_counts3 = torch.zeros_like(d_counts2)
+    m.match_pairs_device(fs, (t_kps.data_ptr(), t_desc.data_ptr(), t_n.data_ptr(), F, cap), pairs, W, H, 15.0, sf, d_assigned3.data_ptr(),
+                         d_counts3.data_ptr(), d_aff.data_ptr())
+    m.synchronize()
+    assert torch.equal(d_assigned2, d_assigned3) and torch.equal(d_counts2, d_counts3)
 
 
 @pytest.mark.parametrize("stereo_only", [False, True])
@@ -173,7 +208,7 @@ def test_fuse_search(oracle_lib, scene, stereo):
     import ydorbslam_amd as y
     total = 0
     for si, s in enumerate(scene):
-        bounds = (0.0, 640.0, 0.0, 480.0)
+        bounds = s["bounds"]
         rng = np.random.default_rng(300 + si)
         kb = s["kb"]
         right = np.where(rng.random(len(kb)) > 0.4, kb["x"] - 20 + rng.normal(0, 0.5, len(kb)), -1).astype(np.float32) if stereo else None
@@ -200,7 +235,7 @@ def test_search_by_projection_in_sim_and_fuse_by_sim3(oracle_lib, scene):
     import ydorbslam_amd as y
     total = 0
     for si, s in enumerate(scene):
-        bounds = (0.0, 640.0, 0.0, 480.0)
+        bounds = s["bounds"]
         rng = np.random.default_rng(700 + si)
         kb = s["kb"]
         for th in (0.8, 1.5, 4.0):

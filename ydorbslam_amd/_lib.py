@@ -68,6 +68,7 @@ SYMBOLS = {
     "ydorb_vocabulary_transform": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "ydorb_stereo_matches": (C.c_int, [_VP, _VP, _VP, _I, C.c_float, C.c_float, _I, _VP, _VP, _VP, _VP, _VP]),
     "ydorb_match_consecutive_device": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, C.c_float, _VP, _I, _VP, _I, _VP, _VP, _VP]),
+    "ydorb_match_pairs_device": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, C.c_float, _VP, _I, _VP, _I, _VP, _VP, _VP]),
     "ydorb_matcher_synchronize": (C.c_int, [_VP]),
     "ydorb_matcher_set_profiling": (C.c_int, [_VP, _I]),
     "ydorb_matcher_stage_times": (C.c_int, [_VP, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_I)]),
@@ -107,6 +108,10 @@ class YdBaResult(C.Structure):
                 ("log_lambda", C.c_double * 32), ("log_trials", _I * 32), ("log_stage", _I * 32), ("edge_outlier", _VP),
                 ("ms_total", C.c_float), ("ms_errors", C.c_float), ("ms_build", C.c_float), ("ms_schur", C.c_float),
                 ("ms_solve", C.c_float), ("ms_update", C.c_float)]
+
+
+class YdFrameSetDev(C.Structure):
+    _fields_ = [("d_kps", _VP), ("d_desc", _VP), ("d_n", _VP), ("n_frames", _I), ("cap", _I)]
 
 
 class YdFrameView(C.Structure):

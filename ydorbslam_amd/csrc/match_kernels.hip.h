@@ -128,6 +128,7 @@ struct CallDev {          // one search call (one target frame, one ordered quer
   float ratio;
   int orbDist, checkOri;
   float invSigma2[8];     // mode 6: the keyframe's m_v_invScaleFactorSquares
+  const KeyPointDev* qkps; // device-resident pair form: the query frame's keypoints (k_queries_from_keypoints builds `queries` from them)
 };
 __device__ __forceinline__ int call_nq(const CallDev& C) { return C.nqPtr ? *C.nqPtr : C.nq; }
 
@@ -523,17 +524,17 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
 // last-frame keypoint is its own position moved by a per-pair 2x3 affine map (identity = constant-position
 // motion model); window th * scaleFactor[octave], level window octave-1..octave+1 — the non-forward /
 // non-backward branch of orbMatcher.cpp:95-101.
-__global__ __launch_bounds__(256) void k_queries_from_keypoints(const KeyPointDev* __restrict__ kps, const int* __restrict__ nPtr,
-                                                                int cap, const float* __restrict__ affine, float th,
+__global__ __launch_bounds__(256) void k_queries_from_keypoints(const CallDev* __restrict__ calls, int cap, const float* __restrict__ affine, float th,
                                                                 const float* __restrict__ scaleFactors, int nLevels,
-                                                                float minX, float maxX, float minY, float maxY,
-                                                                QueryDev* __restrict__ out) {
+                                                                float minX, float maxX, float minY, float maxY) {
   const int f = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= cap) return;
+  const KeyPointDev* __restrict__ kps = calls[f].qkps;
+  QueryDev* __restrict__ out = const_cast<QueryDev*>(calls[f].queries);
   QueryDev Q{};
-  if (i < nPtr[f]) {
-    const KeyPointDev kp = kps[(size_t)f * cap + i];
+  if (i < *calls[f].nqPtr) {
+    const KeyPointDev kp = kps[i];
     const float* A = affine + (size_t)f * 6;
     Q.u = __fadd_rn(__fadd_rn(__fmul_rn(A[0], kp.x), __fmul_rn(A[1], kp.y)), A[2]);
     Q.v = __fadd_rn(__fadd_rn(__fmul_rn(A[3], kp.x), __fmul_rn(A[4], kp.y)), A[5]);
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(256) void k_queries_from_keypoints(const KeyPointDe
     const bool inImage = Q.u >= minX && Q.u < maxX && Q.v >= minY && Q.v < maxY;  // Frame::isInImage, frame.cpp:291-294
     Q.flags = inImage ? 3 : 0;
   }
-  out[(size_t)f * cap + i] = Q;
+  out[i] = Q;
 }
 
 }  // namespace ydorb

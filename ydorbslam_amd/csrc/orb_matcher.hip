@@ -77,6 +77,9 @@ struct ydorb_matcher {
   // cached descriptors of the last batched launch (re-uploaded only when they change)
   std::vector<FrameDev> hFrames;
   std::vector<CallDev> hCalls;
+  float hSf[8] = {0};
+  bool hIdentAffine = false;
+  std::vector<int32_t> consecPairs;
   bool profiling = false;
   hipEvent_t ev[MS_COUNT + 1]{};
   double stageMs[MS_COUNT]{};
@@ -618,17 +621,23 @@ int ydorb_stereo_matches(ydorb_matcher_t* m, const YdStereoSide* L, const YdSter
   return YDORB_OK;
 }
 
-int ydorb_match_consecutive_device(ydorb_matcher_t* m, const YdKeyPoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int32_t cap,
-                                   int32_t nFrames, int32_t width, int32_t height, float th, const float* scaleFactors, int32_t nLevels,
-                                   const float* d_affine, int32_t checkOri, int32_t* d_assigned, int32_t* d_counts, void* stream) {
-  if (!m || !d_kps || !d_desc || !d_n || !d_assigned || !d_counts || !scaleFactors || cap < 1 || cap > 65535 || nFrames < 2 || nLevels < 1 ||
-      nLevels > 8 || width < 1 || height < 1) {
+int ydorb_match_pairs_device(ydorb_matcher_t* m, const YdFrameSetDev* Q, const YdFrameSetDev* T, const int32_t* pairs, int32_t nCalls,
+                             int32_t width, int32_t height, float th, const float* scaleFactors, int32_t nLevels, const float* d_affine,
+                             int32_t checkOri, int32_t* d_assigned, int32_t* d_counts, void* stream) {
+  if (!m || !Q || !T || !pairs || !Q->d_kps || !Q->d_desc || !Q->d_n || !T->d_kps || !T->d_desc || !T->d_n || !d_assigned || !d_counts || !scaleFactors ||
+      Q->cap < 1 || Q->cap > 65535 || T->cap != Q->cap || Q->n_frames < 1 || T->n_frames < 1 || nCalls < 1 || nLevels < 1 || nLevels > 8 || width < 1 ||
+      height < 1) {
     set_error("invalid argument");
     return YDORB_ERR_INVALID_ARG;
   }
+  for (int c = 0; c < nCalls; c++)
+    if (pairs[2 * c] < 0 || pairs[2 * c] >= Q->n_frames || pairs[2 * c + 1] < 0 || pairs[2 * c + 1] >= T->n_frames) {
+      set_error("pair %d references a frame out of range", c);
+      return YDORB_ERR_INVALID_ARG;
+    }
   HIPCHK(hipSetDevice(m->device));
   hipStream_t s = stream ? (hipStream_t)stream : m->stream;
-  const int nCalls = nFrames - 1;
+  const int cap = Q->cap, nFrames = T->n_frames;
   const size_t poolPerCall = (size_t)cap * kSlot + (size_t)cap * 16;  // fixed slots + overflow region
   int rc;
   if ((rc = m->queries.ensure(sizeof(QueryDev) * (size_t)cap * nCalls)) || (rc = m->taken.ensure((size_t)cap * nCalls)) ||
@@ -644,17 +653,19 @@ int ydorb_match_consecutive_device(ydorb_matcher_t* m, const YdKeyPoint* d_kps, 
   const float minX = 0.f, minY = 0.f, maxX = (float)width, maxY = (float)height;  // Frame::computeImageBounds without distortion
   for (int f = 0; f < nFrames; f++) {
     FrameDev F{};
-    F.kps = reinterpret_cast<const KeyPointDev*>(d_kps) + (size_t)f * cap; F.desc = d_desc + (size_t)f * cap * 32; F.rightX = nullptr;
-    F.nPtr = d_n + f; F.n = 0; F.minX = minX; F.minY = minY;
+    F.kps = reinterpret_cast<const KeyPointDev*>(T->d_kps) + (size_t)f * cap; F.desc = T->d_desc + (size_t)f * cap * 32; F.rightX = nullptr;
+    F.nPtr = T->d_n + f; F.n = 0; F.minX = minX; F.minY = minY;
     F.gridWInv = static_cast<float>(kGridCols) / (maxX - minX); F.gridHInv = static_cast<float>(kGridRows) / (maxY - minY);
     F.cellStart = m->cellStart.as<int>() + (size_t)f * (kGridCells + 1); F.cellIdx = m->cellIdx.as<int>() + (size_t)f * cap;
     F.sortedKp = m->sortedKp.as<float4>() + (size_t)f * cap; F.sortedDesc = m->sortedDesc.as<uint8_t>() + (size_t)f * cap * 32;
     hf[f] = F;
   }
   for (int c = 0; c < nCalls; c++) {
+    const int qf = pairs[2 * c], tf = pairs[2 * c + 1];
     CallDev C{};
-    C.frame = c + 1; C.tkps = hf[c + 1].kps; C.qAngle = nullptr; C.queries = m->queries.as<QueryDev>() + (size_t)c * cap;
-    C.qdesc = d_desc + (size_t)c * cap * 32; C.nqPtr = d_n + c; C.nq = 0; C.qInfo = m->qInfo.as<int2>() + (size_t)c * cap;
+    C.frame = tf; C.tkps = hf[tf].kps; C.qAngle = nullptr; C.queries = m->queries.as<QueryDev>() + (size_t)c * cap;
+    C.qkps = reinterpret_cast<const KeyPointDev*>(Q->d_kps) + (size_t)qf * cap;
+    C.qdesc = Q->d_desc + (size_t)qf * cap * 32; C.nqPtr = Q->d_n + qf; C.nq = 0; C.qInfo = m->qInfo.as<int2>() + (size_t)c * cap;
     C.taken = m->taken.as<uint8_t>() + (size_t)c * cap; C.assigned = d_assigned + (size_t)c * cap; C.matchQ = m->matchQ.as<int>() + (size_t)c * cap;
     C.count = d_counts + c; C.mode = 1; C.ratio = 0.9f; C.orbDist = 0; C.checkOri = checkOri;
     hc[c] = C;
@@ -662,11 +673,13 @@ int ydorb_match_consecutive_device(ydorb_matcher_t* m, const YdKeyPoint* d_kps, 
   float hsf[8] = {0};
   for (int l = 0; l < nLevels; l++) hsf[l] = scaleFactors[l];
   const bool same = m->hFrames.size() == hf.size() && m->hCalls.size() == hc.size() && !memcmp(m->hFrames.data(), hf.data(), sizeof(FrameDev) * hf.size()) &&
-                    !memcmp(m->hCalls.data(), hc.data(), sizeof(CallDev) * hc.size());
+                    !memcmp(m->hCalls.data(), hc.data(), sizeof(CallDev) * hc.size()) && !memcmp(m->hSf, hsf, sizeof(hsf)) && m->hIdentAffine == !d_affine;
   if (!same) {
     HIPCHK(hipStreamSynchronize(s));
     m->hFrames = hf;
     m->hCalls = hc;
+    memcpy(m->hSf, hsf, sizeof(hsf));
+    m->hIdentAffine = !d_affine;
     HIPCHK(hipMemcpy(m->frames.p, m->hFrames.data(), sizeof(FrameDev) * nFrames, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(m->calls.p, m->hCalls.data(), sizeof(CallDev) * nCalls, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(m->sf.p, hsf, sizeof(hsf), hipMemcpyHostToDevice));
@@ -683,8 +696,8 @@ int ydorb_match_consecutive_device(ydorb_matcher_t* m, const YdKeyPoint* d_kps, 
   HIPCHK(hipMemsetAsync(m->taken.p, 0, (size_t)cap * nCalls, s));
   HIPCHK(hipMemsetAsync(d_assigned, 0xFF, sizeof(int) * (size_t)cap * nCalls, s));
   if (prof) HIPCHK(hipEventRecord(m->ev[0], s));
-  hipLaunchKernelGGL(k_queries_from_keypoints, dim3((cap + 255) / 256, nCalls), dim3(256), 0, s, reinterpret_cast<const KeyPointDev*>(d_kps), d_n, cap,
-                     aff, th, m->sf.as<float>(), nLevels, minX, maxX, minY, maxY, m->queries.as<QueryDev>());
+  hipLaunchKernelGGL(k_queries_from_keypoints, dim3((cap + 255) / 256, nCalls), dim3(256), 0, s, m->calls.as<CallDev>(), cap, aff, th, m->sf.as<float>(),
+                     nLevels, minX, maxX, minY, maxY);
   { const int rcg = launchGridBuild(nFrames, cap, s, m->frames.as<FrameDev>()); if (rcg) return rcg; }
   if (prof) HIPCHK(hipEventRecord(m->ev[1], s));
   hipLaunchKernelGGL(k_gather_projection, dim3((cap + 3) / 4, nCalls), dim3(256), 0, s, m->calls.as<CallDev>(), m->frames.as<FrameDev>(), cap,
@@ -696,6 +709,19 @@ int ydorb_match_consecutive_device(ydorb_matcher_t* m, const YdKeyPoint* d_kps, 
   if (prof) { HIPCHK(hipEventRecord(m->ev[3], s)); m->evPending = true; }
   HIPCHK(hipGetLastError());
   return YDORB_OK;
+}
+
+int ydorb_match_consecutive_device(ydorb_matcher_t* m, const YdKeyPoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int32_t cap,
+                                   int32_t nFrames, int32_t width, int32_t height, float th, const float* scaleFactors, int32_t nLevels,
+                                   const float* d_affine, int32_t checkOri, int32_t* d_assigned, int32_t* d_counts, void* stream) {
+  if (!m || nFrames < 2) { set_error("invalid argument"); return YDORB_ERR_INVALID_ARG; }
+  const YdFrameSetDev S{d_kps, d_desc, d_n, nFrames, cap};
+  if ((int)m->consecPairs.size() != 2 * (nFrames - 1)) {
+    m->consecPairs.resize((size_t)2 * (nFrames - 1));
+    for (int c = 0; c < nFrames - 1; c++) { m->consecPairs[2 * c] = c; m->consecPairs[2 * c + 1] = c + 1; }
+  }
+  return ydorb_match_pairs_device(m, &S, &S, m->consecPairs.data(), nFrames - 1, width, height, th, scaleFactors, nLevels, d_affine, checkOri, d_assigned,
+                                  d_counts, stream);
 }
 
 int ydorb_matcher_synchronize(ydorb_matcher_t* m) {

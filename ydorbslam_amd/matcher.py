@@ -193,6 +193,15 @@ class OrbMatcher:
         check(self._L.ydorb_match_consecutive_device(self._h, d_kps, d_desc, d_n, cap, n_frames, width, height, th, _p(sf), len(sf), d_affine,
                                                      int(self.check_orientation), d_assigned, d_counts, stream))
 
+    def match_pairs_device(self, q_set, t_set, pairs, width, height, th, scale_factors, d_assigned, d_counts, d_affine=None, stream=None):
+        """ydorb_match_pairs_device: q_set / t_set = (d_kps, d_desc, d_n, n_frames, cap) raw HBM addresses; pairs: [n_pairs, 2] host ints."""
+        from ._lib import YdFrameSetDev
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        pr = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        Q, T = YdFrameSetDev(*q_set), YdFrameSetDev(*t_set)
+        check(self._L.ydorb_match_pairs_device(self._h, C.byref(Q), C.byref(T), _p(pr), len(pr), width, height, th, _p(sf), len(sf), d_affine,
+                                               int(self.check_orientation), d_assigned, d_counts, stream))
+
     def synchronize(self):
         check(self._L.ydorb_matcher_synchronize(self._h))
 
