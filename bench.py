@@ -4,32 +4,42 @@ and local-BA LM iterations/s (config 5: 100 keyframes x 10 000 points) on N MI35
 
 One "step" = one pass of the hot path over one batch of synthetic frames that already sit in HBM:
   ydorb_extract_batch_device (pyramid -> FAST cells -> quad-tree -> blur -> orientation + rBRIEF)
-  + ydorb_match_consecutive_device (grid build -> candidate distances -> ordered resolve) over the F-1 frame pairs.
-N > 1: one process per GPU (torch.distributed / RCCL); frames shard across ranks (weak scaling); the frame pair that
-straddles two ranks is matched after an all-gather of the boundary frames' keypoints + descriptors.
+  + ydorb_match_pairs_device (grid build -> candidate distances -> ordered resolve): every owned frame is searched for the
+  keypoints of its predecessor in the stream (searchByProjectionInLastAndCurrentFrame rules, th = 15), predicted with the known
+  inter-frame motion (all frames distinct, frame t+1 = frame t after a small roll / shift).
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the launch stream; `cpu_baseline` times the
-CPU oracle (a port of the reference algorithm, single thread) on a bounded sample of the same frames.
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself (fresh child processes, before
+anything touches a GPU); under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.  N > 1: one process per GPU
+(torch.distributed / RCCL).  The frames of the stream are dealt round-robin (global frame g lives on rank g % N), so EVERY
+consecutive pair straddles two GPUs: per step each rank all-gathers every rank's [keypoints | descriptors | count] records of
+the step and then matches, locally against the gathered set, the pairs whose later frame it owns.  Per-GPU
+work is fixed as N grows (weak scaling); the gather grows with N.
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the launch stream; `cpu_baseline` times the CPU
+oracle (a port of the reference algorithm) on a bounded sample of the same frames, on one thread and on all host cores.
 """
 import argparse
-import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 W, H, NFEAT = 640, 480, 1000
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
-FP64_VEC_PEAK = 78.6e12    # FLOP/s, MI355X FP64 vector datasheet figure (the in-container guide lists no FP64 number)
+FP64_VEC_PEAK = 78.6e12    # FLOP/s, MI355X FP64 vector / matrix datasheet figure (the in-container guide lists no FP64 number)
+# integer-VALU peak for the brute-force figure: 256 CUs x 4 SIMDs x 32 lanes per cycle at the 2.4 GHz maximum clock
+INT_VALU_PEAK = 256 * 4 * 32 * 2.4e9
+PARITY_NOTE = ("bit-exact vs the build's CPU restatement of the reference algorithm (oracle/); oracle unpinned for extractor / "
+               "matcher / stereo / BoW: OpenCV absent, the reference holds no fixture; BA solver pinned by g2o's own linear-system vector only")
 
 
 def algorithmic_bytes_extract(w, h, n):
     """image read + padded pyramid written (public output) + keypoints/descriptors written."""
+    import numpy as np
     tot = w * h + n * 60
     for l in range(8):
         inv = np.float32(pow(np.float32(1.2), -l))
@@ -38,20 +48,57 @@ def algorithmic_bytes_extract(w, h, n):
     return tot
 
 
+def launch_ranks(n):
+    """--gpus N without a launcher: start N ranks as fresh children (this parent never touches a GPU) and relay rank 0's line."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
+
+
+def cpu_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return model, os.cpu_count() or 1, usable
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=512, help="frames per step and per GPU")
-    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic frames (tiled to --frames)")
-    ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the CPU-oracle baseline sample")
+    ap.add_argument("--segment", type=int, default=64, help="frames per synthetic scene (a new scene is a cut)")
+    ap.add_argument("--cpu-frames", type=int, default=96, help="frames of the 1-thread CPU-oracle sample")
     ap.add_argument("--extractors", type=int, default=2, help="extractor handles (each with its own stream) the frames of a step are split over")
-    ap.add_argument("--ba-threads", type=int, default=8, help="host threads of the concurrent local-BA figure (the library pools 8 contexts per device)")
+    ap.add_argument("--ba-threads", type=int, default=8, help="problems in flight of the concurrent local-BA figure")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-call / PCIe-inclusive / config 3 / config 4 / brute-force sections")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)
+        return
+
+    import numpy as np
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -81,82 +128,81 @@ def main():
         else:
             dist.all_reduce(t, op=op)
 
-    def all_gather_into(out, inp):
+    def all_gather_inplace(full, mine):
+        """full: [world * k, ...] tensor whose slice [rank*k, (rank+1)*k) is `mine` (the extractor wrote it there): no packing copy."""
         if staged:
-            parts = [torch.zeros_like(inp, device="cpu") for _ in range(world)]
-            dist.all_gather(parts, inp.cpu())
-            out.copy_(torch.cat(parts))
+            parts = [torch.zeros_like(mine, device="cpu") for _ in range(world)]
+            dist.all_gather(parts, mine.cpu())
+            full.copy_(torch.cat(parts))
         else:
-            dist.all_gather_into_tensor(out, inp)
+            dist.all_gather_into_tensor(full, mine)
 
     import ydorbslam_amd as y
-    from ydorbslam_amd.synth import synth_frame, synth_ba_problem
+    from ydorbslam_amd.synth import stream_plan, stream_render, synth_ba_problem
 
     F = args.frames
-    distinct = [synth_frame(W, H, rank * 1000 + i) for i in range(min(args.distinct, F))]
-    imgs = np.stack([distinct[i % len(distinct)] for i in range(F)])
-    # The frames of a step are split over `--extractors` handles, each with its own stream (like the reference's two extractor
-    # objects for stereo): while one handle sits in its latency-bound quad-tree stage the other's pyramid/FAST kernels fill the chip.
+    G = F * world                                   # frames of the global stream per step
+    # SURVEY 8(d): every frame distinct; frame g+1 = frame g after a small known motion (scene cut every --segment frames).
+    # Round-robin ownership: global frame g = t * world + rank is this rank's frame t.
+    plan = stream_plan(W, H, G, seed=0, segment=args.segment)
+    own = [t * world + rank for t in range(F)]
+    imgs, _ = stream_render(plan, own)
     NEX = max(1, min(args.extractors, F // 8))
     parts = [(i * F // NEX, (i + 1) * F // NEX) for i in range(NEX)]
     exs = [y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=b - a) for a, b in parts]
     ex = exs[0]
-    mt = y.OrbMatcher(0.9, True, device=local_rank)
     cap = ex.max_keypoints
     sf = ex.tables()["scale"]
     d_img = torch.from_numpy(imgs).to(dev)
-    # Two output sets + two explicit streams: extraction of step k+1 (stream A) overlaps the matching of step k (stream B).
+    # Two output sets + explicit streams: extraction of step k+1 overlaps the matching of step k.  An output set is laid out as the
+    # GATHERED set [world * F][cap]; this rank's extractors write straight into its slice.
     # (The default stream's handle is 0, which the C ABI reads as "use the handle's own stream": always pass real streams.)
-    d_kps = [torch.zeros((F, cap, 7), dtype=torch.float32, device=dev) for _ in range(2)]
-    d_desc = [torch.zeros((F, cap, 32), dtype=torch.uint8, device=dev) for _ in range(2)]
-    d_n = [torch.zeros(F, dtype=torch.int32, device=dev) for _ in range(2)]
-    d_assigned = [torch.zeros((F - 1, cap), dtype=torch.int32, device=dev) for _ in range(2)]
-    d_counts = [torch.zeros(F - 1, dtype=torch.int32, device=dev) for _ in range(2)]
+    g_kps = [torch.zeros((G, cap, 7), dtype=torch.float32, device=dev) for _ in range(2)]
+    g_desc = [torch.zeros((G, cap, 32), dtype=torch.uint8, device=dev) for _ in range(2)]
+    g_n = [torch.zeros(G, dtype=torch.int32, device=dev) for _ in range(2)]
+    lo = rank * F
+    d_kps = [t[lo:lo + F] for t in g_kps]
+    d_desc = [t[lo:lo + F] for t in g_desc]
+    d_n = [t[lo:lo + F] for t in g_n]
+    # pairs (query = predecessor in the global stream, target = an owned frame), as indices into the gathered (rank-major) set
+    pairs, pair_aff = [], []
+    for t in range(F):
+        g = t * world + rank
+        if g == 0:
+            continue
+        pr, pt = (g - 1) % world, (g - 1) // world
+        pairs.append((pr * F + pt, lo + t))
+        pair_aff.append(plan["predicted"][g - 1])
+    pairs = np.array(pairs, np.int32)
+    NPAIR = len(pairs)
+    d_aff = torch.from_numpy(np.ascontiguousarray(np.stack(pair_aff), np.float32)).to(dev)
+    d_assigned = [torch.zeros((NPAIR, cap), dtype=torch.int32, device=dev) for _ in range(2)]
+    d_counts = [torch.zeros(NPAIR, dtype=torch.int32, device=dev) for _ in range(2)]
     sAs, sB = [torch.cuda.Stream(device=dev) for _ in range(NEX)], torch.cuda.Stream(device=dev)
     ev_extracted = [[torch.cuda.Event() for _ in range(NEX)] for _ in range(2)]
     ev_matched = [torch.cuda.Event() for _ in range(2)]
     for e in ev_matched:
         e.record(sB)
-    mts = [mt, y.OrbMatcher(0.9, True, device=local_rank)]   # one matcher (own scratch) per output set
+    mts = [y.OrbMatcher(0.9, True, device=local_rank) for _ in range(2)]   # one matcher (own scratch) per output set
     step_no = [0]
-    # cross-rank boundary pair (only N > 1): all-gather of [keypoints | descriptors] of each rank's last frame
-    if world > 1:
-        rec = cap * (28 + 32) + 4
-        send = torch.zeros(rec, dtype=torch.uint8, device=dev)
-        gathered = torch.zeros(world * rec, dtype=torch.uint8, device=dev)
-        b_kps = torch.zeros((2, cap, 7), dtype=torch.float32, device=dev)
-        b_desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device=dev)
-        b_n = torch.zeros(2, dtype=torch.int32, device=dev)
-        b_assigned = torch.zeros((1, cap), dtype=torch.int32, device=dev)
-        b_counts = torch.zeros(1, dtype=torch.int32, device=dev)
-        mt2 = y.OrbMatcher(0.9, True, device=local_rank)
 
     def step():
         b = step_no[0] & 1
         step_no[0] += 1
         for i, (f0, f1) in enumerate(parts):
             sA = sAs[i]
-            sA.wait_event(ev_matched[b])          # the matcher that last read this output set is done
+            sA.wait_event(ev_matched[b])          # the matcher (and the gather) that last used this output set is done
             exs[i].extract_batch_device(d_img[f0].data_ptr(), W, H, W, W * H, f1 - f0, d_kps[b][f0].data_ptr(), d_desc[b][f0].data_ptr(), cap,
                                         d_n[b][f0:].data_ptr(), sA.cuda_stream)
             ev_extracted[b][i].record(sA)
             sB.wait_event(ev_extracted[b][i])
-        mts[b].match_consecutive_device(d_kps[b].data_ptr(), d_desc[b].data_ptr(), d_n[b].data_ptr(), cap, F, W, H, 15.0, sf,
-                                        d_assigned[b].data_ptr(), d_counts[b].data_ptr(), None, sB.cuda_stream)
-        if world > 1:
-            with torch.cuda.stream(sB):
-                send[:cap * 28] = d_kps[b][F - 1].view(torch.uint8).reshape(-1)
-                send[cap * 28:cap * 60] = d_desc[b][F - 1].reshape(-1)
-                send[cap * 60:] = d_n[b][F - 1:F].view(torch.uint8)
-                all_gather_into(gathered, send)
-                prev = (rank - 1) % world
-                g = gathered[prev * rec:(prev + 1) * rec]
-                b_kps[0] = g[:cap * 28].view(torch.float32).reshape(cap, 7)
-                b_desc[0] = g[cap * 28:cap * 60].reshape(cap, 32)
-                b_n[0:1] = g[cap * 60:].view(torch.int32)
-                b_kps[1], b_desc[1], b_n[1:2] = d_kps[b][0], d_desc[b][0], d_n[b][0:1]
-                mt2.match_consecutive_device(b_kps.data_ptr(), b_desc.data_ptr(), b_n.data_ptr(), cap, 2, W, H, 15.0, sf, b_assigned.data_ptr(),
-                                             b_counts.data_ptr(), None, sB.cuda_stream)
+        with torch.cuda.stream(sB):
+            if world > 1:   # SURVEY 8(e): all-gather of every rank's records of the step, three large collectives, no packing
+                all_gather_inplace(g_kps[b], d_kps[b])
+                all_gather_inplace(g_desc[b], d_desc[b])
+                all_gather_inplace(g_n[b], d_n[b])
+            gs = (g_kps[b].data_ptr(), g_desc[b].data_ptr(), g_n[b].data_ptr(), G, cap)
+            mts[b].match_pairs_device(gs, gs, pairs, W, H, 15.0, sf, d_assigned[b].data_ptr(), d_counts[b].data_ptr(), d_aff.data_ptr(), sB.cuda_stream)
         ev_matched[b].record(sB)
 
     def barrier():
@@ -179,6 +225,8 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    for h_ in exs:
+        h_.synchronize()  # surfaces a quad-tree capacity status, if any
     for m_ in mts:
         m_.synchronize()  # surfaces a record-pool overflow, if any (and reads the last launch's stage events)
     live = {}
@@ -223,21 +271,20 @@ def main():
 
     # ---- roofline of the dominant kernel: per-stage device time, HIP events on the launch stream -------------------
     FL = parts[0][1] - parts[0][0]   # frames per extractor launch in the timed run
+    mt = mts[0]
     ex2 = y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=FL)
     ex2.set_profiling(True)
     mt.set_profiling(True)
     for _ in range(5):
         ex2.extract_batch(imgs[:FL])
-    for _ in range(5):
-        mt.match_consecutive_device(d_kps[0].data_ptr(), d_desc[0].data_ptr(), d_n[0].data_ptr(), cap, F, W, H, 15.0, sf, d_assigned[0].data_ptr(),
-                                    d_counts[0].data_ptr())
+    gs0 = (g_kps[0].data_ptr(), g_desc[0].data_ptr(), g_n[0].data_ptr(), G, cap)
+    for _ in range(6):
+        mt.match_pairs_device(gs0, gs0, pairs, W, H, 15.0, sf, d_assigned[0].data_ptr(), d_counts[0].data_ptr(), d_aff.data_ptr())
         mt.synchronize()
-    mt.match_consecutive_device(d_kps[0].data_ptr(), d_desc[0].data_ptr(), d_n[0].data_ptr(), cap, F, W, H, 15.0, sf, d_assigned[0].data_ptr(),
-                                d_counts[0].data_ptr())
-    mt.synchronize()
     isolated = dict(ex2.stage_times())       # the same stages with nothing else on the GPU (one handle, no overlap): for reference
     isolated.update(mt.stage_times())
     mt.set_profiling(False)
+    del ex2
     stages = dict(isolated)
     stages.update(live)                      # the roofline uses the live durations
     dom = max(stages, key=stages.get)
@@ -248,56 +295,64 @@ def main():
     kbytes = {
         "pyramid": W * H + pyr_pad,                       # read image, write padded pyramid
         "fast_cells": pyr_pad,                            # read every pyramid pixel once (candidates are << 1 %)
-        "quadtree_after_blur": 8 * 4200 * 4,                         # read ~4.2 k packed candidates per level (measured average), write keypoints
-        "blur": 2 * (A_frame - W * H - NFEAT * 60),       # read pyramid, write blurred levels
+        "quadtree_after_blur": 8 * 4200 * 4,              # read ~4.2 k packed candidates per level (measured average), write keypoints
+        "blur": 2 * pyr_pad,                              # read pyramid, write blurred levels
         "orient_describe": int(n_kp_frame) * (60 + 2 * 1849),  # 43x43 patch of the level and of the blurred level + 60 B out
         "grid_build": int(n_kp_frame) * (28 + 4),
         "gather_distances": int(n_kp_frame) * (40 + 32 + 24 * 36),  # query + descriptor + ~24 candidates x (32 B descriptor + 4 B record)
         "resolve": int(n_kp_frame) * 24 * 4,
     }
     t_dom = stages[dom] * 1e-3
-    launch_frames = F if dom in ("grid_build", "gather_distances", "resolve") else FL
+    launch_frames = NPAIR if dom in ("grid_build", "gather_distances", "resolve") else FL
     achieved = kbytes.get(dom, A_frame) * launch_frames / t_dom if t_dom > 0 else 0.0
-    # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01f_pmc_hbm_traffic.csv: separate
-    # FETCH_SIZE / WRITE_SIZE runs of the same kernels at 128 frames per launch; FETCH under-counts this 4-byte access pattern
-    # by 1.33x, calibrated on k_pyr_level0's known read size; WRITE_SIZE is exact) scaled to this run's frames per launch.
-    traffic = None
+    # HBM bytes per launch of the dominant kernel: NOT measured in this run (PMC counters need rocprofv3 around the process).  They
+    # come from the committed counter passes of the same kernels (separate FETCH_SIZE / WRITE_SIZE runs; FETCH under-counts this
+    # 4-byte access pattern by 1.33x, calibrated on k_pyr_level0's known read size; WRITE_SIZE is exact), scaled to this run's frames
+    # per launch; `traffic_source` names the file.
+    traffic, valu_busy, traffic_source = None, None, None
+    stage_kernels = {"pyramid": ("k_pyr_level0", "k_pyr_resize", "k_pyr_borders"), "fast_cells": ("k_fast_cells",), "blur": ("k_blur",),
+                     "quadtree_after_blur": ("k_quadtree_flat", "k_quadtree"), "orient_describe": ("k_orient_describe",)}
     try:
         import csv
-        stage_kernels = {"pyramid": ("k_pyr_level0", "k_pyr_resize", "k_pyr_borders"), "fast_cells": ("k_fast_cells",), "blur": ("k_blur",),
-                         "quadtree_after_blur": ("k_quadtree_flat", "k_quadtree"), "orient_describe": ("k_orient_describe",)}
-        rows = {r["kernel"]: r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01f_pmc_hbm_traffic.csv")))}
-        if dom in stage_kernels:
-            per_frame = sum(float(rows[k]["fetch_MB_per_frame_raw"]) * 1.33 + float(rows[k]["write_MB_per_frame"]) for k in stage_kernels[dom])
-            traffic = per_frame * 1e6 * (F / NEX)
+        for tag in ("r02", "r01f"):
+            pth = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic.csv" % tag)
+            if not os.path.exists(pth):
+                continue
+            rows = {r["kernel"]: r for r in csv.DictReader(open(pth))}
+            if dom in stage_kernels and all(k in rows for k in stage_kernels[dom]):
+                per_frame = sum(float(rows[k]["fetch_MB_per_frame_raw"]) * 1.33 + float(rows[k]["write_MB_per_frame"]) for k in stage_kernels[dom])
+                traffic = per_frame * 1e6 * FL
+                traffic_source = "profiles/%s_pmc_hbm_traffic.csv (separate rocprofv3 --pmc passes, per frame, scaled to %d frames per launch)" % (tag, FL)
+            pth2 = os.path.join(ROOT, "profiles", "%s_pmc_sq_valu.csv" % tag)
+            if os.path.exists(pth2):
+                for r in csv.DictReader(open(pth2)):
+                    if dom in stage_kernels and r["kernel"] == stage_kernels[dom][0]:
+                        valu_busy = float(r["VALU_busy_pct_of_SIMD_cycles"]) / 100.0
+            if traffic is not None:
+                break
     except Exception:  # noqa: BLE001
-        traffic = None
-    # what actually bounds the dominant kernel: share of the launch's SIMD cycles spent issuing vector instructions
-    # (4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), committed SQ pass profiles/r01f_pmc_sq_valu.csv)
-    valu_busy = None
-    try:
-        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01f_pmc_sq_valu.csv"))):
-            if dom in stage_kernels and r["kernel"] == stage_kernels[dom][0]:
-                valu_busy = float(r["VALU_busy_pct_of_SIMD_cycles"]) / 100.0
-    except Exception:  # noqa: BLE001
-        valu_busy = None
+        pass
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK, "traffic": traffic, "valu_busy_frac": valu_busy,
+                "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source, "valu_busy_frac": valu_busy,
+                "valu_busy_source": traffic_source and traffic_source.replace("hbm_traffic", "sq_valu"),
                 "pipeline_achieved_GBps": A_frame * F * args.steps / dt / 1e9, "pipeline_frac": A_frame * F * args.steps / dt / HBM_PEAK,
                 "stage_ms_per_launch": {k: round(v, 4) for k, v in stages.items()},
                 "stage_ms_per_launch_isolated": {k: round(v, 4) for k, v in isolated.items()},
-                "frames_per_extract_launch": FL, "frames_per_match_launch": F}
+                "frames_per_extract_launch": FL, "pairs_per_match_launch": NPAIR}
 
     out = {"metric": "ORB extract+match Mkeypoints/sec", "value": value, "unit": "Mkeypoints/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "u8", "data": "synthetic",
-           "config": {"workload": "TUM-fr1-size 640x480 mono stream, 1000 feat/frame, extract + consecutive-frame searchByProjection",
-                      "frames_per_step_per_gpu": F, "extractor_handles": NEX, "distinct_frames": len(distinct), "keypoints_per_frame": n_kp_frame,
-                      "matches_per_pair": matched_local / max(F - 1, 1), "parallelism": "frames sharded x%d" % world},
+           "dtype": "u8", "data": "synthetic", "parity": "partial", "parity_note": PARITY_NOTE,
+           "config": {"workload": "TUM-fr1-size 640x480 mono stream, 1000 feat/frame, extract + consecutive-frame searchByProjection (th 15); frames resident in HBM",
+                      "frames_per_step_per_gpu": F, "extractor_handles": NEX, "distinct_frames": F * world, "frames_per_scene": args.segment,
+                      "motion": "per frame: roll within +-3 deg, shift within +-8 px (bounded walk); prediction = true motion + N(0,1.5^2) px on the translation",
+                      "keypoints_per_frame": n_kp_frame, "matches_per_pair": matched_local / max(NPAIR, 1),
+                      "parallelism": ("frames dealt round-robin x%d, all-gather of [kp|desc|n] per step, local match against the gathered set" % world)
+                      if world > 1 else "1 GPU"},
            "roofline": roofline}
+    out["extract_only"] = extract_only
 
     # ---- local BA (config 5) ------------------------------------------------------------------------------------------
-    out["extract_only"] = extract_only
     if not args.no_ba:
         prob = synth_ba_problem(100, 10000, 8, seed=1)
         if world > 1:  # shard landmarks (and their edges) across ranks; every rank holds all poses
@@ -331,16 +386,18 @@ def main():
             all_reduce_(tb_all, dist.ReduceOp.MAX)
         tb = float(tb_all.item())
         flops_schur = 89.9e6  # Schur part of one LM trial at C5 / 8 obs
+        flops_chol = 72.7e6   # (6K)^3/3 + 2(6K)^2, same table
         ms = r["ms"]
         out["ba"] = {"metric": "local-BA LM iterations/sec (100 KF x 10k points, 8 obs/point)", "value": trials / tb, "unit": "it/s",
                      "lm_trials_per_solve": r["trials"], "ms_per_solve": tb / reps * 1e3, "final_chi2": float(r["log"][-1, 0]),
                      "device_ms_per_solve": {k: round(float(v), 3) for k, v in ms.items()},
                      "schur_fp64_frac": (flops_schur * r["trials"] / (ms["schur"] * 1e-3) / FP64_VEC_PEAK) if ms["schur"] > 0 else None,
+                     "solve_fp64_frac": (flops_chol * r["trials"] / (ms["solve"] * 1e-3) / FP64_VEC_PEAK) if ms["solve"] > 0 else None,
+                     "fp64_note": "device_ms_per_solve.schur covers k_dinv + k_bd + k_bs + k_schur_pairs, .solve the Cholesky chain + both substitutions; the kernels' own rocprof durations are in profiles/",
+                     "parity_note": "vs the oracle's restatement of g2o (unpinned end to end; dense solver pinned by g2o's linear_solver_test vector, tol 1e-6)",
                      "scaling": "strong (landmarks sharded, all-reduce of the reduced camera system)" if world > 1 else "single GPU"}
         if world == 1:
-            # Additional figure: several independent local-BA problems at once, one host thread each (ctypes drops the
-            # GIL; the library keeps a pool of per-device contexts).  One solve is a latency chain that leaves the GPU mostly
-            # idle, so concurrent maps / sessions overlap almost freely.
+            # Additional figure: several independent local-BA problems at once (ydorb_ba_solve_batch).
             NT = args.ba_threads
             probs = [synth_ba_problem(100, 10000, 8, seed=1) for _ in range(2 * NT)]
             y.Optimizer.local_bundle_adjust_batch(probs[:NT], opt, NT)
@@ -348,7 +405,168 @@ def main():
             bres = y.Optimizer.local_bundle_adjust_batch(probs, opt, NT)
             tcc = time.perf_counter() - tcc
             out["ba"]["concurrent"] = {"problems": len(probs), "in_flight": NT, "value": sum(b_["trials"] for b_ in bres) / tcc, "unit": "it/s (aggregate)",
-                                       "note": "ydorb_ba_solve_batch: independent copies of the same C5 problem, one library thread and one pooled context each"}
+                                       "note": "ydorb_ba_solve_batch: independent copies of the same C5 problem"}
+
+    extras = world == 1 and not args.no_extras
+    pprobs = spairs = vtree = bdescs = groups_d = best_d = None
+
+    # ---- what ONE call of the drop-in sees, host to host (frame.cpp:129, tracking.cpp:456, localMapping.cpp:140) ---------------
+    if extras:
+        def med_ms(fn, n=15):
+            fn()
+            ts = []
+            for _ in range(n):
+                t_ = time.perf_counter(); fn(); ts.append(time.perf_counter() - t_)
+            return float(np.median(ts) * 1e3)
+        ex1 = y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank)
+        one = imgs[3]
+        sc = {"extract_ms": med_ms(lambda: ex1.extract(one)),
+              "extract_plus_pyramid_download_ms": med_ms(lambda: (ex1.extract(one), [ex1.read_level(l) for l in range(8)])),
+              "note": "median host-to-host wall time of one call: ydorb_extract = H2D 307 KB + ~20 launches + D2H 60 KB; the adapter's "
+                      "m_v_imagePyramid download adds 8 level copies (1.16 MB)"}
+        ka_, da_ = ex1.extract(imgs[3]); kb_, db_ = ex1.extract(imgs[4])
+        q1 = np.zeros(len(ka_), y.QUERY_DTYPE)
+        q1["u"], q1["v"] = ka_["x"], ka_["y"]
+        q1["r"] = (np.float32(15.0) * sf[ka_["octave"]]).astype(np.float32)
+        q1["min_level"], q1["max_level"] = ka_["octave"] - 1, ka_["octave"] + 1
+        q1["angle"], q1["level"], q1["flags"] = ka_["angle"], ka_["octave"], 3
+        fv1 = y.FrameView(kb_, db_, (0.0, float(W), 0.0, float(H)))
+        m1 = y.OrbMatcher(0.9, True, device=local_rank)
+        sc["search_by_projection_ms"] = med_ms(lambda: m1.search_by_projection(1, fv1, q1, da_))
+        sc["keypoints_per_s_one_frame_at_a_time"] = len(ka_) / ((sc["extract_ms"] + sc["search_by_projection_ms"]) * 1e-3)
+        if not args.no_ba:
+            sc["ba_solve_ms"] = out["ba"]["ms_per_solve"]
+            from ydorbslam_amd.synth import synth_pose_problem
+            pp1 = [synth_pose_problem(400, seed=100)]
+            sc["pose_optimize_ms"] = med_ms(lambda: y.Optimizer.optimize_poses(pp1))
+        out["single_call"] = sc
+        del ex1
+
+    # ---- PCIe-inclusive: pinned host frames in, host keypoints / descriptors / matches out (SURVEY 8d "incl. H2D/D2H") -------------
+    if extras:
+        CH = 4                                              # chunks per step: copy of chunk c+1 overlaps the extraction of chunk c
+        cf = F // CH
+        h_img = torch.from_numpy(imgs).pin_memory()
+        h_kps = torch.zeros((F, cap, 7), dtype=torch.float32).pin_memory()
+        h_desc = torch.zeros((F, cap, 32), dtype=torch.uint8).pin_memory()
+        h_n = torch.zeros(F, dtype=torch.int32).pin_memory()
+        h_assigned = torch.zeros((NPAIR, cap), dtype=torch.int32).pin_memory()
+        h_counts = torch.zeros(NPAIR, dtype=torch.int32).pin_memory()
+        p_img = torch.zeros_like(d_img)
+        s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        ev_in = [torch.cuda.Event() for _ in range(CH)]
+        ev_ex = [torch.cuda.Event() for _ in range(CH)]
+
+        def pcie_step():
+            for c in range(CH):
+                a_, b_ = c * cf, (c + 1) * cf
+                with torch.cuda.stream(s_in):
+                    p_img[a_:b_].copy_(h_img[a_:b_], non_blocking=True)
+                    ev_in[c].record(s_in)
+                sA = sAs[c % NEX]
+                sA.wait_event(ev_in[c])
+                exs[c % NEX].extract_batch_device(p_img[a_].data_ptr(), W, H, W, W * H, cf, d_kps[0][a_].data_ptr(), d_desc[0][a_].data_ptr(), cap,
+                                                  d_n[0][a_:].data_ptr(), sA.cuda_stream)
+                ev_ex[c].record(sA)
+                with torch.cuda.stream(s_out):
+                    s_out.wait_event(ev_ex[c])
+                    h_kps[a_:b_].copy_(d_kps[0][a_:b_], non_blocking=True)
+                    h_desc[a_:b_].copy_(d_desc[0][a_:b_], non_blocking=True)
+                    h_n[a_:b_].copy_(d_n[0][a_:b_], non_blocking=True)
+                sB.wait_event(ev_ex[c])
+            mts[0].match_pairs_device(gs0, gs0, pairs, W, H, 15.0, sf, d_assigned[0].data_ptr(), d_counts[0].data_ptr(), d_aff.data_ptr(), sB.cuda_stream)
+            with torch.cuda.stream(sB):
+                h_assigned.copy_(d_assigned[0], non_blocking=True)
+                h_counts.copy_(d_counts[0], non_blocking=True)
+        if F % CH == 0 and cf <= FL:
+            pcie_step(); torch.cuda.synchronize()
+            n_p = max(args.steps // 2, 3)
+            tp = time.perf_counter()
+            for _ in range(n_p):
+                pcie_step()
+            torch.cuda.synchronize()
+            tp = (time.perf_counter() - tp) / n_p
+            bytes_in, bytes_out = F * W * H, F * cap * 60 + F * 4 + NPAIR * cap * 4 + NPAIR * 4
+            out["pcie_inclusive"] = {"value": float(h_n.sum().item()) / tp / 1e6, "unit": "Mkeypoints/s", "ms_per_step": tp * 1e3,
+                                     "host_to_device_MB_per_step": bytes_in / 1e6, "device_to_host_MB_per_step": bytes_out / 1e6,
+                                     "note": "pinned host frames -> H2D on a copy stream (%d chunks per step, overlapped with the extraction of the previous chunk) -> extract -> "
+                                             "match -> keypoints, descriptors, counts and match lists back to pinned host memory; never the headline value" % CH}
+        del h_img, h_kps, h_desc, h_assigned, p_img
+
+    # ---- configs 3 and 4: stereo streams (extract L + R, computeStereoMatches, consecutive left-frame search) ----------------------
+    if extras:
+        def stereo_config(w, h, nf, n_pairs, label):
+            pl = stream_plan(w, h, n_pairs, seed=7, segment=32)
+            L_, R_ = stream_render(pl, range(n_pairs), stereo=True)
+            # two extractor instances running side by side, one per eye (frame.cpp:84-87), each on its own stream
+            sxL = y.OrbExtractor(nf, 1.2, 8, 20, 7, device=local_rank, max_batch=n_pairs)
+            sxR = y.OrbExtractor(nf, 1.2, 8, 20, 7, device=local_rank, max_batch=n_pairs)
+            scap = sxL.max_keypoints
+            ssf = sxL.tables()["scale"]
+            diL, diR = torch.from_numpy(L_).to(dev), torch.from_numpy(R_).to(dev)
+            mk = lambda *shape, dt=torch.float32: torch.zeros(shape, dtype=dt, device=dev)
+            dkL, dkR = mk(n_pairs, scap, 7), mk(n_pairs, scap, 7)
+            ddL, ddR = mk(n_pairs, scap, 32, dt=torch.uint8), mk(n_pairs, scap, 32, dt=torch.uint8)
+            dnL, dnR = mk(n_pairs, dt=torch.int32), mk(n_pairs, dt=torch.int32)
+            drx, ddp, dkept = mk(n_pairs, scap), mk(n_pairs, scap), mk(n_pairs, dt=torch.int32)
+            prs = np.array([(i, i + 1) for i in range(n_pairs - 1)], np.int32)
+            daf = torch.from_numpy(np.ascontiguousarray(pl["predicted"], np.float32)).to(dev)
+            das, dct = mk(n_pairs - 1, scap, dt=torch.int32), mk(n_pairs - 1, dt=torch.int32)
+            sm_, mm_ = y.OrbMatcher(device=local_rank), y.OrbMatcher(0.9, True, device=local_rank)
+            stL, stR = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+            evR, evDone = torch.cuda.Event(), torch.cuda.Event()
+            evDone.record(stL)
+            fs_ = (dkL.data_ptr(), ddL.data_ptr(), dnL.data_ptr(), n_pairs, scap)
+
+            def one(full=True):
+                stR.wait_event(evDone)      # the association of the previous step has read the right side's outputs
+                sxL.extract_batch_device(diL.data_ptr(), w, h, w, w * h, n_pairs, dkL.data_ptr(), ddL.data_ptr(), scap, dnL.data_ptr(), stL.cuda_stream)
+                sxR.extract_batch_device(diR.data_ptr(), w, h, w, w * h, n_pairs, dkR.data_ptr(), ddR.data_ptr(), scap, dnR.data_ptr(), stR.cuda_stream)
+                evR.record(stR)
+                stL.wait_event(evR)
+                if full:
+                    sm_.stereo_matches_device(sxL, sxR, dkL.data_ptr(), ddL.data_ptr(), dnL.data_ptr(), scap, dkR.data_ptr(), ddR.data_ptr(), dnR.data_ptr(), scap,
+                                              n_pairs, 40.0, 0.1, drx.data_ptr(), ddp.data_ptr(), dkept.data_ptr(), None, False, (0, 1), (0, 1), stL.cuda_stream)
+                    mm_.match_pairs_device(fs_, fs_, prs, w, h, 15.0, ssf, das.data_ptr(), dct.data_ptr(), daf.data_ptr(), stL.cuda_stream)
+                evDone.record(stL)
+            res = {}
+            for name, full in (("extract_stereo_match", True), ("extract_only", False)):
+                one(full); torch.cuda.synchronize()
+                reps_ = max(args.steps // 2, 4)
+                t_ = time.perf_counter()
+                for _ in range(reps_):
+                    one(full)
+                torch.cuda.synchronize()
+                t_ = (time.perf_counter() - t_) / reps_
+                res[name] = {"value": float(dnL.sum().item() + dnR.sum().item()) / t_ / 1e6, "unit": "Mkeypoints/s", "ms_per_step": t_ * 1e3}
+            sxL.synchronize(); sxR.synchronize(); sm_.synchronize(); mm_.synchronize()
+            A_ = algorithmic_bytes_extract(w, h, nf)
+            res.update({"workload": label, "stereo_pairs_per_step": n_pairs, "keypoints_per_image": float(dnL.float().mean().item()),
+                        "stereo_measurements_per_pair": float(dkept.float().mean().item()), "matches_per_left_pair": float(dct.float().mean().item()),
+                        "algorithmic_bytes_per_image": A_,
+                        "pipeline_frac_of_hbm_peak": A_ * 2 * n_pairs / (res["extract_stereo_match"]["ms_per_step"] * 1e-3) / HBM_PEAK})
+            return res
+        out["config3"] = stereo_config(1241, 376, 2000, 64, "KITTI-00-size 1241x376 stereo, 2000 feat/image: extract L+R, computeStereoMatches (as the reference writes it), consecutive left-frame search")
+        out["config4"] = stereo_config(752, 480, 1000, 64, "EuRoC-MH-size 752x480 stereo batch, 1000 feat/image, one GPU's share: extract L+R, computeStereoMatches, consecutive left-frame search")
+
+    # ---- brute-force N x M Hamming top-2 (north_star; SURVEY 8d secondary figure, against the integer-VALU peak) -------------------
+    if extras and hasattr(y.OrbMatcher, "hamming_topk_device"):
+        NB_ = min(F - 1, 255)
+        mb = y.OrbMatcher(device=local_rank)
+        d_best = torch.zeros((NB_, cap, 4), dtype=torch.int32, device=dev)
+        mb.hamming_topk_device(d_desc[0].data_ptr(), d_n[0].data_ptr(), d_desc[0][1:].data_ptr(), d_n[0][1:].data_ptr(), cap, NB_, d_best.data_ptr())
+        torch.cuda.synchronize()
+        tb_ = time.perf_counter()
+        for _ in range(5):
+            mb.hamming_topk_device(d_desc[0].data_ptr(), d_n[0].data_ptr(), d_desc[0][1:].data_ptr(), d_n[0][1:].data_ptr(), cap, NB_, d_best.data_ptr())
+        torch.cuda.synchronize()
+        tb_ = (time.perf_counter() - tb_) / 5
+        nn_ = d_n[0].cpu().numpy().astype(np.int64)
+        npairs_ = float((nn_[:NB_] * nn_[1:NB_ + 1]).sum())
+        out["match_bruteforce"] = {"metric": "all-pairs 256-bit Hamming top-2, frame t vs frame t+1", "frame_pairs_per_call": NB_,
+                                   "value": npairs_ / tb_ / 1e9, "unit": "G descriptor pairs/s", "ms_per_call": tb_ * 1e3,
+                                   "lane_ops_per_pair": 16, "int_valu_peak_Gops": INT_VALU_PEAK / 1e9,
+                                   "frac_of_int_valu_peak": npairs_ * 16 / tb_ / INT_VALU_PEAK}
 
     # ---- pose-only optimisation (Optimizer::optimizePose): a batch of frames per launch -------------------
     if not args.no_ba and world == 1:
@@ -423,37 +641,71 @@ def main():
         out["distinctive_descriptors"] = {"metric": "computeDistinctiveDescriptors map points/sec (2-20 observations each, one batched call, host in / host out incl. Python packing)",
                                           "points_per_call": NMP, "value": NMP / td, "unit": "points/s", "ms_per_call": td * 1e3}
 
-    # ---- CPU baseline: the oracle (port of the reference algorithm), one thread, bounded sample -------------------------
-    if rank == 0 and world == 1 and not args.no_cpu:
+    # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores, bounded sample ---------------------------
+    # Rank 0 only; at N > 1 it runs after every timed region (the other ranks wait at the final barrier), on a smaller sample.
+    if rank == 0 and not args.no_cpu:
+        from concurrent.futures import ThreadPoolExecutor
         from oracle.orb_oracle import FrameOracle, OrbExtractorOracle, QUERY_DTYPE, ba_solve
-        oex = OrbExtractorOracle(NFEAT, 1.2, 8, 20, 7)
-        ncpu = min(args.cpu_frames, F)
+        model, ncpu_all, ncpu = cpu_info()
+
+        def cpu_chunk(frames, affs):
+            """extract every frame and search each one for its predecessor's keypoints, like the GPU step; returns keypoints processed"""
+            oex = OrbExtractorOracle(NFEAT, 1.2, 8, 20, 7)
+            prev, nk = None, 0
+            for i in range(len(frames)):
+                k, d = oex.extract(frames[i])
+                nk += len(k)
+                if prev is not None:
+                    pk, pd = prev
+                    A = affs[i - 1].astype(np.float32)
+                    q = np.zeros(len(pk), QUERY_DTYPE)
+                    q["u"] = (A[0] * pk["x"] + A[1] * pk["y"]) + A[2]
+                    q["v"] = (A[3] * pk["x"] + A[4] * pk["y"]) + A[5]
+                    q["r"] = (np.float32(15.0) * sf[pk["octave"]]).astype(np.float32)
+                    q["min_level"], q["max_level"] = pk["octave"] - 1, pk["octave"] + 1
+                    q["angle"], q["level"] = pk["angle"], pk["octave"]
+                    q["flags"] = np.where((q["u"] >= 0) & (q["u"] < W) & (q["v"] >= 0) & (q["v"] < H), 3, 0)
+                    FrameOracle(k, d, (0.0, float(W), 0.0, float(H))).search_by_projection(1, q, pd, 0.9, True)
+                prev = (k, d)
+            return nk
+        if world == 1:
+            c_frames, c_affs = imgs, plan["predicted"]
+        else:   # this rank's frames are every world-th frame of the stream: render a contiguous piece for the CPU sample
+            c_frames, _ = stream_render(plan, range(min(args.cpu_frames, 48)))
+            c_affs = plan["predicted"]
+        n1 = min(args.cpu_frames if world == 1 else 32, len(c_frames))
         tc = time.perf_counter()
-        prev = None
-        nk = 0
-        for i in range(ncpu):
-            k, d = oex.extract(imgs[i])
-            nk += len(k)
-            if prev is not None:
-                pk, pd = prev
-                q = np.zeros(len(pk), QUERY_DTYPE)
-                q["u"], q["v"] = pk["x"], pk["y"]
-                q["r"] = (np.float32(15.0) * sf[pk["octave"]]).astype(np.float32)
-                q["min_level"], q["max_level"] = pk["octave"] - 1, pk["octave"] + 1
-                q["angle"], q["level"], q["flags"] = pk["angle"], pk["octave"], 3
-                FrameOracle(k, d, (0.0, float(W), 0.0, float(H))).search_by_projection(1, q, pd, 0.9, True)
-            prev = (k, d)
+        nk1 = cpu_chunk(c_frames[:n1], c_affs)
         tc = time.perf_counter() - tc
-        out["cpu_baseline"] = {"value": nk / tc / 1e6, "unit": "Mkeypoints/s", "cores": 1, "kind": "port",
-                               "sample": "%d of the same 640x480 frames, extract + consecutive match, oracle (C++ -O2), 1 thread" % ncpu}
+        per = max(4, min(16, len(c_frames) // max(ncpu, 1)))
+        chunks = [(i * per, (i + 1) * per) for i in range(ncpu) if (i + 1) * per <= len(c_frames)]
+        tca = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=max(len(chunks), 1)) as pool:   # ctypes releases the GIL inside the oracle
+            nka = sum(pool.map(lambda ab: cpu_chunk(c_frames[ab[0]:ab[1]], c_affs[ab[0]:]), chunks))
+        tca = time.perf_counter() - tca
+        out["cpu_baseline"] = {"value": nk1 / tc / 1e6, "unit": "Mkeypoints/s", "cores": 1, "kind": "port",
+                               "sample": "%d of the same 640x480 frames, extract + consecutive match, oracle (C++ -O2), 1 thread" % n1,
+                               "cpu_model": model, "host_cores": ncpu_all, "usable_cores": ncpu,
+                               "all_cores": {"value": nka / tca / 1e6, "unit": "Mkeypoints/s", "cores": len(chunks),
+                                             "sample": "%d threads x %d consecutive frames each (frame-parallel; the reference itself uses <= 2 extractor threads, frame.cpp:84-85)" % (len(chunks), per)}}
+        out["vs_cpu"] = value / out["cpu_baseline"]["value"]
+        out["vs_cpu_all_cores"] = value / out["cpu_baseline"]["all_cores"]["value"]
         if not args.no_ba:
             pb = synth_ba_problem(100, 10000, 8, seed=1)
             tcb = time.perf_counter()
             rb = ba_solve(pb)
             tcb = time.perf_counter() - tcb
-            out["ba"]["cpu_baseline"] = {"value": rb["trials"] / tcb, "unit": "it/s", "cores": 1, "kind": "port",
+            out["ba"]["cpu_baseline"] = {"value": rb["trials"] / tcb, "unit": "it/s", "cores": 1, "kind": "port", "cpu_model": model,
                                          "sample": "one full localBundleAdjust schedule (%d LM trials) on the same problem" % rb["trials"]}
+            nbp = min(ncpu, 16)
+            tcb2 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=nbp) as pool:
+                tr_ = sum(r_["trials"] for r_ in pool.map(lambda _: ba_solve(pb), range(nbp)))
+            tcb2 = time.perf_counter() - tcb2
+            out["ba"]["cpu_baseline"]["all_cores"] = {"value": tr_ / tcb2, "unit": "it/s (aggregate)", "cores": nbp,
+                                                      "sample": "%d copies of the problem, one solve per core (problem-parallel; g2o itself is single-threaded here)" % nbp}
             out["ba"]["vs_cpu"] = out["ba"]["value"] / out["ba"]["cpu_baseline"]["value"]
+        if not args.no_ba and world == 1:
             from oracle.orb_oracle import pose_optimize as oracle_pose_optimize
             tpc = time.perf_counter()
             for i in range(32):
@@ -486,10 +738,10 @@ def main():
             tdc = (time.perf_counter() - tdc) / 5000
             out["distinctive_descriptors"]["cpu_baseline"] = {"value": 1.0 / tdc, "unit": "points/s", "cores": 1, "kind": "port",
                                                               "sample": "5000 of the same points (results equal: %s)" % ok_d}
-        out["vs_cpu"] = value / out["cpu_baseline"]["value"]
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -177,60 +177,76 @@ __global__ __launch_bounds__(256) void k_gather_projection(const CallDev* __rest
         pref[wv][lane] = incl;
         sStart[wv][lane] = start;
         __builtin_amdgcn_wave_barrier();
+        // static part of the candidate test for window position t (everything but the descriptor distance)
+        auto staticTest = [&](int t, int& pos, int& idx) -> bool {
+          int lo = 0, hi = nx - 1;  // first column whose inclusive prefix exceeds t
+          while (lo < hi) { const int mid = (lo + hi) >> 1; if (pref[wv][mid] > t) hi = mid; else lo = mid + 1; }
+          pos = sStart[wv][lo] + (t - (lo ? pref[wv][lo - 1] : 0));
+          const float4 kp = F.sortedKp[pos];
+          const int octave = __float_as_int(kp.z);
+          idx = __float_as_int(kp.w);
+          bool pass = true;
+          if (Q.minLevel > 0 || Q.maxLevel >= 0)
+            if (octave < Q.minLevel || (Q.maxLevel >= 0 && octave < Q.maxLevel)) pass = false;
+          if (!(fabsf(__fsub_rn(kp.x, Q.u)) > Q.r && fabsf(__fsub_rn(kp.y, Q.v)) < Q.r)) pass = false;
+          if (pass && C.mode == 6) {
+            // fuseByProjection's candidate test (orbMatcher.cpp:711-718): level predicted-1 .. predicted and the chi-square test
+            // on the squared reprojection error — pow(float, 2.0) sums in double, stored to float, times the float inverse sigma^2
+            const float rx = F.rightX ? F.rightX[idx] : -1.0f;
+            const double ax = (double)__fsub_rn(kp.x, Q.u), ay = (double)__fsub_rn(kp.y, Q.v), ar = (double)__fsub_rn(rx, Q.ur);
+            const float monoErr = (float)(ax * ax + ay * ay);
+            const float stereoErr = (float)((double)monoErr + ar * ar);
+            const bool lv = octave >= Q.level - 1 && octave <= Q.level;
+            const float is2 = calls[blockIdx.y].invSigma2[octave & 7];   // indexed from global memory: a dynamic index into the local copy of the call record would move the whole record to scratch
+            pass = lv && ((rx >= 0 && (double)__fmul_rn(stereoErr, is2) <= 7.81) || (rx < 0 && (double)__fmul_rn(monoErr, is2) <= 5.99));
+          } else if (pass && C.mode == 7) {
+            pass = octave >= Q.level - 1 && octave <= Q.level;   // searchByProjectionInSim's explicit level window (orbMatcher.cpp:283-285)
+          } else if (pass && C.mode != 2 && F.rightX) {
+            const float rx = F.rightX[idx];
+            if (!(rx <= 0 || fabsf(__fsub_rn(Q.ur, rx)) <= Q.rs)) pass = false;
+          }
+          return pass;
+        };
+        // Records needed = candidates that pass the static test.  A window with <= kSlot keypoints fits its fixed slot whatever
+        // passes; a larger one (wide windows of the coarse levels, dense frames: most queries of a 1241x376 / 2000-feature frame)
+        // is counted first - a second walk over keypoint records that are in L1/L2 by then - so that the slot still serves
+        // it in the common case and the overflow region only ever holds what is really written.
+        int need = total;
+        if (total > kSlot) {
+          need = 0;
+          for (int t0 = 0; t0 < total; t0 += 64) {
+            const int t = t0 + lane;
+            int pos, idx;
+            const bool pass = t < total && staticTest(t, pos, idx);
+            need += __popcll(__ballot(pass));
+          }
+        }
         unsigned base;
         bool ok = true;
-        if (total <= kSlot) {
+        if (need <= kSlot) {
           base = blockIdx.y * poolPerCall + (unsigned)q * kSlot;
         } else {
           unsigned off = 0;
-          if (lane == 0) off = atomicAdd(poolHeads + blockIdx.y, (unsigned)total);
+          if (lane == 0) off = atomicAdd(poolHeads + blockIdx.y, (unsigned)need);
           off = __shfl(off, 0, 64);
           const unsigned ovfBase = (unsigned)maxQ * kSlot;
-          ok = ovfBase + off + (unsigned)total <= poolPerCall;
+          ok = ovfBase + off + (unsigned)need <= poolPerCall;
           base = blockIdx.y * poolPerCall + ovfBase + off;
           if (!ok && lane == 0) atomicMax(status, 1);
         }
-        if (ok) {
+        if (ok && need > 0) {
           int written = 0;
           const uint4* qd = reinterpret_cast<const uint4*>(C.qdesc + (size_t)q * 32);
           const uint4 qa = qd[0], qb = qd[1];
           for (int t0 = 0; t0 < total; t0 += 64) {
             const int t = t0 + lane;
-            bool pass = false;
-            int idx = 0, dist = 0;
-            if (t < total) {
-              int lo = 0, hi = nx - 1;  // first column whose inclusive prefix exceeds t
-              while (lo < hi) { const int mid = (lo + hi) >> 1; if (pref[wv][mid] > t) hi = mid; else lo = mid + 1; }
-              const int pos = sStart[wv][lo] + (t - (lo ? pref[wv][lo - 1] : 0));
-              const float4 kp = F.sortedKp[pos];
-              const int octave = __float_as_int(kp.z);
-              idx = __float_as_int(kp.w);
-              pass = true;
-              if (Q.minLevel > 0 || Q.maxLevel >= 0)
-                if (octave < Q.minLevel || (Q.maxLevel >= 0 && octave < Q.maxLevel)) pass = false;
-              if (!(fabsf(__fsub_rn(kp.x, Q.u)) > Q.r && fabsf(__fsub_rn(kp.y, Q.v)) < Q.r)) pass = false;
-              if (pass && C.mode == 6) {
-                // fuseByProjection's candidate test (orbMatcher.cpp:711-718): level predicted-1 .. predicted and the chi-square test
-                // on the squared reprojection error — pow(float, 2.0) sums in double, stored to float, times the float inverse sigma^2
-                const float rx = F.rightX ? F.rightX[idx] : -1.0f;
-                const double ax = (double)__fsub_rn(kp.x, Q.u), ay = (double)__fsub_rn(kp.y, Q.v), ar = (double)__fsub_rn(rx, Q.ur);
-                const float monoErr = (float)(ax * ax + ay * ay);
-                const float stereoErr = (float)((double)monoErr + ar * ar);
-                const bool lv = octave >= Q.level - 1 && octave <= Q.level;
-                const float is2 = calls[blockIdx.y].invSigma2[octave & 7];   // indexed from global memory: a dynamic index into the local copy of the call record would move the whole record to scratch
-                pass = lv && ((rx >= 0 && (double)__fmul_rn(stereoErr, is2) <= 7.81) || (rx < 0 && (double)__fmul_rn(monoErr, is2) <= 5.99));
-              } else if (pass && C.mode == 7) {
-                pass = octave >= Q.level - 1 && octave <= Q.level;   // searchByProjectionInSim's explicit level window (orbMatcher.cpp:283-285)
-              } else if (pass && C.mode != 2 && F.rightX) {
-                const float rx = F.rightX[idx];
-                if (!(rx <= 0 || fabsf(__fsub_rn(Q.ur, rx)) <= Q.rs)) pass = false;
-              }
-              if (pass) {
-                const uint4* td = reinterpret_cast<const uint4*>(F.sortedDesc + (size_t)pos * 32);
-                const uint4 ta = td[0], tb = td[1];
-                dist = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) + __popc(qb.x ^ tb.x) +
-                       __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
-              }
+            int pos = 0, idx = 0, dist = 0;
+            const bool pass = t < total && staticTest(t, pos, idx);
+            if (pass) {
+              const uint4* td = reinterpret_cast<const uint4*>(F.sortedDesc + (size_t)pos * 32);
+              const uint4 ta = td[0], tb = td[1];
+              dist = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) + __popc(qb.x ^ tb.x) +
+                     __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
             }
             const unsigned long long m = __ballot(pass);
             if (pass) pool[base + written + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)dist << 16) | (uint32_t)idx;

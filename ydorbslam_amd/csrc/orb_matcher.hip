@@ -80,6 +80,7 @@ struct ydorb_matcher {
   float hSf[8] = {0};
   bool hIdentAffine = false;
   std::vector<int32_t> consecPairs;
+  int ovfPerKeypoint = 16;
   bool profiling = false;
   hipEvent_t ev[MS_COUNT + 1]{};
   double stageMs[MS_COUNT]{};
@@ -638,7 +639,7 @@ int ydorb_match_pairs_device(ydorb_matcher_t* m, const YdFrameSetDev* Q, const Y
   HIPCHK(hipSetDevice(m->device));
   hipStream_t s = stream ? (hipStream_t)stream : m->stream;
   const int cap = Q->cap, nFrames = T->n_frames;
-  const size_t poolPerCall = (size_t)cap * kSlot + (size_t)cap * 16;  // fixed slots + overflow region
+  const size_t poolPerCall = (size_t)cap * kSlot + (size_t)cap * m->ovfPerKeypoint;  // fixed slots + overflow region (records of queries with > kSlot candidates)
   int rc;
   if ((rc = m->queries.ensure(sizeof(QueryDev) * (size_t)cap * nCalls)) || (rc = m->taken.ensure((size_t)cap * nCalls)) ||
       (rc = m->matchQ.ensure(sizeof(int) * (size_t)cap * nCalls)) || (rc = m->qInfo.ensure(sizeof(int2) * (size_t)cap * nCalls)) ||
@@ -734,7 +735,9 @@ int ydorb_matcher_synchronize(ydorb_matcher_t* m) {
     HIPCHK(hipMemcpy(hmisc, m->misc.p, sizeof(hmisc), hipMemcpyDeviceToHost));
     if (hmisc[1] != 0) {
       (void)hipMemset(m->misc.p, 0, 8);
-      set_error("candidate record pool overflow in the batched search (%u records)", (unsigned)hmisc[0]);
+      m->ovfPerKeypoint *= 4;   // the next batched call gets a larger overflow region
+      set_error("candidate record pool overflow in the batched search: results of that call are incomplete; the overflow region is now %d records per keypoint, call again",
+                m->ovfPerKeypoint);
       return YDORB_ERR_CAPACITY;
     }
   }

@@ -186,3 +186,104 @@ def synth_vocabulary(k=10, levels=3, seed=0, early_leaf_frac=0.0, stopped_frac=0
         weight[u] = 0.0 if rng.random() < stopped_frac else float(np.log(1.0 + rng.uniform(0.5, 200.0)))
     return dict(levels=levels, child_begin=child_begin, child_ids=np.array(child_ids, np.int32), node_desc=np.stack(desc),
                 node_weight=weight, node_word=word, n_words=len(leaves))
+
+
+# ---------------------------------------------------------------------------------------------
+# Synthetic frame STREAM (SURVEY.md §8(d) "synthetic matching workload"): every frame distinct, frame t+1 = frame t seen after a
+# small known motion (roll within +-3 deg and shift within +-8 px per step), so that consecutive-frame matching has true
+# correspondences and a known position prediction.
+# ---------------------------------------------------------------------------------------------
+def _sample_bilinear(canvas, xs, ys):
+    x0 = np.floor(xs).astype(np.int32); y0 = np.floor(ys).astype(np.int32)
+    fx = (xs - x0).astype(np.float32); fy = (ys - y0).astype(np.float32)
+    np.clip(x0, 0, canvas.shape[1] - 2, out=x0); np.clip(y0, 0, canvas.shape[0] - 2, out=y0)
+    a = canvas[y0, x0]; b = canvas[y0, x0 + 1]; c = canvas[y0 + 1, x0]; d = canvas[y0 + 1, x0 + 1]
+    return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+
+
+def stream_plan(w, h, n_frames, seed=0, segment=64, pred_sigma=1.5):
+    """Motion of a stream of n_frames frames (cheap; every rank of a multi-GPU run computes the plan of the WHOLE stream and renders
+    only the frames it owns).  Every `segment` frames share one scene; frame t views it through a similarity (rotation theta_t about the
+    image centre, shift T_t): a bounded random walk with steps |dtheta| <= 3 deg, |dT| <= 8 px (rng seed 2000 + seed).  A new segment
+    is a scene cut.  Returns dict(pose [F,3] (theta, tx, ty), affine [F-1,6] f32: the 2x3 map taking a pixel of frame t to its place in
+    frame t+1 (identity across a cut), predicted [F-1,6] f32: the same with the translation off by N(0, pred_sigma^2) px (a motion
+    model's prediction error), cut [F-1] bool, plus the arguments)."""
+    rng = np.random.default_rng(2000 + seed)
+    cx, cy = (w - 1) * 0.5, (h - 1) * 0.5
+    poses = np.zeros((n_frames, 3))
+    aff = np.zeros((max(n_frames - 1, 0), 6), np.float32)
+    pred = np.zeros_like(aff)
+    cut = np.zeros(max(n_frames - 1, 0), bool)
+    lim = np.array([np.deg2rad(9.0), 24.0, 24.0])
+    pose = None
+    for t in range(n_frames):
+        if t % segment == 0:
+            new = np.array([rng.uniform(-lim[0], lim[0]) * 0.3, rng.uniform(-8, 8), rng.uniform(-8, 8)])
+            is_cut = True
+        else:
+            step = np.array([np.deg2rad(rng.uniform(-3, 3)), rng.uniform(-8, 8), rng.uniform(-8, 8)])
+            new = pose + step
+            over = np.abs(new) > lim                      # reflect at the bounds: the walk stays inside the canvas margin
+            new[over] = pose[over] - step[over]
+            is_cut = False
+        if t > 0:
+            if is_cut:
+                A = np.array([1, 0, 0, 0, 1, 0], np.float64)
+            else:  # p' = c + R1^T (R0 (p - c) + T0 - T1)
+                c0, s0, c1, s1 = np.cos(pose[0]), np.sin(pose[0]), np.cos(new[0]), np.sin(new[0])
+                R0 = np.array([[c0, -s0], [s0, c0]]); R1 = np.array([[c1, -s1], [s1, c1]])
+                M = R1.T @ R0
+                cvec = np.array([cx, cy])
+                off = cvec + R1.T @ (pose[1:] - new[1:]) - M @ cvec
+                A = np.array([M[0, 0], M[0, 1], off[0], M[1, 0], M[1, 1], off[1]])
+            aff[t - 1] = A
+            P = A.copy()
+            if not is_cut:
+                P[2] += rng.normal(0, pred_sigma); P[5] += rng.normal(0, pred_sigma)
+            pred[t - 1] = P
+            cut[t - 1] = is_cut
+        pose = new
+        poses[t] = pose
+    return dict(w=w, h=h, n_frames=n_frames, seed=seed, segment=segment, pose=poses, affine=aff, predicted=pred, cut=cut)
+
+
+def stream_render(plan, indices, stereo=False, disparities=(7, 15, 26), margin=112):
+    """Render the frames `indices` of a planned stream: the segment's scene `synth_frame(w + 2*margin, h + 2*margin, seed*1000 + s)`
+    sampled bilinearly through the frame's similarity, plus N(0,1) sensor noise (rng seeded per frame, so the pixels of frame t do not
+    depend on which process renders it).  Returns (frames [n,h,w] u8, right [n,h,w] u8 or None); the rectified right view shows the
+    same rows with the scene moved left by a per-band disparity, with independent N(0,1.5^2) noise."""
+    w, h, seed, segment = plan["w"], plan["h"], plan["seed"], plan["segment"]
+    cx, cy = (w - 1) * 0.5, (h - 1) * 0.5
+    indices = list(indices)
+    frames = np.empty((len(indices), h, w), np.uint8)
+    right = np.empty((len(indices), h, w), np.uint8) if stereo else None
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    xx -= cx; yy -= cy
+    bands = np.linspace(0, h, len(disparities) + 1).astype(int)
+    drow = np.zeros((h, 1), np.float32)
+    for b, d in enumerate(disparities):
+        drow[bands[b]:bands[b + 1]] = d
+    canvases = {}
+    for i, t in enumerate(indices):
+        sg = t // segment
+        if sg not in canvases:
+            canvases = {sg: synth_frame(w + 2 * margin, h + 2 * margin, seed * 1000 + sg).astype(np.float32)}   # keep one
+        canvas = canvases[sg]
+        pose = plan["pose"][t]
+        rng = np.random.default_rng([3000 + seed, t])
+        c_, s_ = np.float32(np.cos(pose[0])), np.float32(np.sin(pose[0]))
+        xs = c_ * xx - s_ * yy + np.float32(cx + pose[1] + margin)
+        ys = s_ * xx + c_ * yy + np.float32(cy + pose[2] + margin)
+        img = _sample_bilinear(canvas, xs, ys) + rng.normal(0, 1.0, (h, w)).astype(np.float32)
+        frames[i] = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+        if stereo:
+            img = _sample_bilinear(canvas, xs + c_ * drow, ys + s_ * drow) + rng.normal(0, 1.5, (h, w)).astype(np.float32)
+            right[i] = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    return frames, right
+
+
+def synth_stream(w=640, h=480, n_frames=64, seed=0, segment=64, stereo=False, disparities=(7, 15, 26), margin=112, pred_sigma=1.5):
+    """stream_plan + stream_render of every frame: dict(frames, right, affine, predicted, cut)."""
+    plan = stream_plan(w, h, n_frames, seed, segment, pred_sigma)
+    frames, right = stream_render(plan, range(n_frames), stereo, disparities, margin)
+    return dict(frames=frames, right=right, affine=plan["affine"], predicted=plan["predicted"], cut=plan["cut"])
