@@ -165,17 +165,11 @@ def main():
     d_desc = [t[lo:lo + F] for t in g_desc]
     d_n = [t[lo:lo + F] for t in g_n]
     # pairs (query = predecessor in the global stream, target = an owned frame), as indices into the gathered (rank-major) set
-    pairs, pair_aff = [], []
-    for t in range(F):
-        g = t * world + rank
-        if g == 0:
-            continue
-        pr, pt = (g - 1) % world, (g - 1) // world
-        pairs.append((pr * F + pt, lo + t))
-        pair_aff.append(plan["predicted"][g - 1])
-    pairs = np.array(pairs, np.int32)
+    from ydorbslam_amd.parallel import round_robin_pairs
+    pairs, pred_idx = round_robin_pairs(rank, world, F)
+    pair_aff = plan["predicted"][pred_idx]
     NPAIR = len(pairs)
-    d_aff = torch.from_numpy(np.ascontiguousarray(np.stack(pair_aff), np.float32)).to(dev)
+    d_aff = torch.from_numpy(np.ascontiguousarray(pair_aff, np.float32)).to(dev)
     d_assigned = [torch.zeros((NPAIR, cap), dtype=torch.int32, device=dev) for _ in range(2)]
     d_counts = [torch.zeros(NPAIR, dtype=torch.int32, device=dev) for _ in range(2)]
     sAs, sB = [torch.cuda.Stream(device=dev) for _ in range(NEX)], torch.cuda.Stream(device=dev)

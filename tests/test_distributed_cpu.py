@@ -58,6 +58,51 @@ def _worker(rank, world, port, q):
     res["chi2_sum"], res["n_pts"], res["n_edges"] = part.tolist()
     res["chi2_full"] = chi2(prob)
     res["n_pts_full"], res["n_edges_full"] = len(prob["points"]), len(prob["edge_pose"])
+    # 4. SURVEY 8(e) match exchange: frames dealt round-robin, all-gather of every rank's [keypoints | descriptors | count] records
+    #    (each rank's outputs ARE its slice of the gathered set), then a local match of the pairs whose later frame the rank owns.
+    #    The records are real (oracle extraction of a small stream); the union over ranks must equal the consecutive matching of the
+    #    whole stream done by one process.
+    from ydorbslam_amd.synth import stream_plan, stream_render
+    Wd, Hd, Fr = 320, 240, 3
+    G = Fr * world
+    plan = stream_plan(Wd, Hd, G, seed=5, segment=G)
+    oex = o.OrbExtractorOracle(300)
+    cap2 = int(oex.tables()["per_level"].sum())
+    sfo = oex.tables()["scale"]
+    KP = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+    g_kps = torch.zeros((G, cap2, 28), dtype=torch.uint8); g_desc = torch.zeros((G, cap2, 32), dtype=torch.uint8); g_n = torch.zeros(G, dtype=torch.int32)
+    own = [t * world + rank for t in range(Fr)]
+    frames, _ = stream_render(plan, own)
+    for t in range(Fr):
+        k, d = oex.extract(frames[t])
+        g_kps[rank * Fr + t, :len(k)] = torch.from_numpy(k.view(np.uint8).reshape(-1, 28).copy())
+        g_desc[rank * Fr + t, :len(k)] = torch.from_numpy(d.copy())
+        g_n[rank * Fr + t] = len(k)
+    for full in (g_kps, g_desc, g_n):
+        mine = full[rank * Fr:(rank + 1) * Fr]
+        dist.all_gather_into_tensor(full, mine.clone())
+
+    def match(kq, dq, kt, dt_, A):
+        q = np.zeros(len(kq), o.QUERY_DTYPE)
+        A = A.astype(np.float32)
+        q["u"] = (A[0] * kq["x"] + A[1] * kq["y"]) + A[2]; q["v"] = (A[3] * kq["x"] + A[4] * kq["y"]) + A[5]
+        q["r"] = (np.float32(15.0) * sfo[kq["octave"]]).astype(np.float32)
+        q["min_level"], q["max_level"] = kq["octave"] - 1, kq["octave"] + 1
+        q["angle"], q["level"] = kq["angle"], kq["octave"]
+        q["flags"] = np.where((q["u"] >= 0) & (q["u"] < Wd) & (q["v"] >= 0) & (q["v"] < Hd), 3, 0)
+        n_, a_, _ = o.FrameOracle(kt, dt_, (0.0, float(Wd), 0.0, float(Hd))).search_by_projection(1, q, dq, 0.9, True)
+        return n_, a_.tolist()
+
+    def rec(i):
+        n_ = int(g_n[i])
+        return g_kps[i, :n_].numpy().reshape(-1).view(KP).copy(), g_desc[i, :n_].numpy().copy()
+    pairs, pred = par.round_robin_pairs(rank, world, Fr)
+    res["pairs"] = pairs.tolist()
+    res["match"] = {int(p): match(*rec(qi), *rec(ti), plan["predicted"][p]) for (qi, ti), p in zip(pairs, pred)}
+    if rank == 0:   # the same stream, one process, consecutive pairs
+        allf, _ = stream_render(plan, range(G))
+        recs = [oex.extract(f) for f in allf]
+        res["match_single"] = {g: match(*recs[g], *recs[g + 1], plan["predicted"][g]) for g in range(G - 1)}
     mx = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     res["max"] = mx.item()
@@ -85,3 +130,15 @@ def test_two_rank_gloo():
         assert res["n_pts"] == res["n_pts_full"] and res["n_edges"] == res["n_edges_full"]
         assert abs(res["chi2_sum"] - res["chi2_full"]) <= 1e-9 * res["chi2_full"]
         assert res["max"] == world
+    # every consecutive pair of the stream is matched exactly once, by the owner of its later frame, with the single-process answer
+    merged = {}
+    for r in range(world):
+        for g, v in out[r]["match"].items():
+            assert g not in merged and (g + 1) % world == r
+            merged[g] = v
+    single = out[0]["match_single"]
+    assert sorted(merged) == sorted(single) == list(range(world * 3 - 1))
+    for g in single:
+        assert merged[g][0] == single[g][0] and merged[g][1] == single[g][1], "pair %d" % g
+    assert sum(v[0] for v in single.values()) > 0
+    assert out[1]["pairs"][0] == [0, 3]        # rank 1's frame 0 (global 1) is searched for rank 0's frame 0 (global 0)

@@ -1,11 +1,14 @@
 """Multi-GPU host logic (one process per GPU, torch.distributed over RCCL): how the hot path shards.
 
-* extract + match: frames are independent units -> contiguous chunks per rank, no collective for extraction; the frame
-  pair that straddles two ranks needs one exchange: an all-gather of each rank's LAST frame record
-  (keypoints 28 B + descriptors 32 B per keypoint + count), after which rank r matches (last frame of rank r-1) -> (its frame 0).
+* extract + match: frames are independent units.  The frames of a stream are dealt ROUND-ROBIN (global frame g lives on rank
+  g % world as local frame g // world), so extraction needs no collective and every consecutive pair straddles two ranks.  Per
+  step each rank all-gathers every rank's [keypoints 28 B | descriptors 32 B | count] records (three large collectives straight
+  out of the extractor's output buffers, which ARE this rank's slice of the gathered set: no packing copy), then matches, locally
+  against the gathered set, the pairs whose later frame it owns (`round_robin_pairs`); greedy acceptance stays with that owner.
+  (`frame_shard` / `pack_boundary`: the contiguous-chunk alternative, where only the chunk boundary frame is exchanged.)
 * local BA: landmarks (and their edges) shard across ranks, every rank holds all poses; per LM trial one all-reduce(sum)
   of the reduced camera system (+ small reductions of chi2 / scale), see ydorbslam_amd/csrc/ba_solver.hip.
-Nothing here computes on the hot path; it only slices inputs and packs records.
+Nothing here computes on the hot path; it only slices inputs and plans index lists.
 """
 import numpy as np
 
@@ -15,6 +18,22 @@ def frame_shard(n_frames, rank, world):
     base, rem = divmod(n_frames, world)
     begin = rank * base + min(rank, rem)
     return begin, begin + base + (1 if rank < rem else 0)
+
+
+def round_robin_pairs(rank, world, frames_per_rank):
+    """Pairs (query, target) this rank matches, as indices into the gathered set laid out rank-major ([world][frames_per_rank]):
+    target = an owned frame t (global g = t*world + rank), query = its predecessor g-1 in the stream, which lives on rank
+    (g-1) % world.  Returns (pairs [n,2] int32, pred [n] = g-1, the index of the pair's motion / affine in the stream)."""
+    F = frames_per_rank
+    pairs, pred = [], []
+    for t in range(F):
+        g = t * world + rank
+        if g == 0:
+            continue
+        pr, pt = (g - 1) % world, (g - 1) // world
+        pairs.append((pr * F + pt, rank * F + t))
+        pred.append(g - 1)
+    return np.array(pairs, np.int32).reshape(-1, 2), np.array(pred, np.int64)
 
 
 def boundary_record_bytes(cap):
