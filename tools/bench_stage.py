@@ -5,7 +5,7 @@ import numpy as np
 import ydorbslam_amd as y
 from ydorbslam_amd.synth import synth_frame
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-imgs = np.stack([synth_frame(640, 480, i % 16) for i in range(F)])
+imgs = np.stack([synth_frame(640, 480, i % 32) for i in range(F)])
 ex = y.OrbExtractor(1000, max_batch=F)
 ex.extract_batch(imgs)
 ex.set_profiling(True)

@@ -252,187 +252,213 @@ __global__ __launch_bounds__(256) void k_pyr_borders(uint8_t* __restrict__ pyr, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// FAST-9/16 (cv::FAST, call site orbExtractor.cpp:581).  The kernel is VALU-issue bound (rocprofv3: SQ_ACTIVE_INST_VALU x 4
-// = SIMD cycles of the launch), so the three tests are arranged for few vector instructions and no workgroup traffic:
+// FAST-9/16 (cv::FAST, call site orbExtractor.cpp:581).  The kernel is VALU-issue bound, and on gfx950 the vector instructions
+// come in two speed classes (tools/ubench/valu_rate*.hip, 8 waves per SIMD: ~1.05 ns per wave-instruction for 32-bit add / sub /
+// and / or / xor / shifts, f32 add / mul / fma and the 16-bit VOP2 forms v_min/max/add/sub/mul_lo_u16; ~1.8 ns for everything that
+// needs a VOP3 encoding - packed i16, perm, bfe, mad, min3/med3, lshl_or - and also for 32-bit and f32 min / max, compares, cndmask,
+// mbcnt, cvt).  So the per-pixel work below is written on uint16_t values (the compiler selects the 16-bit VOP2 forms) with as
+// few compares / conversions as possible:
 //   compass test : a 9-arc of the 16-ring always contains >= 2 of the 4 compass pixels, so "second largest compass pixel
-//                  > v + t or second smallest < v - t" is necessary (min/max network, 2 compares);
-//   arc test + score : d = v - ring as 8 packed i16 pairs (d[j], d[j+8]); max over the 16 arcs of min(d) and of min(-d) by a
-//                  doubling network of v_pk_min/max_i16 (rotations by 8 are the half swap, free via op_sel).  The larger of
-//                  the two IS OpenCV's cornerScore<16> + 1, and "> t" IS the strict 9-contiguous segment test, so one
-//                  network answers both;
-//   NMS          : strictly greater than the 8 neighbours in the cell's score map.
-// Each of the 4 waves owns a contiguous block of band rows and keeps its survivors in its own LDS segment, compacted in place
-// with ballots: inside a wave LDS accesses are ordered, so there is no workgroup barrier until the score map is complete.
+//                  > v + t or second smallest < v - t" is necessary: 8 x v_min/max_u16, two subtractions whose sign bits are
+//                  the two answers, ONE compare for the ballot;
+//   arc test + score : d = (v - ring) * polarity as 8 packed i16 pairs (d[j], d[j+8]) built by one v_pk_mad_i16 each; the
+//                  maximum over the 16 circular 9-arcs of min(d) from prefix / suffix minima of the two 8-blocks (29 packed
+//                  operations; the doubling network took 39).  That maximum IS OpenCV's cornerScore<16> + 1, and "> t" IS the
+//                  strict 9-contiguous segment test, so one network answers both;
+//   NMS          : strictly greater than the maximum of the 8 neighbours in the cell's score map.
+// ONE WAVE PER CELL: the 4 waves of a workgroup take 4 consecutive cells and never meet (no workgroup barrier, no cross-wave
+// offsets); inside a wave LDS accesses are ordered.  A wave walks its band two rows per step (32 lanes per row; cells wider than
+// 32 px - only where a level is < 62 px across - one row per step), keeps the pixels that pass a stage in its own LDS list,
+// compacted in place with ballots (row-major = the order cv::FAST returns them), and feeds the list to the next stage, so the
+// expensive arc network runs on full waves of survivors of the whole cell.
 // ------------------------------------------------------------------------------------------------
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s16x2 pk_swap(s16x2 x) { return __builtin_shufflevector(x, x, 1, 0); }
 __device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
-// max over the 16 circular 9-arcs of the minimum (MIN = true) or min over the arcs of the maximum (MIN = false) of d[0..15]
-template <bool MIN>
-__device__ __forceinline__ int fast_arc_extreme(const s16x2 (&P)[8]) {
-  s16x2 a[8], b[8];
+// max over the 16 circular 9-arcs of the minimum of d[0..15], d as pairs P[j] = (d[j], d[j + 8]).
+// The arc that starts at k < 8 is d[k..7] + d[8..8+k] = min(suffix_lo[k], prefix_hi[k]); the one that starts at 8 + k is
+// d[8+k..15] + d[0..k] = min(suffix_hi[k], prefix_lo[k]): both at once as pk_min(suffix[k], swap(prefix[k])).
+__device__ __forceinline__ int fast_arc_best(const s16x2 (&P)[8]) {
+  s16x2 pre[8], suf[8];
+  pre[0] = P[0];
 #pragma unroll
-  for (int j = 0; j < 8; j++) { const s16x2 o = j < 7 ? P[j + 1] : pk_swap(P[0]); a[j] = MIN ? pk_min(P[j], o) : pk_max(P[j], o); }          // 2 wide
+  for (int j = 1; j < 8; j++) pre[j] = pk_min(pre[j - 1], P[j]);
+  suf[7] = P[7];
 #pragma unroll
-  for (int j = 0; j < 8; j++) { const s16x2 o = j < 6 ? a[j + 2] : pk_swap(a[j - 6]); b[j] = MIN ? pk_min(a[j], o) : pk_max(a[j], o); }      // 4 wide
+  for (int j = 6; j >= 0; j--) suf[j] = pk_min(suf[j + 1], P[j]);
+  s16x2 m[8];
 #pragma unroll
-  for (int j = 0; j < 8; j++) { const s16x2 o = j < 4 ? b[j + 4] : pk_swap(b[j - 4]); a[j] = MIN ? pk_min(b[j], o) : pk_max(b[j], o); }      // 8 wide
-#pragma unroll
-  for (int j = 0; j < 8; j++) { const s16x2 o = pk_swap(P[j]); b[j] = MIN ? pk_min(a[j], o) : pk_max(a[j], o); }                             // 9 wide
-  s16x2 r;
-  if (MIN) r = pk_max(pk_max(pk_max(b[0], b[1]), pk_max(b[2], b[3])), pk_max(pk_max(b[4], b[5]), pk_max(b[6], b[7])));
-  else r = pk_min(pk_min(pk_min(b[0], b[1]), pk_min(b[2], b[3])), pk_min(pk_min(b[4], b[5]), pk_min(b[6], b[7])));
-  return MIN ? max((int)r.x, (int)r.y) : min((int)r.x, (int)r.y);
+  for (int j = 0; j < 8; j++) m[j] = pk_min(suf[j], pk_swap(pre[j]));
+  const s16x2 r = pk_max(pk_max(pk_max(m[0], m[1]), pk_max(m[2], m[3])), pk_max(pk_max(m[4], m[5]), pk_max(m[6], m[7])));
+  return max((int)r.x, (int)r.y);
 }
 
-constexpr int kFastSeg = ((kTileMax - 6 + 3) / 4) * (kTileMax - 6);   // band pixels one wave can own
+// number of set bits of a ballot below this lane (v_mbcnt_lo + v_mbcnt_hi)
+__device__ __forceinline__ int wave_rank(unsigned long long m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// LDS of one wave: [tile rows x PITCH][score map][candidate list]; sizes come from the plan's largest cell (host: fastLdsLayout)
+struct FastLds { int tileBytes, scoreBytes, listBytes; };
 
 // ------------------------------------------------------------------------------------------------
-// One workgroup per (cell, frame): cv::FAST(cell sub-image, thr, nms=true) — orbExtractor.cpp:562-590.
+// One wave per (cell, frame): cv::FAST(cell sub-image, thr, nms=true) — orbExtractor.cpp:562-590.
 // FAST never looks outside the sub-image, so each cell has a private 3-px dead border and NMS sees
 // zeros outside the cell's detection band.  Survivors are written in row-major order (the order
 // cv::FAST returns them) into the cell's fixed slot; the quad-tree kernel concatenates cells in
 // (row, col) order, which reproduces keyPointsToDistr.  The retry at :583 uses the same threshold
 // (m_int_minFastThd is initialised from _initFastThd, :318), so it is a no-op and is not launched.
+// PITCH = LDS row pitch of the tile (48 when every cell tile is <= 44 px wide, else 80): a compile-time constant, so the ring
+// offsets are immediates of the ds_read instructions.
 // ------------------------------------------------------------------------------------------------
+template <int PITCH>
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyrFrameStride, PlanDev P,
-                                                    const CellDev* __restrict__ cells, int thr,
+                                                    const CellDev* __restrict__ cells, int thr, FastLds lds,
                                                     uint32_t* __restrict__ cellCount, uint32_t* __restrict__ cellCand) {
-  __shared__ __align__(4) uint8_t tile[kTileMax * kTileMax];
-  __shared__ uint8_t score[(kTileMax - 4) * (kTileMax - 4)];
-  __shared__ uint16_t list[4][kFastSeg];   // per wave: (band row << 7) | band column | darker-arcs flag << 14 | brighter << 15
-  __shared__ int cntD[4];
+  extern __shared__ __align__(16) uint8_t fastSmem[];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint8_t* tile = fastSmem + (size_t)wv * (lds.tileBytes + lds.scoreBytes + lds.listBytes);
+  uint8_t* score = tile + lds.tileBytes;
+  uint16_t* list = reinterpret_cast<uint16_t*>(score + lds.scoreBytes);   // (band row << 6) | band column | darker-arcs flag << 14 | brighter << 15
   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own L2); gridDim.x is a multiple of 8, so
   // block (bx, f) runs on XCD bx % 8.  Inside every group of 8 frames the (bx, f) pairs are permuted so that XCD x processes ALL
   // cells of frame 8*(f/8) + x: the 6-px halo a cell shares with its neighbours (and the level a frame's cells share) is then
   // fetched into one L2 instead of eight, while different XCDs still stream different frames (no channel hot-spot).
-  int cellId = blockIdx.x, f = blockIdx.y;
+  int grp = blockIdx.x, f = blockIdx.y;
   if ((f | 7) < (int)gridDim.y) {   // a full group of 8 frames
-    cellId = (f & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    grp = (f & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     f = (f & ~7) | (blockIdx.x & 7);
   }
-  if (cellId >= P.nCellsTotal) return;
+  const int cellId = grp * 4 + wv;
+  if (cellId >= P.nCellsTotal) return;   // (waves never synchronise with each other)
   const CellDev c = cells[cellId];
-  const LevelDev L = P.lv[c.level];
+  const int pitch = P.lv[c.level].pitch;
   const int tw = c.x1 - c.x0, th = c.y1 - c.y0;
   const int bw = tw - 6, bh = th - 6;  // detection band
   const size_t slot = (size_t)f * P.nCellsTotal + cellId;
   if (bw <= 0 || bh <= 0) {
-    if (threadIdx.x == 0) cellCount[slot] = 0;
+    if (lane == 0) cellCount[slot] = 0;
     return;
   }
-  {  // tile load: (unaligned) dwords, up to 18 per row (reads past tw stay inside the level's 19-px padding); thread = (row mod 16,
-     // dword column): no index arithmetic beyond one multiply-add per pass
+  {  // tile load: unaligned 8-byte loads (reads past tw stay inside the level's 19-px padding), ALL of a lane's rows in flight before
+     // the first LDS write: the kernel is otherwise paced by the round trips of these loads (one wave = one cell, nothing to overlap).
+     // PITCH 48: lane = (row mod 8, 8-byte column 0..5), <= 6 rows per lane; PITCH 80: (row mod 4, column 0..9), groups of 6 rows.
+    constexpr int COLS = PITCH == 48 ? 8 : 16, ROWS = 64 / COLS, NR = 6;
     const uint8_t* sub = pyr + (size_t)f * pyrFrameStride + c.srcOff;
-    const int wpr = (tw + 3) >> 2, ty0 = threadIdx.x >> 4, wd = threadIdx.x & 15;
-    for (int ty = ty0; ty < th; ty += 16) {
-      if (wd < wpr) *reinterpret_cast<uint32_t*>(&tile[ty * kTileMax + 4 * wd]) = *reinterpret_cast<const u32_unaligned*>(sub + ty * L.pitch + 4 * wd);
-      if (wd + 16 < wpr) *reinterpret_cast<uint32_t*>(&tile[ty * kTileMax + 4 * wd + 64]) = *reinterpret_cast<const u32_unaligned*>(sub + ty * L.pitch + 4 * wd + 64);
+    const int wpr = (tw + 7) >> 3, ty0 = lane / COLS, wd = lane % COLS;
+    const bool colOk = wd < wpr;
+    for (int tyb = 0; tyb < th; tyb += ROWS * NR) {
+      unsigned long long r[NR];
+#pragma unroll
+      for (int k = 0; k < NR; k++) {
+        const int ty = tyb + ty0 + ROWS * k;
+        r[k] = (colOk && ty < th) ? *reinterpret_cast<const u64_unaligned*>(sub + (size_t)ty * pitch + 8 * wd) : 0ull;
+      }
+#pragma unroll
+      for (int k = 0; k < NR; k++) {
+        const int ty = tyb + ty0 + ROWS * k;
+        if (colOk && ty < th) *reinterpret_cast<unsigned long long*>(tile + ty * PITCH + 8 * wd) = r[k];
+      }
     }
   }
   const int sw = bw + 2, sh = bh + 2;  // score map with a zero ring
-  for (int i = threadIdx.x; i < (sw * sh + 3) >> 2; i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const unsigned long long below = (1ull << lane) - 1ull;
-  uint16_t* seg = list[wv];
-  const float rbw = 1.0f / (float)bw;   // i / bw as (int)((i + 0.5f) * rbw): exact for i < 4096
-  // stage A: compass test over this wave's rows of the band
+  for (int i = lane; i < (sw * sh + 3) >> 2; i += 64) reinterpret_cast<uint32_t*>(score)[i] = 0;
+  __builtin_amdgcn_wave_barrier();
+  // stage A: compass test over the band.  Two rows of <= 32 columns per step, or one row of <= 64.
   int n1 = 0;
   {
-    const int iEnd = ((bh * (wv + 1)) >> 2) * bw;
-    for (int base = ((bh * wv) >> 2) * bw; base < iEnd; base += 64) {
-      const int i = base + lane;
-      bool keep = false;
-      unsigned ent = 0;
-      if (i < iEnd) {
-        const int by = (int)(((float)i + 0.5f) * rbw), bx = i - by * bw;
-        const uint8_t* p = &tile[(by + 3) * kTileMax + bx + 3];
-        const int v = p[0];
-        const int a = p[3 * kTileMax], b = p[-3 * kTileMax], cc = p[3], d = p[-3];
-        const int lo1 = min(a, b), hi1 = max(a, b), lo2 = min(cc, d), hi2 = max(cc, d);
-        const int second = max(max(lo1, lo2), min(hi1, hi2)), third = min(min(hi1, hi2), max(lo1, lo2));
-        const bool cb = second > v + thr, cd = third < v - thr;   // >= 2 brighter / >= 2 darker compass pixels
-        keep = cb || cd;
-        ent = (unsigned)(by << 7) | (unsigned)bx | (cd ? 0x4000u : 0u) | (cb ? 0x8000u : 0u);   // which arc polarity can still pass
-      }
-      const unsigned long long m = __ballot(keep);
-      if (keep) seg[n1 + __popcll(m & below)] = (uint16_t)ent;
+    const bool wide = bw > 32;
+    const int bxl = wide ? lane : (lane & 31), byl = wide ? 0 : (lane >> 5), rowsPerIt = wide ? 1 : 2;
+    const uint8_t* p = tile + (byl + 3) * PITCH + bxl + 3;
+    unsigned ent = (unsigned)(byl << 6) | (unsigned)bxl;
+    const uint16_t t16 = (uint16_t)thr;
+    auto step = [&](bool valid) {
+      const uint16_t v = p[0], a = p[3 * PITCH], b = p[-3 * PITCH], cc = p[3], d = p[-3];
+      const uint16_t lo1 = min(a, b), hi1 = max(a, b), lo2 = min(cc, d), hi2 = max(cc, d);
+      const uint16_t mx = max(lo1, lo2), mn = min(hi1, hi2);
+      const uint16_t second = max(mx, mn), third = min(mn, mx);
+      const uint16_t s1 = (uint16_t)((uint16_t)(v + t16) - second);   // sign set: >= 2 brighter compass pixels
+      const uint16_t s2 = (uint16_t)(third - (uint16_t)(v - t16));    // sign set: >= 2 darker compass pixels
+      const bool keep = ((int16_t)(s1 | s2) < 0) & valid;
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+      if (keep) list[n1 + wave_rank(m)] = (uint16_t)(ent | (s1 & 0x8000u) | ((s2 & 0x8000u) >> 1));
       n1 += __popcll(m);
-    }
+      p += rowsPerIt * PITCH;
+      ent += rowsPerIt * 64;
+    };
+    const bool colOk = bxl < bw;
+    int by0 = 0;
+    for (; by0 + rowsPerIt <= bh; by0 += rowsPerIt) step(colOk);
+    if (by0 < bh) step(colOk && byl == 0);   // odd band height: only the first row of the last step is inside
   }
-  // stage B: arc test and score in one network; corners stay in the segment (compacted in place: writes never pass the reads)
+  __builtin_amdgcn_wave_barrier();
+  // stage B: arc test and score in one network; corners stay in the list (compacted in place: writes never pass the reads)
   int n2 = 0;
   for (int base = 0; base < n1; base += 64) {
     const int j = base + lane;
     bool keep = false;
     unsigned ent = 0;
-    int sc = 0, si = 0;
     if (j < n1) {
-      ent = seg[j];
-      const int by = (ent >> 7) & 127, bx = ent & 127;
-      const uint8_t* p = &tile[(by + 3) * kTileMax + bx + 3];
+      ent = list[j];
+      const int by = (ent >> 6) & 127, bx = ent & 63;
+      const uint8_t* p = tile + (by + 3) * PITCH + bx + 3;
       const short v = (short)p[0];
-      const s16x2 vv = {v, v};
       // One polarity per pixel: the compass test already says whether the darker or the brighter arcs can pass (a pixel cannot
       // be a corner both ways: 9 + 9 > 16), so d is sign-adjusted and ONE min-network runs.  The few pixels whose compass test
-      // passed both ways get the second polarity in a wave-uniform extra step.
+      // passed both ways get the other polarity in a wave-uniform extra step.
       const bool dark = (ent & 0x4000u) != 0;
       const s16x2 sg = dark ? s16x2{1, 1} : s16x2{-1, -1};
-      s16x2 Pd[8];
-      Pd[0] = (vv - s16x2{(short)p[3 * kTileMax], (short)p[-3 * kTileMax]}) * sg;
-      Pd[1] = (vv - s16x2{(short)p[3 * kTileMax + 1], (short)p[-3 * kTileMax - 1]}) * sg;
-      Pd[2] = (vv - s16x2{(short)p[2 * kTileMax + 2], (short)p[-2 * kTileMax - 2]}) * sg;
-      Pd[3] = (vv - s16x2{(short)p[kTileMax + 3], (short)p[-kTileMax - 3]}) * sg;
-      Pd[4] = (vv - s16x2{(short)p[3], (short)p[-3]}) * sg;
-      Pd[5] = (vv - s16x2{(short)p[-kTileMax + 3], (short)p[kTileMax - 3]}) * sg;
-      Pd[6] = (vv - s16x2{(short)p[-2 * kTileMax + 2], (short)p[2 * kTileMax - 2]}) * sg;
-      Pd[7] = (vv - s16x2{(short)p[-3 * kTileMax + 1], (short)p[3 * kTileMax - 1]}) * sg;
-      int best = fast_arc_extreme<true>(Pd);
-      if (__ballot((ent & 0xC000u) == 0xC000u)) {   // some pixel of this chunk needs the brighter arcs too
-        if ((ent & 0xC000u) == 0xC000u) best = max(best, -fast_arc_extreme<false>(Pd));
+      const s16x2 vs = s16x2{v, v} * sg, ng = -sg;
+      s16x2 Pd[8];   // (v - ring) * sg = vs + ring * (-sg): one packed multiply-add per opposite pair
+      Pd[0] = s16x2{(short)p[3 * PITCH], (short)p[-3 * PITCH]} * ng + vs;
+      Pd[1] = s16x2{(short)p[3 * PITCH + 1], (short)p[-3 * PITCH - 1]} * ng + vs;
+      Pd[2] = s16x2{(short)p[2 * PITCH + 2], (short)p[-2 * PITCH - 2]} * ng + vs;
+      Pd[3] = s16x2{(short)p[PITCH + 3], (short)p[-PITCH - 3]} * ng + vs;
+      Pd[4] = s16x2{(short)p[3], (short)p[-3]} * ng + vs;
+      Pd[5] = s16x2{(short)p[-PITCH + 3], (short)p[PITCH - 3]} * ng + vs;
+      Pd[6] = s16x2{(short)p[-2 * PITCH + 2], (short)p[2 * PITCH - 2]} * ng + vs;
+      Pd[7] = s16x2{(short)p[-3 * PITCH + 1], (short)p[3 * PITCH - 1]} * ng + vs;
+      int best = fast_arc_best(Pd);
+      if (__builtin_amdgcn_ballot_w64((ent & 0xC000u) == 0xC000u)) {   // some pixel of this chunk needs the brighter arcs too
+        if ((ent & 0xC000u) == 0xC000u) {
+          s16x2 Nd[8];
+#pragma unroll
+          for (int k = 0; k < 8; k++) Nd[k] = -Pd[k];
+          best = max(best, fast_arc_best(Nd));
+        }
       }
       keep = best > thr;
-      sc = best - 1;                               // cornerScore<16>: max(t, arcs) - 1
-      si = (by + 1) * sw + bx + 1;
+      if (keep) score[(by + 1) * sw + bx + 1] = (uint8_t)(best - 1);   // cornerScore<16>: max(t, arcs) - 1
     }
-    const unsigned long long m = __ballot(keep);
-    if (keep) {
-      seg[n2 + __popcll(m & below)] = (uint16_t)ent;
-      score[si] = (uint8_t)sc;
-    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+    if (keep) list[n2 + wave_rank(m)] = (uint16_t)ent;
     n2 += __popcll(m);
   }
-  __syncthreads();
-  // stage C: NMS (strictly greater than the 8 neighbours; zeros outside the band), again compacted in place
+  __builtin_amdgcn_wave_barrier();
+  // stage C: NMS (strictly greater than the 8 neighbours; zeros outside the band) and the ordered output
   int n3 = 0;
+  uint32_t* dst = cellCand + slot * P.cellCap;
   for (int base = 0; base < n2; base += 64) {
     const int j = base + lane;
     bool keep = false;
-    unsigned ent = 0;
+    uint32_t rec = 0;
     if (j < n2) {
-      ent = seg[j];
-      const uint8_t* q = &score[(((ent >> 7) & 127) + 1) * sw + (ent & 127) + 1];
-      const int s = q[0];
-      keep = s > q[-1] && s > q[1] && s > q[-sw - 1] && s > q[-sw] && s > q[-sw + 1] && s > q[sw - 1] && s > q[sw] && s > q[sw + 1];
+      const unsigned ent = list[j];
+      const int by = (ent >> 6) & 127, bx = ent & 63;
+      const uint8_t* q = &score[(by + 1) * sw + bx + 1];
+      const uint16_t s = q[0];
+      const uint16_t nb = max(max(max((uint16_t)q[-1], (uint16_t)q[1]), max((uint16_t)q[-sw - 1], (uint16_t)q[-sw])),
+                              max(max((uint16_t)q[-sw + 1], (uint16_t)q[sw - 1]), max((uint16_t)q[sw], (uint16_t)q[sw + 1])));
+      keep = s > nb;
+      rec = qt_pack(c.x0 + 3 + bx - kBorder, c.y0 + 3 + by - kBorder, s);
     }
-    const unsigned long long m = __ballot(keep);
-    if (keep) seg[n3 + __popcll(m & below)] = (uint16_t)ent;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+    const int pos = n3 + wave_rank(m);
+    if (keep && pos < P.cellCap) dst[pos] = rec;
     n3 += __popcll(m);
   }
-  if (lane == 0) cntD[wv] = n3;
-  __syncthreads();
-  // ordered output: the waves' row blocks are consecutive, so wave w's keypoints follow those of waves < w
-  int off = 0;
-  for (int w = 0; w < wv; w++) off += cntD[w];
-  uint32_t* dst = cellCand + slot * P.cellCap;
-  for (int j = lane; j < n3; j += 64) {
-    const unsigned ent = seg[j];
-    const int by = (ent >> 7) & 127, bx = ent & 127, pos = off + j;
-    if (pos < P.cellCap) dst[pos] = qt_pack(c.x0 + 3 + bx - kBorder, c.y0 + 3 + by - kBorder, score[(by + 1) * sw + bx + 1]);
-  }
-  if (threadIdx.x == 0) cellCount[slot] = (uint32_t)min(cntD[0] + cntD[1] + cntD[2] + cntD[3], P.cellCap);
+  if (lane == 0) cellCount[slot] = (uint32_t)min(n3, P.cellCap);
 }
 
 

@@ -31,6 +31,7 @@ struct HostPlan {
   PlanDev dev{};
   std::vector<CellDev> cells;
   size_t pyrFrameStride = 0, blurFrameStride = 0, qtFrameStride = 0;
+  int maxCellDim = 0;   // largest FAST cell (without its 6-px halo): sizes the per-wave LDS of k_fast_cells
   // quad-tree launch geometry per level: node table for 4*quota nodes, LDS-resident candidates up to candCap (HBM beyond)
   struct QtLevel { int nodeCap, candCap; size_t lds; int flatItems; size_t flatLds; bool passOk; } qt[kMaxLevels]{};
   size_t qtLdsMax = 0;
@@ -208,6 +209,7 @@ int buildPlan(ydorb_extractor* e, int w, int h, HostPlan& P) {
     return YDORB_ERR_UNSUPPORTED;
   }
   D.nCellsTotal = (int)P.cells.size();
+  P.maxCellDim = maxCellDim;
   // NMS survivors are pairwise non-adjacent: at most ceil(w/2)*ceil(h/2) per cell band
   D.cellCap = alignUp(std::max(((maxCellDim + 1) / 2) * ((maxCellDim + 1) / 2), 64), 64);
   D.sumQuota = kpOff;
@@ -379,9 +381,26 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
     hipLaunchKernelGGL(k_pyr_borders, dim3(D.borderBegin[D.nLevels] / 256, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, D);
   }
   if (prof) HIPCHK(hipEventRecord(e->ev[1], s));
-  if (D.nCellsTotal > 0)
-    hipLaunchKernelGGL(k_fast_cells, dim3((D.nCellsTotal + 7) / 8 * 8, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, D, e->d_cells,
-                       std::min(std::max(e->cfg.ini_fast_thr, 0), 255), e->d_cellCount, e->d_cellCand);
+  if (D.nCellsTotal > 0) {
+    // one wave per cell, 4 cells per workgroup; the per-wave LDS (tile, score map, candidate list) is sized for the plan's largest cell
+    const int maxT = P.maxCellDim + 6, maxB = P.maxCellDim;
+    const bool narrow = maxT <= 44;
+    const int pitch = narrow ? 48 : 80;
+    FastLds fl;
+    fl.tileBytes = alignUp((maxT + 3) * pitch, 16);                 // + 3 rows: lanes outside the band still read (and discard) a ring
+    fl.scoreBytes = alignUp((maxB + 2) * (maxB + 2) + 4, 16);
+    fl.listBytes = alignUp(2 * maxB * maxB, 16);
+    const size_t dyn = (size_t)4 * (fl.tileBytes + fl.scoreBytes + fl.listBytes);
+    const int thr = std::min(std::max(e->cfg.ini_fast_thr, 0), 255);
+    const dim3 grid(((D.nCellsTotal + 3) / 4 + 7) / 8 * 8, nFrames);
+    if (narrow) {
+      if (dyn > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells<48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+      hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(256), dyn, s, e->d_pyr, P.pyrFrameStride, D, e->d_cells, thr, fl, e->d_cellCount, e->d_cellCand);
+    } else {
+      if (dyn > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells<80>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+      hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(256), dyn, s, e->d_pyr, P.pyrFrameStride, D, e->d_cells, thr, fl, e->d_cellCount, e->d_cellCand);
+    }
+  }
   if (prof) HIPCHK(hipEventRecord(e->ev[2], s));
   // fork: the blur (needs only the pyramid) goes first on `s` so that it heads its hardware queue; the quad-tree launches, one
   // per level on the side streams, wait for the FAST results only and overlap it
