@@ -547,7 +547,7 @@ def main():
     if extras and hasattr(y.OrbMatcher, "hamming_topk_device"):
         NB_ = min(F - 1, 255)
         mb = y.OrbMatcher(device=local_rank)
-        d_best = torch.zeros((NB_, cap, 4), dtype=torch.int32, device=dev)
+        d_best = torch.zeros((NB_, cap, 6), dtype=torch.int32, device=dev)
         mb.hamming_topk_device(d_desc[0].data_ptr(), d_n[0].data_ptr(), d_desc[0][1:].data_ptr(), d_n[0][1:].data_ptr(), cap, NB_, d_best.data_ptr())
         torch.cuda.synchronize()
         tb_ = time.perf_counter()

@@ -291,6 +291,22 @@ typedef struct YdFrameSetDev {
 int ydorb_match_pairs_device(ydorb_matcher_t* h, const YdFrameSetDev* queries, const YdFrameSetDev* targets, const int32_t* pairs,
                              int32_t n_pairs, int32_t width, int32_t height, float th, const float* scale_factors, int32_t n_levels,
                              const float* d_affine, int32_t check_orientation, int32_t* d_assigned, int32_t* d_counts, void* stream);
+/* Brute-force 256-bit Hamming top-2 (BASELINE north_star).  For every query descriptor the result of the reference's
+ * best / second-best chain (orbMatcher.cpp:39-52 and the same chain at :327-334, :404-417, :518-528) over its candidates in list
+ * order: best = the FIRST candidate with the least distance, second = the first one with the least distance among the others;
+ * both start at 256 and only a strictly smaller distance replaces them (dist 256 / index -1 = none).  *_rank = position in the
+ * query's candidate list (what breaks ties), *_idx = the target row.
+ * Host form: q [nq][32], t [nt][32]; candidates of query i = cand_idx[cand_offsets[i] .. cand_offsets[i+1]) (CSR), or - with
+ * cand_offsets == cand_idx == NULL - all nt targets in index order.  nt <= 65535 per list. */
+typedef struct YdMatch2 {
+  int32_t best_dist, best_idx, second_dist, second_idx, best_rank, second_rank;
+} YdMatch2;
+int ydorb_hamming_topk(ydorb_matcher_t* h, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, const int32_t* cand_offsets,
+                       const int32_t* cand_idx, YdMatch2* out);
+/* Device-resident all-pairs form for n_pairs (query frame, target frame) pairs laid out [n_pairs][cap][32] with per-pair counts:
+ * d_out [n_pairs][cap] YdMatch2.  Asynchronous on `stream` (or the matcher's own). */
+int ydorb_hamming_topk_device(ydorb_matcher_t* h, const uint8_t* d_qdesc, const int32_t* d_nq, const uint8_t* d_tdesc, const int32_t* d_nt,
+                              int32_t cap, int32_t n_pairs, YdMatch2* d_out, void* stream);
 int ydorb_matcher_synchronize(ydorb_matcher_t* h);
 /* average device ms of grid build / gather / resolve over calls since enabling (HIP events on the launch stream) */
 int ydorb_matcher_set_profiling(ydorb_matcher_t* h, int32_t on);

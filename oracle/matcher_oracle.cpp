@@ -380,6 +380,27 @@ int yo_search_for_triangulation(const void* kpsA, const uint8_t* descA, int nA, 
   return matchNum;
 }
 
+// Brute-force top-2 over a candidate list: the best / second-best chain of the searches as written (orbMatcher.cpp:39-52; the same
+// chain at :327-334, :404-417): both start at 256, `dist < best` shifts best into second, `else if dist < second` replaces second.
+// out per query: best_dist, best_idx, second_dist, second_idx, best_rank, second_rank (rank = position in the list, -1 = none).
+void yo_hamming_topk(const uint8_t* q, int nq, const uint8_t* t, int nt, const int* candOff, const int* candIdx, int* out) {
+  for (int i = 0; i < nq; i++) {
+    const int c0 = candOff ? candOff[i] : 0, c1 = candOff ? candOff[i + 1] : nt;
+    int best = 256, second = 256, bestRank = -1, secondRank = -1;
+    for (int r = 0; r < c1 - c0; r++) {
+      const int idx = candIdx ? candIdx[c0 + r] : r;
+      if (idx < 0 || idx >= nt) continue;
+      const int d = descriptorDistance(q + (size_t)i * 32, t + (size_t)idx * 32);
+      if (d < best) { second = best; secondRank = bestRank; best = d; bestRank = r; }
+      else if (d < second) { second = d; secondRank = r; }
+    }
+    int* o = out + (size_t)i * 6;
+    o[0] = best; o[1] = bestRank < 0 ? -1 : (candIdx ? candIdx[c0 + bestRank] : bestRank);
+    o[2] = second; o[3] = secondRank < 0 ? -1 : (candIdx ? candIdx[c0 + secondRank] : secondRank);
+    o[4] = bestRank; o[5] = secondRank;
+  }
+}
+
 void yo_three_maxima(const int* sizes, int L, int* idx3) {
   std::vector<std::vector<int>> h(L);
   for (int i = 0; i < L; i++) h[i].assign(sizes[i], 0);

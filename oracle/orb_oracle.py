@@ -216,6 +216,23 @@ QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("r", "<f4"), ("min_level", 
                         ("ur", "<f4"), ("rs", "<f4"), ("angle", "<f4"), ("level", "<i4"), ("flags", "<i4")])
 
 
+MATCH2_DTYPE = np.dtype([("best_dist", "<i4"), ("best_idx", "<i4"), ("second_dist", "<i4"), ("second_idx", "<i4"), ("best_rank", "<i4"),
+                         ("second_rank", "<i4")])
+
+
+def hamming_topk(q, t, cand_offsets=None, cand_idx=None):
+    """Best / second-best chain of orbMatcher.cpp:39-52 over each query's candidate list (all targets when no lists are given)."""
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32); t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    out = np.zeros(len(q), MATCH2_DTYPE)
+    co = None if cand_offsets is None else np.ascontiguousarray(cand_offsets, np.int32)
+    ci = None if cand_idx is None else np.ascontiguousarray(cand_idx, np.int32)
+    f = lib().yo_hamming_topk
+    f.restype = None
+    f.argtypes = [C.c_void_p] + [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 3
+    f(_p(q), len(q), _p(t), len(t), None if co is None else _p(co), None if ci is None or len(ci) == 0 else _p(ci), _p(out))
+    return out
+
+
 def descriptor_distance(a, b):
     a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
     return lib().yo_descriptor_distance(_p(a), _p(b))

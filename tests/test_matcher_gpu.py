@@ -273,3 +273,40 @@ def test_distinctive_descriptors_batch(oracle_lib):
     want = [oracle_lib.distinctive_descriptor(g) if len(g) else -1 for g in groups]
     assert list(got) == want
     assert len(y.OrbMatcher().distinctive_descriptors([])) == 0
+
+
+def test_hamming_topk_brute_force(oracle_lib, scene):
+    """ydorb_hamming_topk (north_star: brute-force 256-bit Hamming top-2 with wave min-reductions): the CSR-candidate form, the
+    all-targets form and the device-resident all-pairs form all equal the oracle's best / second-best chain, ties included."""
+    import torch
+    import ydorbslam_amd as y
+    s = scene[0]
+    da, db = s["da"].copy(), s["db"].copy()
+    db[5] = da[0]; db[9] = da[0]; db[700 % len(db)] = da[0]          # a three-way tie at distance 0 for query 0
+    m = y.OrbMatcher()
+    ref = oracle_lib.hamming_topk(da, db)
+    got = m.hamming_topk(da, db)
+    assert got.tobytes() == ref.tobytes()
+    assert got[0]["best_idx"] == 5 and got[0]["second_idx"] == 9 and got[0]["best_dist"] == 0 == got[0]["second_dist"]
+    rng = np.random.default_rng(3)
+    sizes = rng.integers(0, 200, len(da)); sizes[3] = 0; sizes[4] = 1
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    cand = rng.integers(0, len(db), int(offs[-1])).astype(np.int32)
+    ref = oracle_lib.hamming_topk(da, db, offs, cand)
+    got = m.hamming_topk(da, db, offs, cand)
+    assert got.tobytes() == ref.tobytes()
+    assert got[3].tolist() == (256, -1, 256, -1, -1, -1) and got[4]["second_idx"] == -1
+    # device form: two (query frame, target frame) pairs in [pairs][cap][32] layout
+    cap = max(len(da), len(db)) + 7
+    dev = torch.device("cuda:0")
+    qd = np.zeros((2, cap, 32), np.uint8); td = np.zeros((2, cap, 32), np.uint8)
+    qd[0, :len(da)] = da; td[0, :len(db)] = db; qd[1, :len(db)] = db; td[1, :len(da)] = da
+    nq = np.array([len(da), len(db)], np.int32); nt = np.array([len(db), len(da)], np.int32)
+    d_q, d_t = torch.from_numpy(qd).to(dev), torch.from_numpy(td).to(dev)
+    d_nq, d_nt = torch.from_numpy(nq).to(dev), torch.from_numpy(nt).to(dev)
+    d_out = torch.zeros((2, cap, 6), dtype=torch.int32, device=dev)
+    m.hamming_topk_device(d_q.data_ptr(), d_nq.data_ptr(), d_t.data_ptr(), d_nt.data_ptr(), cap, 2, d_out.data_ptr())
+    m.synchronize()
+    out = d_out.cpu().numpy()
+    assert np.array_equal(out[0, :len(da)], oracle_lib.hamming_topk(da, db).view(np.int32).reshape(-1, 6))
+    assert np.array_equal(out[1, :len(db)], oracle_lib.hamming_topk(db, da).view(np.int32).reshape(-1, 6))

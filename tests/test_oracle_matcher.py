@@ -233,3 +233,34 @@ def test_distinctive_descriptor_numpy_statement(oracle_lib):
             d = np.unpackbits(g[:, None, :] ^ g[None, :, :], axis=2).sum(axis=2)
             med = np.sort(d, axis=1)[:, int(0.5 * m)]
             assert oracle_lib.distinctive_descriptor(g) == int(np.argmin(med)), (seed, m)
+
+
+def test_hamming_topk_chain_against_numpy(oracle_lib):
+    """yo_hamming_topk = the best / second-best chain of orbMatcher.cpp:39-52.  Independent statement: stable argsort of the
+    distances gives the first minimum and the first minimum of the rest; a distance of 256 never replaces the initial 256."""
+    rng = np.random.default_rng(11)
+    q = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (90, 32), dtype=np.uint8)
+    t[7] = t[3]; t[50] = t[3]; q[0] = t[3]                      # ties at distance 0
+    q[1] = 0; t[10] = 255                                       # distance 256
+    offs = [0]
+    cand = []
+    for i in range(len(q)):
+        n = int(rng.integers(0, 30)) if i != 1 else 1
+        c = rng.integers(0, len(t), n) if i != 1 else np.array([10])
+        cand += list(c); offs.append(len(cand))
+    for co, ci in ((None, None), (np.array(offs, np.int32), np.array(cand, np.int32))):
+        got = oracle_lib.hamming_topk(q, t, co, ci)
+        for i in range(len(q)):
+            lst = np.arange(len(t)) if ci is None else ci[co[i]:co[i + 1]]
+            d = np.unpackbits(q[i][None] ^ t[lst], axis=1).sum(axis=1) if len(lst) else np.zeros(0, int)
+            order = np.argsort(d, kind="stable")
+            order = [r for r in order if d[r] < 256]
+            exp = [256, -1, 256, -1, -1, -1]
+            if len(order) > 0:
+                exp[0], exp[1], exp[4] = int(d[order[0]]), int(lst[order[0]]), int(order[0])
+            if len(order) > 1:
+                exp[2], exp[3], exp[5] = int(d[order[1]]), int(lst[order[1]]), int(order[1])
+            assert list(got[i].tolist()) == exp, (i, got[i], exp)
+    assert oracle_lib.hamming_topk(q[:1], t)[0]["best_idx"] == 3 and oracle_lib.hamming_topk(q[:1], t)[0]["second_idx"] == 7
+    assert oracle_lib.hamming_topk(q[1:2], t, np.array([0, 1], np.int32), np.array([10], np.int32))[0].tolist() == (256, -1, 256, -1, -1, -1)

@@ -69,6 +69,8 @@ SYMBOLS = {
     "ydorb_stereo_matches": (C.c_int, [_VP, _VP, _VP, _I, C.c_float, C.c_float, _I, _VP, _VP, _VP, _VP, _VP]),
     "ydorb_match_consecutive_device": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, C.c_float, _VP, _I, _VP, _I, _VP, _VP, _VP]),
     "ydorb_match_pairs_device": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, C.c_float, _VP, _I, _VP, _I, _VP, _VP, _VP]),
+    "ydorb_hamming_topk": (C.c_int, [_VP, _VP, _I, _VP, _I, _VP, _VP, _VP]),
+    "ydorb_hamming_topk_device": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
     "ydorb_matcher_synchronize": (C.c_int, [_VP]),
     "ydorb_matcher_set_profiling": (C.c_int, [_VP, _I]),
     "ydorb_matcher_stage_times": (C.c_int, [_VP, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_I)]),

@@ -567,4 +567,99 @@ __global__ __launch_bounds__(256) void k_queries_from_keypoints(const CallDev* _
   out[i] = Q;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Brute-force 256-bit Hamming top-2 (north_star; SURVEY 8(b) ydorb_hamming_topk).  The answer per query is what the reference's
+// if / else-if chain leaves after walking the candidates in order (orbMatcher.cpp:39-52, 327-334, ...): best = FIRST candidate with
+// the least distance, second = first candidate with the least distance among the others; both start at 256 and only a strictly
+// smaller distance replaces them.  With key = distance << 16 | rank (rank = position in the candidate list, so keys are distinct and
+// ordered by (distance, rank)) that is: the two smallest keys below 256 << 16.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
+  unsigned r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+struct TopkOut { int bestDist, bestIdx, secondDist, secondIdx, bestRank, secondRank; };   // == YdMatch2
+constexpr unsigned kTopkInit = 256u << 16;
+
+// all pairs, one lane per query: the lane keeps its query in 8 registers, the workgroup stages 256 targets at a time in LDS and every
+// lane walks them with wave-uniform (broadcast) ds_read_b128: per pair 8 v_xor + 8 v_bcnt (accumulating) + key + min + med3.
+// grid = (ceil(cap / 256), pairs).  q / t: [pairs][cap][32] with per-pair counts nq / nt (device).
+__global__ __launch_bounds__(256) void k_topk_allpairs(const uint8_t* __restrict__ qdesc, const int* __restrict__ nqPtr, size_t qStride,
+                                                       const uint8_t* __restrict__ tdesc, const int* __restrict__ ntPtr, size_t tStride,
+                                                       int cap, TopkOut* __restrict__ out) {
+  __shared__ __align__(16) uint4 tl[256][2];
+  const int pr = blockIdx.y;
+  const int nq = min(nqPtr[pr], cap), nt = min(ntPtr[pr], cap);
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 >= nq) return;   // the whole workgroup is past the queries
+  const uint8_t* Q = qdesc + (size_t)pr * qStride;
+  const uint8_t* T = tdesc + (size_t)pr * tStride;
+  uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+  if (q < nq) { qa = reinterpret_cast<const uint4*>(Q + (size_t)q * 32)[0]; qb = reinterpret_cast<const uint4*>(Q + (size_t)q * 32)[1]; }
+  unsigned k1 = kTopkInit, k2 = kTopkInit;
+  for (int t0 = 0; t0 < nt; t0 += 256) {
+    __syncthreads();
+    if (t0 + (int)threadIdx.x < nt) {
+      tl[threadIdx.x][0] = reinterpret_cast<const uint4*>(T + (size_t)(t0 + threadIdx.x) * 32)[0];
+      tl[threadIdx.x][1] = reinterpret_cast<const uint4*>(T + (size_t)(t0 + threadIdx.x) * 32)[1];
+    }
+    __syncthreads();
+    auto one = [&](int j) {
+      const uint4 ta = tl[j][0], tb = tl[j][1];
+      const unsigned d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) + __popc(qb.x ^ tb.x) +
+                         __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+      const unsigned key = (d << 16) | (unsigned)(t0 + j);
+      const unsigned lo = min(k1, key);
+      k2 = umed3(k1, k2, key);   // second smallest of (k1 <= k2, key)
+      k1 = lo;
+    };
+    if (nt - t0 >= 256) {
+#pragma unroll 4
+      for (int j = 0; j < 256; j++) one(j);
+    } else {
+      for (int j = 0; j < nt - t0; j++) one(j);
+    }
+  }
+  if (q < nq) {
+    TopkOut o;
+    o.bestDist = (int)(k1 >> 16); o.bestIdx = o.bestRank = k1 < kTopkInit ? (int)(k1 & 0xFFFFu) : -1;
+    o.secondDist = (int)(k2 >> 16); o.secondIdx = o.secondRank = k2 < kTopkInit ? (int)(k2 & 0xFFFFu) : -1;
+    out[(size_t)pr * cap + q] = o;
+  }
+}
+
+// candidate lists (CSR), one wave per query: lanes stride over the list, each keeps its two smallest keys; the wave's best is a
+// DPP wave-min (wave_min_u32 above), the lane that held it promotes its own runner-up, and a second wave-min gives the second.
+__global__ __launch_bounds__(256) void k_topk_csr(const uint8_t* __restrict__ qdesc, int nq, const uint8_t* __restrict__ tdesc, int nt,
+                                                  const int* __restrict__ candOff, const int* __restrict__ candIdx, TopkOut* __restrict__ out) {
+  const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= nq) return;
+  const int c0 = candOff ? candOff[q] : 0, c1 = candOff ? candOff[q + 1] : nt;
+  const uint4 qa = reinterpret_cast<const uint4*>(qdesc + (size_t)q * 32)[0], qb = reinterpret_cast<const uint4*>(qdesc + (size_t)q * 32)[1];
+  unsigned k1 = kTopkInit, k2 = kTopkInit;
+  for (int r = lane; r < c1 - c0; r += 64) {
+    const int idx = candIdx ? candIdx[c0 + r] : r;
+    if (idx < 0 || idx >= nt) continue;
+    const uint4 ta = reinterpret_cast<const uint4*>(tdesc + (size_t)idx * 32)[0], tb = reinterpret_cast<const uint4*>(tdesc + (size_t)idx * 32)[1];
+    const unsigned d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) + __popc(qb.x ^ tb.x) +
+                       __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+    const unsigned key = (d << 16) | (unsigned)r;
+    const unsigned lo = min(k1, key);
+    k2 = umed3(k1, k2, key);
+    k1 = lo;
+  }
+  const unsigned b = wave_min_u32(k1);
+  if (k1 == b && b < kTopkInit) k1 = k2;          // keys are distinct: exactly one lane held the best
+  const unsigned s2 = wave_min_u32(k1);
+  if (lane == 0) {
+    TopkOut o;
+    o.bestDist = (int)(b >> 16); o.bestRank = b < kTopkInit ? (int)(b & 0xFFFFu) : -1;
+    o.secondDist = (int)(s2 >> 16); o.secondRank = s2 < kTopkInit ? (int)(s2 & 0xFFFFu) : -1;
+    o.bestIdx = o.bestRank < 0 ? -1 : (candIdx ? candIdx[c0 + o.bestRank] : o.bestRank);
+    o.secondIdx = o.secondRank < 0 ? -1 : (candIdx ? candIdx[c0 + o.secondRank] : o.secondRank);
+    out[q] = o;
+  }
+}
+
 }  // namespace ydorb

@@ -725,6 +725,57 @@ int ydorb_match_consecutive_device(ydorb_matcher_t* m, const YdKeyPoint* d_kps, 
                                   d_counts, stream);
 }
 
+int ydorb_hamming_topk(ydorb_matcher_t* m, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, const int32_t* candOffsets,
+                       const int32_t* candIdx, YdMatch2* out) {
+  static_assert(sizeof(YdMatch2) == sizeof(TopkOut), "YdMatch2 layout");
+  if (!m || nq < 0 || nt < 0 || nt > 65535 || (nq && (!q || !out)) || (nt && !t) || ((candOffsets == nullptr) != (candIdx == nullptr))) {
+    set_error("invalid argument");
+    return YDORB_ERR_INVALID_ARG;
+  }
+  if (nq == 0) return YDORB_OK;
+  int rc = require_device(m->device);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(m->device));
+  size_t nCand = 0;
+  if (candOffsets) {
+    if (candOffsets[0] != 0) { set_error("cand_offsets[0] must be 0"); return YDORB_ERR_INVALID_ARG; }
+    for (int i = 0; i < nq; i++) {
+      const int n = candOffsets[i + 1] - candOffsets[i];
+      if (n < 0 || n > 65535) { set_error("candidate list %d has %d entries (0..65535 supported)", i, n); return YDORB_ERR_INVALID_ARG; }
+    }
+    nCand = (size_t)candOffsets[nq];
+  }
+  hipStream_t s = m->stream;
+  if ((rc = m->qdesc.ensure((size_t)32 * nq)) || (rc = m->desc.ensure((size_t)32 * std::max(nt, 1))) || (rc = m->pool.ensure(sizeof(TopkOut) * (size_t)nq)) ||
+      (rc = m->cellStart.ensure(sizeof(int) * ((size_t)nq + 1))) || (rc = m->cellIdx.ensure(sizeof(int) * std::max<size_t>(nCand, 1))))
+    return rc;
+  HIPCHK(hipMemcpyAsync(m->qdesc.p, q, (size_t)32 * nq, hipMemcpyHostToDevice, s));
+  if (nt) HIPCHK(hipMemcpyAsync(m->desc.p, t, (size_t)32 * nt, hipMemcpyHostToDevice, s));
+  if (candOffsets) {
+    HIPCHK(hipMemcpyAsync(m->cellStart.p, candOffsets, sizeof(int) * ((size_t)nq + 1), hipMemcpyHostToDevice, s));
+    if (nCand) HIPCHK(hipMemcpyAsync(m->cellIdx.p, candIdx, sizeof(int) * nCand, hipMemcpyHostToDevice, s));
+  }
+  hipLaunchKernelGGL(k_topk_csr, dim3((nq + 3) / 4), dim3(256), 0, s, m->qdesc.as<uint8_t>(), nq, m->desc.as<uint8_t>(), nt,
+                     candOffsets ? m->cellStart.as<int>() : nullptr, candOffsets ? m->cellIdx.as<int>() : nullptr, m->pool.as<TopkOut>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, m->pool.p, sizeof(TopkOut) * (size_t)nq, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return YDORB_OK;
+}
+
+int ydorb_hamming_topk_device(ydorb_matcher_t* m, const uint8_t* d_qdesc, const int32_t* d_nq, const uint8_t* d_tdesc, const int32_t* d_nt, int32_t cap,
+                              int32_t nPairs, YdMatch2* d_out, void* stream) {
+  if (!m || !d_qdesc || !d_nq || !d_tdesc || !d_nt || !d_out || cap < 1 || cap > 65535 || nPairs < 1) { set_error("invalid argument"); return YDORB_ERR_INVALID_ARG; }
+  int rc = require_device(m->device);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t s = stream ? (hipStream_t)stream : m->stream;
+  hipLaunchKernelGGL(k_topk_allpairs, dim3((cap + 255) / 256, nPairs), dim3(256), 0, s, d_qdesc, d_nq, (size_t)cap * 32, d_tdesc, d_nt, (size_t)cap * 32, cap,
+                     reinterpret_cast<TopkOut*>(d_out));
+  HIPCHK(hipGetLastError());
+  return YDORB_OK;
+}
+
 int ydorb_matcher_synchronize(ydorb_matcher_t* m) {
   if (!m) { set_error("null handle"); return YDORB_ERR_INVALID_ARG; }
   HIPCHK(hipSetDevice(m->device));

@@ -8,6 +8,8 @@ from .extractor import KP_DTYPE
 QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("r", "<f4"), ("min_level", "<i4"), ("max_level", "<i4"),
                         ("ur", "<f4"), ("rs", "<f4"), ("angle", "<f4"), ("level", "<i4"), ("flags", "<i4")])
 assert QUERY_DTYPE.itemsize == 40
+MATCH2_DTYPE = np.dtype([("best_dist", "<i4"), ("best_idx", "<i4"), ("second_dist", "<i4"), ("second_idx", "<i4"), ("best_rank", "<i4"),
+                         ("second_rank", "<i4")])
 
 TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30  # orbMatcher.cpp:7-9
 FRAME_MAPPOINT, LAST_CURRENT, KEYFRAME_CURRENT, BOW_KEYFRAME_FRAME, BOW_TWO_KEYFRAMES = range(5)
@@ -201,6 +203,22 @@ class OrbMatcher:
         Q, T = YdFrameSetDev(*q_set), YdFrameSetDev(*t_set)
         check(self._L.ydorb_match_pairs_device(self._h, C.byref(Q), C.byref(T), _p(pr), len(pr), width, height, th, _p(sf), len(sf), d_affine,
                                                int(self.check_orientation), d_assigned, d_counts, stream))
+
+    def hamming_topk(self, q, t, cand_offsets=None, cand_idx=None):
+        """ydorb_hamming_topk: brute-force top-2 of every query row against its candidate list (CSR) or, without lists, against all
+        target rows.  Returns an array of MATCH2_DTYPE (best_dist, best_idx, second_dist, second_idx, best_rank, second_rank)."""
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        out = np.zeros(len(q), MATCH2_DTYPE)
+        co = None if cand_offsets is None else np.ascontiguousarray(cand_offsets, np.int32)
+        ci = None if cand_idx is None else np.ascontiguousarray(cand_idx, np.int32)
+        if ci is not None and len(ci) == 0:
+            ci = np.zeros(1, np.int32)
+        check(self._L.ydorb_hamming_topk(self._h, _p(q), len(q), _p(t), len(t), _p(co), _p(ci), _p(out)))
+        return out
+
+    def hamming_topk_device(self, d_qdesc, d_nq, d_tdesc, d_nt, cap, n_pairs, d_out, stream=None):
+        check(self._L.ydorb_hamming_topk_device(self._h, d_qdesc, d_nq, d_tdesc, d_nt, cap, n_pairs, d_out, stream))
 
     def synchronize(self):
         check(self._L.ydorb_matcher_synchronize(self._h))
