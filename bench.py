@@ -415,9 +415,9 @@ def main():
         ex1 = y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank)
         one = imgs[3]
         sc = {"extract_ms": med_ms(lambda: ex1.extract(one)),
-              "extract_plus_pyramid_download_ms": med_ms(lambda: (ex1.extract(one), [ex1.read_level(l) for l in range(8)])),
+              "extract_plus_pyramid_download_ms": med_ms(lambda: (ex1.extract(one), ex1.read_pyramid())),
               "note": "median host-to-host wall time of one call: ydorb_extract = H2D 307 KB + ~20 launches + D2H 60 KB; the adapter's "
-                      "m_v_imagePyramid download adds 8 level copies (1.16 MB)"}
+                      "m_v_imagePyramid refresh adds one 1.3 MB device-to-host copy + host repacking (ydorb_extractor_read_pyramid)"}
         ka_, da_ = ex1.extract(imgs[3]); kb_, db_ = ex1.extract(imgs[4])
         q1 = np.zeros(len(ka_), y.QUERY_DTYPE)
         q1["u"], q1["v"] = ka_["x"], ka_["y"]

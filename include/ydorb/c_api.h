@@ -102,6 +102,9 @@ int ydorb_extractor_pyramid(const ydorb_extractor_t* h, int32_t frame, int32_t l
                             int32_t* w, int32_t* hgt, int32_t* stride);
 /* Copy one padded level ((hgt+38) rows x (w+38) bytes, tightly packed) of the last call to host. */
 int ydorb_extractor_read_level(ydorb_extractor_t* h, int32_t frame, int32_t level, uint8_t* dst, size_t dst_bytes);
+/* All levels 0 .. n_levels-1 of one frame in ONE device-to-host transfer: dst_levels[l] receives (hgt_l+38) rows x (w_l+38) bytes,
+ * tightly packed (the layout of ydorb_extractor_read_level).  This is what the adapter's m_v_imagePyramid refresh uses. */
+int ydorb_extractor_read_pyramid(ydorb_extractor_t* h, int32_t frame, uint8_t* const* dst_levels, const size_t* dst_bytes, int32_t n_levels);
 
 /* Test/diagnostic access to intermediate stages of the last call (parity tests compare each stage
  * with the oracle).  what: 0 = blurred level (hgt x w bytes), 1 = pre-quad-tree candidates

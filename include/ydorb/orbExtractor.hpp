@@ -70,14 +70,23 @@ class OrbExtractor {
  protected:
   void downloadPyramid() {
     m_v_imagePyramid.clear();
+    std::vector<cv::Mat> full;
+    std::vector<uint8_t*> ptrs;
+    std::vector<size_t> bytes;
+    std::vector<int32_t> ws, hs;
     for (int l = 0; l < m_int_levelsNum; l++) {
       int32_t w, h, stride;
       const uint8_t* d = nullptr;
-      if (ydorb_extractor_pyramid(m_handle, 0, l, &d, &w, &h, &stride) != YDORB_OK) break;
-      cv::Mat full(h + 38, w + 38, CV_8UC1);
-      if (ydorb_extractor_read_level(m_handle, 0, l, full.data, full.total()) != YDORB_OK) break;
-      m_v_imagePyramid.push_back(full(cv::Rect(19, 19, w, h)));
+      if (ydorb_extractor_pyramid(m_handle, 0, l, &d, &w, &h, &stride) != YDORB_OK) return;
+      full.emplace_back(h + 38, w + 38, CV_8UC1);
+      ptrs.push_back(full.back().data);
+      bytes.push_back(full.back().total());
+      ws.push_back(w); hs.push_back(h);
     }
+    // one device-to-host transfer for all levels
+    if (ydorb_extractor_read_pyramid(m_handle, 0, ptrs.data(), bytes.data(), m_int_levelsNum) != YDORB_OK)
+      throw std::runtime_error(std::string("ydorb: ") + ydorb_last_error());
+    for (int l = 0; l < m_int_levelsNum; l++) m_v_imagePyramid.push_back(full[l](cv::Rect(19, 19, ws[l], hs[l])));
   }
   ydorb_extractor_t* m_handle = nullptr;
   int m_int_levelsNum;

@@ -203,3 +203,17 @@ def test_device_path_reports_capacity_errors_once():
     n = int(d_n.item())
     assert n == len(k1)
     assert np.array_equal(d_desc[0, :n].cpu().numpy(), d1)
+
+
+def test_read_pyramid_single_transfer_equals_level_reads():
+    """ydorb_extractor_read_pyramid (all levels, one device-to-host transfer: the adapter's m_v_imagePyramid refresh) against the
+    per-level reads that are themselves byte-compared with the oracle in test_stages_and_output_bit_exact."""
+    import ydorbslam_amd as y
+    ex = y.OrbExtractor(1000, max_batch=3)
+    imgs = np.stack([synth_frame(752, 480, i) for i in range(3)])
+    ex.extract_batch(imgs)
+    for f in (0, 2):
+        lv = ex.read_pyramid(f)
+        assert len(lv) == 8
+        for l in range(8):
+            assert np.array_equal(lv[l], ex.read_level(l, f)), "frame %d level %d" % (f, l)

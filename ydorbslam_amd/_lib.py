@@ -49,6 +49,7 @@ SYMBOLS = {
     "ydorb_extractor_synchronize": (C.c_int, [_VP]),
     "ydorb_extractor_pyramid": (C.c_int, [_VP, _I, _I, C.POINTER(_VP), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "ydorb_extractor_read_level": (C.c_int, [_VP, _I, _I, _VP, _Z]),
+    "ydorb_extractor_read_pyramid": (C.c_int, [_VP, _I, _VP, _VP, _I]),
     "ydorb_extractor_debug_read": (C.c_int, [_VP, _I, _I, _I, _VP, _Z, C.POINTER(_Z)]),
     "ydorb_extractor_set_profiling": (C.c_int, [_VP, _I]),
     "ydorb_extractor_stage_times": (C.c_int, [_VP, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_I)]),

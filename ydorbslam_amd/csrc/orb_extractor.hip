@@ -66,6 +66,8 @@ struct ydorb_extractor {
   uint8_t* d_nodeScratch = nullptr;  // HBM node tables of the levels whose quota does not fit the LDS (usually none)
   uint8_t* d_needPass = nullptr;   // [frame][level]: 1 = the flat quad-tree kernel left the unit to the pass kernel
   int *d_lvlCount = nullptr, *d_status = nullptr, *d_nOut = nullptr;
+  uint8_t* h_pyr = nullptr;           // pinned staging of one frame's pyramid block (ydorb_extractor_read_pyramid)
+  size_t h_pyrBytes = 0;
   hipStream_t lastStream = nullptr;   // stream of the last enqueue (a caller's stream on the device-resident path)
   int *d_lvlMaxN = nullptr, *h_lvlMaxN = nullptr;   // largest candidate count seen per level (device max, copied back after every call)
   float* d_lvlAngle = nullptr;
@@ -108,7 +110,8 @@ void freeBuffers(ydorb_extractor* e) {
   F(e->d_lvlKp); F(e->d_qtNode); F(e->d_needPass); F(e->d_nodeScratch); F(e->d_lvlCount); F(e->d_lvlMaxN); F(e->d_status); F(e->d_nOut); F(e->d_lvlAngle); F(e->d_cells);
   F(e->d_tabInt); F(e->d_tabShort); F(e->d_kps); F(e->d_desc);
   auto H = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
-  H(e->h_img); H(e->h_kps); H(e->h_desc); H(e->h_nOut); H(e->h_status); H(e->h_lvlMaxN);
+  H(e->h_img); H(e->h_kps); H(e->h_desc); H(e->h_nOut); H(e->h_status); H(e->h_lvlMaxN); H(e->h_pyr);
+  e->h_pyrBytes = 0;
   e->planValid = false;
 }
 
@@ -670,6 +673,37 @@ int ydorb_extractor_read_level(ydorb_extractor_t* e, int32_t frame, int32_t leve
   HIPCHK(hipSetDevice(e->cfg.device));
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy2D(dst, w + 2 * kPad, roi - (size_t)kPad * stride - kPad, stride, w + 2 * kPad, h + 2 * kPad, hipMemcpyDeviceToHost));
+  return YDORB_OK;
+}
+
+int ydorb_extractor_read_pyramid(ydorb_extractor_t* e, int32_t frame, uint8_t* const* dst_levels, const size_t* dst_bytes, int32_t n_levels) {
+  if (!e || !e->planValid || frame < 0 || frame >= e->lastFrames || !dst_levels || !dst_bytes || n_levels < 1 || n_levels > e->cfg.n_levels) {
+    set_error("invalid argument");
+    return YDORB_ERR_INVALID_ARG;
+  }
+  const HostPlan& P = e->plan;
+  for (int l = 0; l < n_levels; l++) {
+    const LevelDev& L = P.dev.lv[l];
+    const size_t need = (size_t)(L.w + 2 * kPad) * (L.h + 2 * kPad);
+    if (!dst_levels[l] || dst_bytes[l] < need) { set_error("level %d needs %zu bytes", l, need); return YDORB_ERR_CAPACITY; }
+  }
+  HIPCHK(hipSetDevice(e->cfg.device));
+  // ONE device-to-host copy of the frame's pyramid block (levels sit back to back, rows at a 64-byte pitch) into pinned staging,
+  // then the rows are repacked on the host: eight pitched copies into pageable memory cost ~1.6 ms each.
+  if (e->h_pyrBytes < P.pyrFrameStride) {
+    if (e->h_pyr) (void)hipHostFree(e->h_pyr);
+    e->h_pyr = nullptr; e->h_pyrBytes = 0;
+    HIPCHK(hipHostMalloc(&e->h_pyr, P.pyrFrameStride));
+    e->h_pyrBytes = P.pyrFrameStride;
+  }
+  hipStream_t s = e->lastStream ? e->lastStream : e->stream;
+  HIPCHK(hipMemcpyAsync(e->h_pyr, e->d_pyr + (size_t)frame * P.pyrFrameStride, P.pyrFrameStride, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  for (int l = 0; l < n_levels; l++) {
+    const LevelDev& L = P.dev.lv[l];
+    const int rowBytes = L.w + 2 * kPad;
+    for (int y = 0; y < L.h + 2 * kPad; y++) memcpy(dst_levels[l] + (size_t)y * rowBytes, e->h_pyr + L.padOff + (size_t)y * L.pitch, rowBytes);
+  }
   return YDORB_OK;
 }
 

@@ -84,6 +84,17 @@ class OrbExtractor:
         check(self._L.ydorb_extractor_read_level(self._h, frame, level, _p(out), out.size))
         return out
 
+    def read_pyramid(self, frame=0):
+        """m_v_imagePyramid of one frame, all levels with their 19-px borders, in one device-to-host transfer."""
+        outs = []
+        for l in range(self.n_levels):
+            w, h, _, _ = self.level_dims(l, frame)
+            outs.append(np.zeros((h + 38, w + 38), np.uint8))
+        ptrs = (C.c_void_p * len(outs))(*[o.ctypes.data for o in outs])
+        sizes = (C.c_size_t * len(outs))(*[o.size for o in outs])
+        check(self._L.ydorb_extractor_read_pyramid(self._h, frame, ptrs, sizes, len(outs)))
+        return outs
+
     def debug_read(self, what, level, frame=0):
         w, h, _, _ = self.level_dims(level, frame)
         written = C.c_size_t(0)
