@@ -172,7 +172,7 @@ __device__ __forceinline__ R block_sum(R v, R* lds) {  // deterministic workgrou
 }
 
 // computeActiveErrors + activeRobustChi2 (sparse_optimizer.cpp:63-116): err[e], per-workgroup partial chi2
-__global__ __launch_bounds__(256) void k_errors(EdgeSoA Ed, const R* __restrict__ poses, const R* __restrict__ pts, Cam cam,
+__device__ __forceinline__ void b_errors(EdgeSoA Ed, const R* __restrict__ poses, const R* __restrict__ pts, Cam cam,
                                                 R deltaMono, R deltaStereo, R* __restrict__ err, R* __restrict__ partial) {
   __shared__ R lds[4];
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -195,8 +195,11 @@ __global__ __launch_bounds__(256) void k_errors(EdgeSoA Ed, const R* __restrict_
   const R s = block_sum(chi, lds);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
+__global__ __launch_bounds__(256) void k_errors(EdgeSoA Ed, const R* __restrict__ poses, const R* __restrict__ pts, Cam cam,
+                                                R deltaMono, R deltaStereo, R* __restrict__ err, R* __restrict__ partial) { b_errors(Ed, poses, pts, cam, deltaMono, deltaStereo, err, partial); }
+
 // final ordered sum of the partials: out[slot] = sum(partial[0..n))
-__global__ __launch_bounds__(256) void k_sum_partials(const R* __restrict__ partial, int n, R* __restrict__ out, int slot,
+__device__ __forceinline__ void b_sum_partials(const R* __restrict__ partial, int n, R* __restrict__ out, int slot,
                                                       const int* __restrict__ status) {
   __shared__ R lds[4];
   R v = 0;
@@ -207,10 +210,13 @@ __global__ __launch_bounds__(256) void k_sum_partials(const R* __restrict__ part
     if (status) { out[6] = (R)status[0]; out[7] = (R)status[1]; }   // the factorisation status rides along in the same read-back
   }
 }
+__global__ __launch_bounds__(256) void k_sum_partials(const R* __restrict__ partial, int n, R* __restrict__ out, int slot,
+                                                      const int* __restrict__ status) { b_sum_partials(partial, n, out, slot, status); }
+
 
 // buildSystem, landmark side (constructQuadraticForm for `from` = point): one thread per active landmark.
 // Hll[l] = sum A^T W A (6 unique), bl[l] = sum A^T (-rho' Omega e), Hpl[e] = B^T W A (6x3) for free poses.
-__global__ __launch_bounds__(128) void k_build_points(EdgeSoA Ed, const int* __restrict__ ptStart, int nL, const R* __restrict__ poses,
+__device__ __forceinline__ void b_build_points(EdgeSoA Ed, const int* __restrict__ ptStart, int nL, const R* __restrict__ poses,
                                                       const R* __restrict__ pts, Cam cam, R deltaMono, R deltaStereo,
                                                       const R* __restrict__ err, R* __restrict__ Hll, R* __restrict__ bl,
                                                       R* __restrict__ Hpl) {
@@ -254,9 +260,14 @@ __global__ __launch_bounds__(128) void k_build_points(EdgeSoA Ed, const int* __r
   for (int k = 0; k < 6; k++) Hll[(size_t)6 * l + k] = h[k];
   bl[3 * l] = b[0]; bl[3 * l + 1] = b[1]; bl[3 * l + 2] = b[2];
 }
+__global__ __launch_bounds__(128) void k_build_points(EdgeSoA Ed, const int* __restrict__ ptStart, int nL, const R* __restrict__ poses,
+                                                      const R* __restrict__ pts, Cam cam, R deltaMono, R deltaStereo,
+                                                      const R* __restrict__ err, R* __restrict__ Hll, R* __restrict__ bl,
+                                                      R* __restrict__ Hpl) { b_build_points(Ed, ptStart, nL, poses, pts, cam, deltaMono, deltaStereo, err, Hll, bl, Hpl); }
+
 
 // buildSystem, pose side: one workgroup per free pose, threads over that pose's edges; Hpp[i] (6x6) and bp[6i..].
-__global__ __launch_bounds__(256) void k_build_poses(EdgeSoA Ed, const int* __restrict__ poseStart, const int* __restrict__ poseEdges,
+__device__ __forceinline__ void b_build_poses(EdgeSoA Ed, const int* __restrict__ poseStart, const int* __restrict__ poseEdges,
                                                      const R* __restrict__ poses, const R* __restrict__ pts, Cam cam, R deltaMono,
                                                      R deltaStereo, const R* __restrict__ err, R* __restrict__ Hpp,
                                                      R* __restrict__ bp) {
@@ -321,9 +332,14 @@ __global__ __launch_bounds__(256) void k_build_poses(EdgeSoA Ed, const int* __re
   }
   (void)lds;
 }
+__global__ __launch_bounds__(256) void k_build_poses(EdgeSoA Ed, const int* __restrict__ poseStart, const int* __restrict__ poseEdges,
+                                                     const R* __restrict__ poses, const R* __restrict__ pts, Cam cam, R deltaMono,
+                                                     R deltaStereo, const R* __restrict__ err, R* __restrict__ Hpp,
+                                                     R* __restrict__ bp) { b_build_poses(Ed, poseStart, poseEdges, poses, pts, cam, deltaMono, deltaStereo, err, Hpp, bp); }
+
 
 // max |diagonal| of the Hessian (computeLambdaInit, levenberg.cpp:150-164) -> out[slot]
-__global__ __launch_bounds__(256) void k_max_diag(const R* __restrict__ Hpp, int nP, const R* __restrict__ Hll, int nL, R* __restrict__ out,
+__device__ __forceinline__ void b_max_diag(const R* __restrict__ Hpp, int nP, const R* __restrict__ Hll, int nL, R* __restrict__ out,
                                                   int slot) {
   __shared__ R lds[4];
   R m = 0;
@@ -338,9 +354,12 @@ __global__ __launch_bounds__(256) void k_max_diag(const R* __restrict__ Hpp, int
   __syncthreads();
   if (threadIdx.x == 0) out[slot] = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
 }
+__global__ __launch_bounds__(256) void k_max_diag(const R* __restrict__ Hpp, int nP, const R* __restrict__ Hll, int nL, R* __restrict__ out,
+                                                  int slot) { b_max_diag(Hpp, nP, Hll, nL, out, slot); }
+
 
 // D^-1 = (Hll + lambda I)^-1 (Eigen cofactor inverse, block_solver.hpp:350) and db = D^-1 b_l, per landmark
-__global__ __launch_bounds__(256) void k_dinv(const R* __restrict__ Hll, const R* __restrict__ bl, int nL, R lambda, R* __restrict__ Dinv,
+__device__ __forceinline__ void b_dinv(const R* __restrict__ Hll, const R* __restrict__ bl, int nL, R lambda, R* __restrict__ Dinv,
                                               R* __restrict__ db, int* __restrict__ status) {
   const int l = blockIdx.x * 256 + threadIdx.x;
   if (l == 0) { status[0] = 0; status[1] = 0; }   // first kernel of a trial: clears the factorisation status
@@ -357,6 +376,9 @@ __global__ __launch_bounds__(256) void k_dinv(const R* __restrict__ Hll, const R
   db[3 * l + 1] = o[1] * b0 + o[3] * b1 + o[4] * b2;
   db[3 * l + 2] = o[2] * b0 + o[4] * b1 + o[5] * b2;
 }
+__global__ __launch_bounds__(256) void k_dinv(const R* __restrict__ Hll, const R* __restrict__ bl, int nL, R lambda, R* __restrict__ Dinv,
+                                              R* __restrict__ db, int* __restrict__ status) { b_dinv(Hll, bl, nL, lambda, Dinv, db, status); }
+
 
 // ---- Schur complement (block_solver.hpp:342-393) without atomics ---------------------------------------------------
 // S(i2,i1) = [i1==i2](Hpp_i1 + lambda I) - sum over landmarks seen by both poses of  B_i2 D^-1 B_i1^T   (lower triangle, i2 >= i1).
@@ -439,7 +461,7 @@ __global__ __launch_bounds__(256) void k_pair_sort(const int* __restrict__ start
   }
 }
 // BD_e = Hpl_e D^-1 (6x3) for every observation of a free pose
-__global__ __launch_bounds__(256) void k_bd(EdgeSoA Ed, const int* __restrict__ edgeLm, const R* __restrict__ Hpl, const R* __restrict__ Dinv,
+__device__ __forceinline__ void b_bd(EdgeSoA Ed, const int* __restrict__ edgeLm, const R* __restrict__ Hpl, const R* __restrict__ Dinv,
                                             R* __restrict__ BD) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= Ed.n || Ed.pidx[e] < 0) return;
@@ -453,8 +475,11 @@ __global__ __launch_bounds__(256) void k_bd(EdgeSoA Ed, const int* __restrict__ 
     o[r * 3 + 2] = B[r * 3] * di[2] + B[r * 3 + 1] * di[4] + B[r * 3 + 2] * di[5];
   }
 }
+__global__ __launch_bounds__(256) void k_bd(EdgeSoA Ed, const int* __restrict__ edgeLm, const R* __restrict__ Hpl, const R* __restrict__ Dinv,
+                                            R* __restrict__ BD) { b_bd(Ed, edgeLm, Hpl, Dinv, BD); }
+
 // bs_i = contrib * bp_i - sum over the observations e of pose i of Hpl_e (D^-1 b_l)   (one workgroup per free pose)
-__global__ __launch_bounds__(256) void k_bs(EdgeSoA Ed, const int* __restrict__ poseStart, const int* __restrict__ poseEdges,
+__device__ __forceinline__ void b_bs(EdgeSoA Ed, const int* __restrict__ poseStart, const int* __restrict__ poseEdges,
                                             const int* __restrict__ edgeLm, const R* __restrict__ Hpl, const R* __restrict__ db,
                                             const R* __restrict__ bp, R contrib, R* __restrict__ bs) {
   __shared__ R part[4][6];
@@ -476,13 +501,17 @@ __global__ __launch_bounds__(256) void k_bs(EdgeSoA Ed, const int* __restrict__ 
   __syncthreads();
   if (threadIdx.x < 6) bs[6 * i + threadIdx.x] = contrib * bp[6 * i + threadIdx.x] - (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
+__global__ __launch_bounds__(256) void k_bs(EdgeSoA Ed, const int* __restrict__ poseStart, const int* __restrict__ poseEdges,
+                                            const int* __restrict__ edgeLm, const R* __restrict__ Hpl, const R* __restrict__ db,
+                                            const R* __restrict__ bp, R contrib, R* __restrict__ bs) { b_bs(Ed, poseStart, poseEdges, edgeLm, Hpl, db, bp, contrib, bs); }
+
 // One workgroup per lower 6x6 block (i2 >= i1); the last workgroup also writes the identity padding of S and bs.
 // The block is the contraction  [Hpl_b rows q | 3m columns] x [BD_a rows r | 3m columns]^T  over the m landmarks the two poses
 // share: it runs on the FP64 matrix core, v_mfma_f64_16x16x4_f64 (A[i = lane&15][k = lane>>4], B[k][j = lane&15],
 // D col = lane&15, row = (lane>>4) + 4*reg; rows/cols >= 6 are fed zeros), four k-columns per instruction.
 typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int kSchurWaves = 4;   // waves per bucket
-__global__ __launch_bounds__(64 * kSchurWaves) void k_schur_pairs(const int* __restrict__ start, const int2* __restrict__ items, int nP, int nBuckets,
+__device__ __forceinline__ void b_schur_pairs(const int* __restrict__ start, const int2* __restrict__ items, int nP, int nBuckets,
                                                      const R* __restrict__ BD, const R* __restrict__ Hpl, const R* __restrict__ Hpp, R lambda,
                                                      R contrib, int n, R* __restrict__ S, R* __restrict__ bs) {
   // One workgroup per bucket, its items split over the workgroup's waves (the buckets of poses that see the same landmarks hold hundreds of
@@ -491,7 +520,7 @@ __global__ __launch_bounds__(64 * kSchurWaves) void k_schur_pairs(const int* __r
   __shared__ R part[kSchurWaves][36];
   const int bkt = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (bkt >= nBuckets) {
-    if (blockIdx.x == gridDim.x - 1) {  // padding rows/cols 6 nP .. n-1: identity (scaled like the rest for the all-reduce)
+    if (bkt == nBuckets) {  // the extra workgroup; padding rows/cols 6 nP .. n-1: identity (scaled like the rest for the all-reduce)
       for (int idx = threadIdx.x; idx < (n - 6 * nP) * n; idx += 64 * kSchurWaves) {
         const int r = 6 * nP + idx / n, c = idx % n;
         if (c <= r) S[(size_t)r * n + c] = r == c ? contrib : 0.0;
@@ -550,6 +579,10 @@ __global__ __launch_bounds__(64 * kSchurWaves) void k_schur_pairs(const int* __r
     S[(size_t)(6 * i2 + q) * n + 6 * i1 + r] = v;
   }
 }
+__global__ __launch_bounds__(64 * kSchurWaves) void k_schur_pairs(const int* __restrict__ start, const int2* __restrict__ items, int nP, int nBuckets,
+                                                     const R* __restrict__ BD, const R* __restrict__ Hpl, const R* __restrict__ Hpp, R lambda,
+                                                     R contrib, int n, R* __restrict__ S, R* __restrict__ bs) { b_schur_pairs(start, items, nP, nBuckets, BD, Hpl, Hpp, lambda, contrib, n, S, bs); }
+
 
 // ---- dense blocked right-looking Cholesky of S (n multiple of 32, lower triangle, row-major) ----------------------
 // Launch kb (0 .. nb-1) has one workgroup per tile (i >= j >= kb) of the trailing lower triangle:
@@ -701,7 +734,7 @@ __device__ long long g_cholClk[2][32][12];
 #else
 #define CH_CLK(p) do { } while (0)
 #endif
-__global__ __launch_bounds__(256) void k_chol_step(R* __restrict__ S, R* __restrict__ diagL, R* __restrict__ diagInv, int n, int kb,
+__device__ __forceinline__ void b_chol_step(R* __restrict__ S, R* __restrict__ diagL, R* __restrict__ diagInv, int n, int kb,
                                                    int* __restrict__ status, R* __restrict__ bvec, R* __restrict__ yv) {
   __shared__ R Ta[NB][NBP];   // this tile
   __shared__ R Dg[NB][NBP];   // diagonal tile of the panel (panel workgroups only)
@@ -883,13 +916,16 @@ __global__ __launch_bounds__(256) void k_chol_step(R* __restrict__ S, R* __restr
   for (int c = 0; c < 4; c++) S[(size_t)(i * NB + tr) * n + kb * NB + tc4 + c] = xo[c];
   CH_CLK(10);
 }
+__global__ __launch_bounds__(256) void k_chol_step(R* __restrict__ S, R* __restrict__ diagL, R* __restrict__ diagInv, int n, int kb,
+                                                   int* __restrict__ status, R* __restrict__ bvec, R* __restrict__ yv) { b_chol_step(S, diagL, diagInv, n, kb, status, bvec, yv); }
+
 
 // Backward substitution L^T x = y (y comes out of the factorisation launches), single workgroup, blocked by 32 with the
 // diagonal blocks applied through their inverses:  x_k = Linv_kk^T y_k ;  y_j -= L(k,j)^T x_k  (j < k).  It first finishes the
 // forward substitution (last block of y).  The chain over the 19 blocks is serial, so each step is kept short: the block inverse (exactly 1024 numbers, one per
 // thread) and the 32 L entries a thread needs for the update are fetched BEFORE the step's reduction (they do not depend on x),
 // and x_k is a 32-way shuffle reduction on all 1024 threads instead of a 32-term loop on 32 of them.
-__global__ __launch_bounds__(1024) void k_chol_solve(const R* __restrict__ L, const R* __restrict__ diagInv, int n, const R* __restrict__ yin,
+__device__ __forceinline__ void b_chol_solve(const R* __restrict__ L, const R* __restrict__ diagInv, int n, const R* __restrict__ yin,
                                                      const R* __restrict__ bvec, R* __restrict__ x) {
   extern __shared__ R y[];  // [n]
   __shared__ R inv[NB][NB + 1];
@@ -941,6 +977,9 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const R* __restrict__ L, co
   __syncthreads();
   for (int i = tid; i < n; i += 1024) x[i] = y[i];
 }
+__global__ __launch_bounds__(1024) void k_chol_solve(const R* __restrict__ L, const R* __restrict__ diagInv, int n, const R* __restrict__ yin,
+                                                     const R* __restrict__ bvec, R* __restrict__ x) { b_chol_solve(L, diagInv, n, yin, bvec, x); }
+
 
 // Launch of k_chol_solve: y[n] sits in dynamic LDS, so n is bounded by the CU's 160 KiB (minus the kernel's 8.7 KiB of static LDS)
 // and anything above the 64 KiB default needs the attribute.  Returns false when the system is too wide.
@@ -956,7 +995,7 @@ inline bool launch_chol_solve(hipStream_t s, const R* L, const R* diagInv, int n
 }
 
 // landmark step (block_solver.hpp:420-444): xl = D^-1 (b_l - sum_e Hpl_e^T xp[pose(e)])
-__global__ __launch_bounds__(128) void k_backsub(EdgeSoA Ed, const int* __restrict__ ptStart, int nL, const R* __restrict__ Hpl,
+__device__ __forceinline__ void b_backsub(EdgeSoA Ed, const int* __restrict__ ptStart, int nL, const R* __restrict__ Hpl,
                                                  const R* __restrict__ Dinv, const R* __restrict__ bl, const R* __restrict__ xp,
                                                  R* __restrict__ xl) {
   const int l = blockIdx.x * 128 + threadIdx.x;
@@ -977,6 +1016,10 @@ __global__ __launch_bounds__(128) void k_backsub(EdgeSoA Ed, const int* __restri
   xl[3 * l + 1] = di[1] * c0 + di[3] * c1 + di[4] * c2;
   xl[3 * l + 2] = di[2] * c0 + di[4] * c1 + di[5] * c2;
 }
+__global__ __launch_bounds__(128) void k_backsub(EdgeSoA Ed, const int* __restrict__ ptStart, int nL, const R* __restrict__ Hpl,
+                                                 const R* __restrict__ Dinv, const R* __restrict__ bl, const R* __restrict__ xp,
+                                                 R* __restrict__ xl) { b_backsub(Ed, ptStart, nL, Hpl, Dinv, bl, xp, xl); }
+
 
 // VertexSE3Expmap::oplusImpl: pose <- exp(u) * pose, u = [omega, upsilon] (se3quat.h:100-106, 218-257)
 __device__ __forceinline__ void pose_oplus(V3& t, Q4& q, const R* u) {
@@ -1012,7 +1055,7 @@ __device__ __forceinline__ void pose_oplus(V3& t, Q4& q, const R* u) {
 
 // SparseOptimizer::update (sparse_optimizer.cpp:433): poses <- exp(dxi) * pose (se3quat.h:100-106, 218-257),
 // points <- X + dX.  Reads `src`, writes `dst` (push/pop become a buffer swap on the host).
-__global__ __launch_bounds__(256) void k_update(const R* __restrict__ srcPoses, const R* __restrict__ srcPts, R* __restrict__ dstPoses,
+__device__ __forceinline__ void b_update(const R* __restrict__ srcPoses, const R* __restrict__ srcPts, R* __restrict__ dstPoses,
                                                 R* __restrict__ dstPts, const int* __restrict__ poseOf, int nP,
                                                 const int* __restrict__ ptOf, int nL, const R* __restrict__ xp, const R* __restrict__ xl) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1032,9 +1075,13 @@ __global__ __launch_bounds__(256) void k_update(const R* __restrict__ srcPoses, 
     dstPts[3 * p + 2] = srcPts[3 * p + 2] + xl[3 * i + 2];
   }
 }
+__global__ __launch_bounds__(256) void k_update(const R* __restrict__ srcPoses, const R* __restrict__ srcPts, R* __restrict__ dstPoses,
+                                                R* __restrict__ dstPts, const int* __restrict__ poseOf, int nP,
+                                                const int* __restrict__ ptOf, int nL, const R* __restrict__ xp, const R* __restrict__ xl) { b_update(srcPoses, srcPts, dstPoses, dstPts, poseOf, nP, ptOf, nL, xp, xl); }
+
 
 // computeScale (levenberg.cpp:166-173): sum_j x_j (lambda x_j + b_j) over pose and landmark unknowns -> per-workgroup partials
-__global__ __launch_bounds__(256) void k_scale(const R* __restrict__ xp, const R* __restrict__ bp, int np6, const R* __restrict__ xl,
+__device__ __forceinline__ void b_scale(const R* __restrict__ xp, const R* __restrict__ bp, int np6, const R* __restrict__ xl,
                                                const R* __restrict__ bl, int nl3, R lambda, R* __restrict__ partial) {
   __shared__ R lds[4];
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1044,16 +1091,32 @@ __global__ __launch_bounds__(256) void k_scale(const R* __restrict__ xp, const R
   const R s = block_sum(v, lds);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
+__global__ __launch_bounds__(256) void k_scale(const R* __restrict__ xp, const R* __restrict__ bp, int np6, const R* __restrict__ xl,
+                                               const R* __restrict__ bl, int nl3, R lambda, R* __restrict__ partial) { b_scale(xp, bp, np6, xl, bl, nl3, lambda, partial); }
 
-// depth of every edge under the current estimate (isDepthPositive, types_six_dof_expmap.h:215-219,276-280)
-__global__ __launch_bounds__(256) void k_depths(const int* __restrict__ ePose, const int* __restrict__ ePt, int E, const R* __restrict__ poses,
-                                                const R* __restrict__ pts, R* __restrict__ depth) {
+
+// The chi2 / depth test of optimizer.cpp:292-311 (after the first stage) and :318-334 (final outlier list) on the device, so that
+// neither the errors (24 B per edge) nor the depths travel to the host between the stages.  chi2 = information * |error|^2 with the
+// ORIGINAL information and the error of the edge's last evaluation (a culled edge keeps it: it left g2o's active set), depth of the
+// point under the current estimate (isDepthPositive, types_six_dof_expmap.h:215-219,276-280).
+// final == 0: a failing edge gets information 0 (= level 1: every kernel skips it) and every edge loses its robust kernel;
+// final == 1: outlier[e] = fails.
+__global__ __launch_bounds__(256) void k_cull(const int* __restrict__ ePose, const int* __restrict__ ePt, const R* __restrict__ meas, int E,
+                                              const R* __restrict__ info0, const R* __restrict__ err, const R* __restrict__ poses,
+                                              const R* __restrict__ pts, R chi2Mono, R chi2Stereo, int final, R* __restrict__ info,
+                                              uint8_t* __restrict__ robust, uint8_t* __restrict__ outlier) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= E) return;
   V3 t; Q4 q;
   load_pose(poses, ePose[e], t, q);
   const R* X = pts + 3 * ePt[e];
-  depth[e] = add(qrot(q, V3{X[0], X[1], X[2]}), t).z;
+  const R depth = add(qrot(q, V3{X[0], X[1], X[2]}), t).z;
+  const R* r = err + 3 * e;
+  const R chi2 = info0[e] * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  const R th = meas[3 * e + 2] >= 0 ? chi2Stereo : chi2Mono;
+  const bool bad = chi2 > th || !(depth > 0.0);
+  if (final) outlier[e] = bad ? 1 : 0;
+  else { if (bad) info[e] = 0; robust[e] = 0; }
 }
 
 
@@ -1301,6 +1364,109 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(int nFrames, con
     trialsOut[f] = trials;
   }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Lock-step batch of independent problems (ydorb_ba_solve_batch): the same kernel bodies, one launch per phase for ALL problems
+// of the batch, blockIdx.z = problem.  A latency chain of ~35 small launches per LM trial leaves the GPU nearly idle; B chains in
+// one set of launches cost about the same wall time as one.  Every problem keeps its own buffers (BaDev = its pointers, sizes and
+// the scalars of the trial at hand); grids are sized for the largest problem and workgroups beyond a problem's extent - or of a
+// problem that sits this phase out (finished, or waiting while others retry a rejected step) - leave at once.  The arithmetic and
+// its order are those of the single-problem launches, so a batched solve is bit-identical to its own single solve.
+// ---------------------------------------------------------------------------------------------------
+struct BaDev {
+  EdgeSoA Ed;
+  const int *ptStart, *poseStart, *poseEdges, *eLm, *poseOf, *ptOf, *pairStart;
+  const int2* pairItems;
+  R *poses[2], *pts[2];
+  R *err, *partial, *Hll, *bl, *Hpl, *BD, *Hpp, *S, *diagL, *diagInv, *Dinv, *db, *xp, *yv, *xl, *scal;
+  int* status;
+  Cam cam;
+  R dM, dSt;
+  int nL, nPf, Ea, n, nb, nBlkE, nBuckets;
+  // the round at hand (rewritten by the host before every round)
+  R lambda;
+  int cur;        // which of poses[2] / pts[2] holds the current estimate
+  int build;      // takes part in the chi2 / build-system launches of this round
+  int chi2;       // ... and needs the errors of the current estimate recomputed first (first iteration, or after a rejected NaN step)
+  int maxdiag;    // ... and its initial lambda (first iteration of an optimize() call)
+  int trial;      // takes part in the trial launches of this round
+};
+#define YD_BA_PROB(flag)                         \
+  const BaDev& D = all[blockIdx.z];              \
+  if (!D.flag) return
+__global__ __launch_bounds__(256) void kb_errors(const BaDev* __restrict__ all, int onTrial) {
+  const BaDev& D = all[blockIdx.z];
+  if (!(onTrial ? D.trial : (D.build && D.chi2)) || blockIdx.x >= (unsigned)D.nBlkE) return;
+  const int buf = onTrial ? (D.cur ^ 1) : D.cur;
+  b_errors(D.Ed, D.poses[buf], D.pts[buf], D.cam, D.dM, D.dSt, D.err, D.partial);
+}
+// use 0: chi2 of the current estimate (no status), 1: chi2 of the trial estimate (+ factorisation status), 2: the scale sum
+__global__ __launch_bounds__(256) void kb_sum_partials(const BaDev* __restrict__ all, int use) {
+  const BaDev& D = all[blockIdx.z];
+  if (!(use == 0 ? (D.build && D.chi2) : D.trial)) return;
+  if (use == 2) b_sum_partials(D.partial + D.nBlkE, (6 * D.nPf + 3 * D.nL + 255) / 256, D.scal, 2, nullptr);
+  else b_sum_partials(D.partial, D.nBlkE, D.scal, 0, use == 1 ? D.status : nullptr);
+}
+__global__ __launch_bounds__(128) void kb_build_points(const BaDev* __restrict__ all) {
+  YD_BA_PROB(build);
+  if (blockIdx.x >= (unsigned)((D.nL + 127) / 128)) return;
+  b_build_points(D.Ed, D.ptStart, D.nL, D.poses[D.cur], D.pts[D.cur], D.cam, D.dM, D.dSt, D.err, D.Hll, D.bl, D.Hpl);
+}
+__global__ __launch_bounds__(256) void kb_build_poses(const BaDev* __restrict__ all) {
+  YD_BA_PROB(build);
+  if (blockIdx.x >= (unsigned)D.nPf) return;
+  b_build_poses(D.Ed, D.poseStart, D.poseEdges, D.poses[D.cur], D.pts[D.cur], D.cam, D.dM, D.dSt, D.err, D.Hpp, D.Hpp + (size_t)36 * D.nPf);
+}
+__global__ __launch_bounds__(256) void kb_max_diag(const BaDev* __restrict__ all) {
+  const BaDev& D = all[blockIdx.z];
+  if (!(D.build && D.maxdiag)) return;
+  b_max_diag(D.Hpp, D.nPf, D.Hll, D.nL, D.scal, 1);
+}
+__global__ __launch_bounds__(256) void kb_dinv(const BaDev* __restrict__ all) {
+  YD_BA_PROB(trial);
+  if (blockIdx.x >= (unsigned)((D.nL + 255) / 256)) return;
+  b_dinv(D.Hll, D.bl, D.nL, D.lambda, D.Dinv, D.db, D.status);
+}
+__global__ __launch_bounds__(256) void kb_bd(const BaDev* __restrict__ all) {
+  YD_BA_PROB(trial);
+  if (blockIdx.x >= (unsigned)D.nBlkE) return;
+  b_bd(D.Ed, D.eLm, D.Hpl, D.Dinv, D.BD);
+}
+__global__ __launch_bounds__(256) void kb_bs(const BaDev* __restrict__ all) {
+  YD_BA_PROB(trial);
+  if (blockIdx.x >= (unsigned)D.nPf) return;
+  b_bs(D.Ed, D.poseStart, D.poseEdges, D.eLm, D.Hpl, D.db, D.Hpp + (size_t)36 * D.nPf, 1.0, D.S + (size_t)D.n * D.n);
+}
+__global__ __launch_bounds__(64 * kSchurWaves) void kb_schur_pairs(const BaDev* __restrict__ all) {
+  YD_BA_PROB(trial);
+  if (blockIdx.x >= (unsigned)(D.nBuckets + 1)) return;
+  b_schur_pairs(D.pairStart, D.pairItems, D.nPf, D.nBuckets, D.BD, D.Hpl, D.Hpp, D.lambda, 1.0, D.n, D.S, D.S + (size_t)D.n * D.n);
+}
+__global__ __launch_bounds__(256) void kb_chol_step(const BaDev* __restrict__ all, int kb) {
+  YD_BA_PROB(trial);
+  if (kb >= D.nb || blockIdx.x >= (unsigned)((D.nb - kb) * (D.nb - kb + 1) / 2 + (kb > 0))) return;
+  b_chol_step(D.S, D.diagL, D.diagInv, D.n, kb, D.status, D.S + (size_t)D.n * D.n, D.yv);
+}
+__global__ __launch_bounds__(1024) void kb_chol_solve(const BaDev* __restrict__ all) {
+  YD_BA_PROB(trial);
+  b_chol_solve(D.S, D.diagInv, D.n, D.yv, D.S + (size_t)D.n * D.n, D.xp);
+}
+__global__ __launch_bounds__(128) void kb_backsub(const BaDev* __restrict__ all) {
+  YD_BA_PROB(trial);
+  if (blockIdx.x >= (unsigned)((D.nL + 127) / 128)) return;
+  b_backsub(D.Ed, D.ptStart, D.nL, D.Hpl, D.Dinv, D.bl, D.xp, D.xl);
+}
+__global__ __launch_bounds__(256) void kb_update(const BaDev* __restrict__ all) {
+  YD_BA_PROB(trial);
+  if (blockIdx.x >= (unsigned)((max(D.nPf, D.nL) + 255) / 256)) return;
+  b_update(D.poses[D.cur], D.pts[D.cur], D.poses[D.cur ^ 1], D.pts[D.cur ^ 1], D.poseOf, D.nPf, D.ptOf, D.nL, D.xp, D.xl);
+}
+__global__ __launch_bounds__(256) void kb_scale(const BaDev* __restrict__ all) {
+  YD_BA_PROB(trial);
+  if (blockIdx.x >= (unsigned)((6 * D.nPf + 3 * D.nL + 255) / 256)) return;
+  b_scale(D.xp, D.Hpp + (size_t)36 * D.nPf, 6 * D.nPf, D.xl, D.bl, 3 * D.nL, D.lambda, D.partial + D.nBlkE);
+}
+#undef YD_BA_PROB
 
 }  // namespace ba
 }  // namespace ydorb

@@ -8,6 +8,7 @@
 #include <chrono>
 
 #include <algorithm>
+#include <functional>
 #include <string>
 #include <thread>
 #include <atomic>
@@ -56,8 +57,8 @@ enum { PH_ERR = 0, PH_BUILD, PH_SCHUR, PH_SOLVE, PH_UPDATE, PH_COUNT };
 struct Ctx {  // per-device scratch, reused across calls (localBundleAdjust runs on one thread, localMapping.cpp:29)
   int device = -1;
   hipStream_t stream = nullptr;
-  DBuf poses[2], pts[2], ePoseAll, ePtAll, depth;
-  DBuf ePose, ePidx, ePt, eMeas, eInfo, eRobust, eLm, ptStart, poseStart, poseEdges, poseOf, ptOf;
+  DBuf poses[2], pts[2];
+  DBuf ePose, ePidx, ePt, eMeas, eInfo, eInfo0, eRobust, eOutlier, eLm, ptStart, poseStart, poseEdges, poseOf, ptOf;
   DBuf err, partial, Hll, bl, Hpl, BD, Hpp, bp, S, diagL, diagInv, bs, Dinv, db, xp, xl, yv, scal, status, pairCnt, pairStart, pairCursor, pairA, pairB;
   hipEvent_t ev[2 * PH_COUNT + 2]{};
   bool evInit = false;
@@ -78,8 +79,7 @@ struct Run {
   const YdBaOptions* O;
   YdBaResult* res;
   int cur = 0;  // which of poses[2]/pts[2] holds the current estimate
-  std::vector<uint8_t> level, robust;
-  std::vector<double> err;  // per original edge, as last computed
+  bool noRobust = false;   // YDORB_BA_NO_ROBUST
   Cam cam;
   double phaseMs[PH_COUNT] = {0, 0, 0, 0, 0};
   bool pending[PH_COUNT] = {false, false, false, false, false};
@@ -122,8 +122,10 @@ struct PhaseTimer {
   }
 };
 
-// one SparseOptimizer::optimize(iterations) on the level-0 edges
-int optimize(Run& R_, int iterations, int stage, bool reuse) {
+// initializeOptimization(0) for one optimize() call: host ordering of the level-0 edges, uploads, pose-pair buckets (stage 1), or the
+// refreshed information / robust flags on stage 1's structures (stage 2); leaves S cleared and both estimate buffers in agreement.
+// R_.sys.Ea == 0 afterwards means there is nothing to optimise.
+int prepareStage(Run& R_, bool reuse) {
   Ctx& c = *R_.c;
   const YdBaProblem& P = *R_.P;
   const YdBaOptions& O = *R_.O;
@@ -136,7 +138,7 @@ int optimize(Run& R_, int iterations, int stage, bool reuse) {
   // edges stay in the system with H = lambda*I, b = 0, i.e. dx = 0: the same estimate g2o keeps by leaving them out.
   auto prepare = [&]() -> int {
     std::vector<int> act;
-    for (int e = 0; e < E; e++) if (!R_.level[e]) act.push_back(e);
+    for (int e = 0; e < E; e++) act.push_back(e);   // every edge starts at level 0 (optimizer.cpp:239-280)
     if (act.empty()) { Y.Ea = 0; return YDORB_OK; }
     // index mapping (buildIndexMapping, sparse_optimizer.cpp:168-192): free poses first, then landmarks, active ones only
     std::vector<int> poseIdx(K, -1), ptIdx(NP, -1), poseOf, ptOf;
@@ -177,7 +179,7 @@ int optimize(Run& R_, int iterations, int stage, bool reuse) {
       hPose[i] = P.edge_pose[e]; hPidx[i] = poseIdx[P.edge_pose[e]]; hPt[i] = P.edge_point[e]; hLm[i] = ptIdx[P.edge_point[e]];
       for (int d = 0; d < 3; d++) hMeas[3 * i + d] = P.edge_meas[3 * e + d];
       hInfo[i] = P.edge_inv_sigma2[e];
-      hRobust[i] = R_.robust[e];
+      hRobust[i] = R_.noRobust ? 0 : 1;
       hPtStart[hLm[i] + 1]++;
       if (hPidx[i] >= 0) hPoseStart[hPidx[i] + 1]++;
     }
@@ -193,7 +195,7 @@ int optimize(Run& R_, int iterations, int stage, bool reuse) {
     int rc;
     if ((rc = c.ePose.ensure(sizeof(int) * Ea)) || (rc = c.ePidx.ensure(sizeof(int) * Ea)) || (rc = c.ePt.ensure(sizeof(int) * Ea)) ||
         (rc = c.eLm.ensure(sizeof(int) * Ea)) || (rc = c.eMeas.ensure(sizeof(double) * 3 * Ea)) || (rc = c.eInfo.ensure(sizeof(double) * Ea)) ||
-        (rc = c.eRobust.ensure(Ea)) || (rc = c.ptStart.ensure(sizeof(int) * (nL + 1))) || (rc = c.poseStart.ensure(sizeof(int) * (nPf + 1))) ||
+        (rc = c.eRobust.ensure(Ea)) || (rc = c.eInfo0.ensure(sizeof(double) * Ea)) || (rc = c.eOutlier.ensure(Ea)) || (rc = c.ptStart.ensure(sizeof(int) * (nL + 1))) || (rc = c.poseStart.ensure(sizeof(int) * (nPf + 1))) ||
         (rc = c.poseEdges.ensure(sizeof(int) * std::max<size_t>(hPoseEdges.size(), 1))) || (rc = c.poseOf.ensure(sizeof(int) * std::max(nPf, 1))) ||
         (rc = c.ptOf.ensure(sizeof(int) * nL)) || (rc = c.err.ensure(sizeof(double) * 3 * Ea)) || (rc = c.partial.ensure(sizeof(double) * (nBlkE + (6 * nPf + 3 * nL + 255) / 256 + 1))) ||
         (rc = c.Hll.ensure(sizeof(double) * 6 * nL)) || (rc = c.bl.ensure(sizeof(double) * 3 * nL)) || (rc = c.Hpl.ensure(sizeof(double) * 18 * (size_t)Ea)) ||
@@ -207,6 +209,8 @@ int optimize(Run& R_, int iterations, int stage, bool reuse) {
     trace("optimize: host ordering done");
   #define UP(buf, vec, T) HIPCHK(hipMemcpyAsync(c.buf.p, vec.data(), sizeof(T) * vec.size(), hipMemcpyHostToDevice, s))
     UP(ePose, hPose, int); UP(ePidx, hPidx, int); UP(ePt, hPt, int); UP(eLm, hLm, int); UP(eMeas, hMeas, double); UP(eInfo, hInfo, double);
+    UP(eInfo0, hInfo, double);   // the original information: the chi2 tests between and after the stages use it (k_cull)
+    HIPCHK(hipMemsetAsync(c.err.p, 0, sizeof(double) * 3 * Ea, s));   // an edge that is never evaluated (stop flag) has error 0
     UP(eRobust, hRobust, uint8_t); UP(ptStart, hPtStart, int); UP(poseStart, hPoseStart, int); UP(ptOf, ptOf, int);
     if (!hPoseEdges.empty()) UP(poseEdges, hPoseEdges, int);
     if (nPf) UP(poseOf, poseOf, int);
@@ -240,16 +244,28 @@ int optimize(Run& R_, int iterations, int stage, bool reuse) {
   int rc;
   if (!reuse || Y.Ea == 0) {
     if ((rc = prepare())) return rc;
-  } else {
-    std::vector<double> hInfo(Y.Ea);
-    std::vector<uint8_t> hRobust(Y.Ea);
-    for (int i = 0; i < Y.Ea; i++) { const int e = Y.act[i]; hInfo[i] = R_.level[e] ? 0.0 : P.edge_inv_sigma2[e]; hRobust[i] = R_.robust[e]; }
-    HIPCHK(hipMemcpyAsync(c.eInfo.p, hInfo.data(), sizeof(double) * Y.Ea, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(c.eRobust.p, hRobust.data(), Y.Ea, hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));   // the staging vectors die here
   }
+  // (stage 2 re-uses stage 1's device structures as they are: k_cull already zeroed the information of the culled edges and
+  // cleared the robust flags on the device)
   if (Y.Ea == 0) return YDORB_OK;
-  const std::vector<int>& act = Y.act;
+  // the two estimate buffers must agree on everything the update kernel does not write (fixed poses, points without edges)
+  HIPCHK(hipMemcpyAsync(c.poses[R_.cur ^ 1].p, c.poses[R_.cur].p, sizeof(double) * 7 * K, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(c.pts[R_.cur ^ 1].p, c.pts[R_.cur].p, sizeof(double) * 3 * NP, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemsetAsync(c.S.p, 0, sizeof(double) * ((size_t)Y.n * Y.n + Y.n), s));
+  return YDORB_OK;
+}
+
+// one SparseOptimizer::optimize(iterations) on the level-0 edges
+int optimize(Run& R_, int iterations, int stage, bool reuse) {
+  int rc = prepareStage(R_, reuse);
+  if (rc) return rc;
+  Ctx& c = *R_.c;
+  const YdBaProblem& P = *R_.P;
+  const YdBaOptions& O = *R_.O;
+  hipStream_t s = c.stream;
+  Run::Sys& Y = R_.sys;
+  if (Y.Ea == 0) return YDORB_OK;
+  (void)P;
   const int nL = Y.nL, nPf = Y.nPf, Ea = Y.Ea, n = Y.n, nb = Y.nb, nBlkE = Y.nBlkE, nBuckets = Y.nBuckets;
   // Hpp and bp are contiguous ([36 nPf | 6 nPf]) so one all-reduce covers both; bs follows S for the same reason
   double* dHpp = c.Hpp.as<double>();
@@ -258,10 +274,6 @@ int optimize(Run& R_, int iterations, int stage, bool reuse) {
   double* dbs = dS + (size_t)n * n;
   EdgeSoA Ed{c.ePose.as<int>(), c.ePidx.as<int>(), c.ePt.as<int>(), c.eMeas.as<double>(), c.eInfo.as<double>(), c.eRobust.as<uint8_t>(), Ea};
   const double dM = O.delta_mono, dSt = O.delta_stereo;
-  // the two estimate buffers must agree on everything the update kernel does not write (fixed poses, points without edges)
-  HIPCHK(hipMemcpyAsync(c.poses[R_.cur ^ 1].p, c.poses[R_.cur].p, sizeof(double) * 7 * K, hipMemcpyDeviceToDevice, s));
-  HIPCHK(hipMemcpyAsync(c.pts[R_.cur ^ 1].p, c.pts[R_.cur].p, sizeof(double) * 3 * NP, hipMemcpyDeviceToDevice, s));
-  HIPCHK(hipMemsetAsync(dS, 0, sizeof(double) * ((size_t)n * n + n), s));
   double* hscal = c.hPin;
   int* hstatus = reinterpret_cast<int*>(c.hPin + 8);
   const bool multi = O.world > 1 && O.allreduce;
@@ -390,28 +402,327 @@ int optimize(Run& R_, int iterations, int stage, bool reuse) {
     if (qmax == O.max_trials || rho == 0 || !std::isfinite(lambda)) break;  // SolverResult::Terminate
   }
   trace("optimize: LM loop done");
-  // errors as g2o leaves them in the edges: those of the last evaluated state (possibly a rejected trial)
-  std::vector<double> herr((size_t)3 * Ea);
-  HIPCHK(hipMemcpyAsync(herr.data(), c.err.p, sizeof(double) * 3 * Ea, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
-  for (int i = 0; i < Ea; i++)
-    if (!R_.level[act[i]])   // a culled edge keeps the error of its last evaluation (it is not in g2o's active set any more)
-      for (int d = 0; d < 3; d++) R_.err[(size_t)3 * act[i] + d] = herr[(size_t)3 * i + d];
   for (int ph = 0; ph < PH_COUNT; ph++) PhaseTimer::collect(R_, ph);
   trace("optimize: errors read back");
   return YDORB_OK;
 }
 
-int edgeDepths(Run& R_, std::vector<double>& depth) {
-  Ctx& c = *R_.c;
-  const int E = R_.P->n_edges;
-  depth.resize(E);
-  if (!E) return YDORB_OK;
-  hipLaunchKernelGGL(k_depths, dim3((E + 255) / 256), dim3(256), 0, c.stream, c.ePoseAll.as<int>(), c.ePtAll.as<int>(), E, c.poses[R_.cur].as<double>(),
-                     c.pts[R_.cur].as<double>(), c.depth.as<double>());
-  HIPCHK(hipMemcpyAsync(depth.data(), c.depth.p, sizeof(double) * E, hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipStreamSynchronize(c.stream));
+
+
+// validation shared by the single and the batched entry points; fills *Oout with the effective options
+int checkProblem(const YdBaProblem* P, const YdBaOptions* optIn, YdBaResult* res, YdBaOptions* Oout) {
+  if (!P || !res) { set_error("null argument"); return YDORB_ERR_INVALID_ARG; }
+  YdBaOptions O;
+  if (optIn) O = *optIn; else ydorb_ba_default_options(&O);
+  uint8_t* outlier = res->edge_outlier;
+  memset(res, 0, sizeof(*res));
+  res->edge_outlier = outlier;
+  const int K = P->n_poses, NP = P->n_points, E = P->n_edges;
+  if (K < 0 || NP < 0 || E < 0 || (K && (!P->poses || !P->pose_fixed)) || (NP && !P->points) ||
+      (E && (!P->edge_pose || !P->edge_point || !P->edge_meas || !P->edge_inv_sigma2)) || O.device < 0 || O.device >= 16 || O.max_trials < 1) {
+    set_error("invalid BA problem");
+    return YDORB_ERR_INVALID_ARG;
+  }
+  for (int e = 0; e < E; e++)
+    if (P->edge_pose[e] < 0 || P->edge_pose[e] >= K || P->edge_point[e] < 0 || P->edge_point[e] >= NP) {
+      set_error("edge %d references a vertex out of range", e);
+      return YDORB_ERR_INVALID_ARG;
+    }
+  if (outlier) memset(outlier, 0, E);
+  *Oout = O;
   return YDORB_OK;
+}
+
+// state upload at the start of a solve (the vertices g2o is handed at optimizer.cpp:185-230)
+int beginSolve(Run& R_) {
+  Ctx& c = *R_.c;
+  const YdBaProblem* P = R_.P;
+  const YdBaOptions& O = *R_.O;
+  const int K = P->n_poses, NP = P->n_points;
+  int rc;
+  R_.noRobust = (O.flags & YDORB_BA_NO_ROBUST) != 0;
+  R_.cam = Cam{P->fx, P->fy, P->cx, P->cy, P->bf};
+  for (int i = 0; i < 2; i++)
+    if ((rc = c.poses[i].ensure(sizeof(double) * 7 * K)) || (rc = c.pts[i].ensure(sizeof(double) * 3 * NP))) return rc;
+  {  // SE3Quat's 7-vector constructor normalises the rotation (se3quat.h:80-86)
+    std::vector<double> hp(P->poses, P->poses + (size_t)7 * K);
+    for (int k = 0; k < K; k++) {
+      double* q = &hp[7 * k + 3];
+      if (q[3] < 0) for (int d = 0; d < 4; d++) q[d] = -q[d];
+      const double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+      for (int d = 0; d < 4; d++) q[d] /= nrm;
+    }
+    HIPCHK(hipMemcpyAsync(c.poses[0].p, hp.data(), sizeof(double) * 7 * K, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));   // hp dies here
+  }
+  HIPCHK(hipMemcpyAsync(c.pts[0].p, P->points, sizeof(double) * 3 * NP, hipMemcpyHostToDevice, c.stream));
+  return YDORB_OK;
+}
+
+int launchCull(Run& R_, int final) {
+  Ctx& c = *R_.c;
+  const YdBaOptions& O = *R_.O;
+  const int Ea = R_.sys.Ea;
+  if (Ea == 0) return YDORB_OK;
+  hipLaunchKernelGGL(k_cull, dim3((Ea + 255) / 256), dim3(256), 0, c.stream, c.ePose.as<int>(), c.ePt.as<int>(), c.eMeas.as<double>(), Ea, c.eInfo0.as<double>(),
+                     c.err.as<double>(), c.poses[R_.cur].as<double>(), c.pts[R_.cur].as<double>(), O.chi2_mono, O.chi2_stereo, final, c.eInfo.as<double>(),
+                     c.eRobust.as<uint8_t>(), c.eOutlier.as<uint8_t>());
+  HIPCHK(hipGetLastError());
+  return YDORB_OK;
+}
+
+// optimizer.cpp:290-311: edges whose chi2 exceeds the threshold or whose depth is not positive leave the second stage; no kernels any more
+int cullAfterFirstStage(Run& R_) { return launchCull(R_, 0); }
+
+// optimizer.cpp:315-351 up to the write-back: the final outlier list and the estimates
+int endSolve(Run& R_) {
+  Ctx& c = *R_.c;
+  const YdBaProblem* P = R_.P;
+  const Run::Sys& Y = R_.sys;
+  int rc = launchCull(R_, 1);
+  if (rc) return rc;
+  uint8_t* outlier = R_.res->edge_outlier;
+  std::vector<uint8_t> ho(Y.Ea);
+  if (outlier && Y.Ea) HIPCHK(hipMemcpyAsync(ho.data(), c.eOutlier.p, Y.Ea, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipMemcpyAsync(P->poses, c.poses[R_.cur].p, sizeof(double) * 7 * P->n_poses, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipMemcpyAsync(P->points, c.pts[R_.cur].p, sizeof(double) * 3 * P->n_points, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipStreamSynchronize(c.stream));
+  if (outlier) for (int i = 0; i < Y.Ea; i++) outlier[Y.act[i]] = ho[i];   // device edges are in (landmark, pose) order
+  if (R_.stopped()) R_.res->stopped = 1;
+  return YDORB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// ydorb_ba_solve_batch: independent problems advance in LOCK STEP through one set of launches per phase (blockIdx.z = problem,
+// ba_kernels.hip.h "Lock-step batch").  The host keeps one LM state per problem - exactly the scalars and decisions of optimize()
+// above - and every round (a) builds the system of the problems that start an iteration, (b) runs one LM trial of every unfinished
+// problem, (c) reads all problems' three scalars back with ONE copy and decides accept / retry / terminate per problem.  A problem
+// that is done with a stage goes through the same cull / second stage / read-back steps as a single solve while the others go on.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct Job {
+  Ctx ctx;                 // its own buffers; ctx.stream is the batch's stream (not owned)
+  YdBaOptions O;
+  Run* run = nullptr;
+  int stage = 1, it = 0, iterations = 0, qmax = 0;
+  double lambda = 0, ni = 2, currentChi = 0, rho = 0;
+  bool lastAccepted = true, needBuild = false, done = false;
+  int rc = YDORB_OK;
+  ~Job() { delete run; }
+};
+struct BatchPool {   // per device: contexts, stream and staging of the lock-step batches (one batch at a time per device)
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  std::vector<Job*> jobs;          // grown on demand; buffers are kept between calls
+  DBuf dDev, dScal;                // BaDev[B]; per problem 8 doubles (chi2, max diag, scale sum, ..., status copies) + 2 ints of status
+  BaDev* hDev = nullptr;           // pinned
+  double* hScal = nullptr;         // pinned
+  int cap = 0;
+};
+BatchPool g_batch[16];
+constexpr int kBatchGroup = 64;    // problems per lock-step group (C5-sized problems take ~40 MB each)
+
+void fillDev(Job& J, BaDev& D, double* dScal, int* dStatus) {
+  Ctx& c = J.ctx;
+  const Run::Sys& Y = J.run->sys;
+  memset(&D, 0, sizeof(D));
+  D.Ed = EdgeSoA{c.ePose.as<int>(), c.ePidx.as<int>(), c.ePt.as<int>(), c.eMeas.as<double>(), c.eInfo.as<double>(), c.eRobust.as<uint8_t>(), Y.Ea};
+  D.ptStart = c.ptStart.as<int>(); D.poseStart = c.poseStart.as<int>(); D.poseEdges = c.poseEdges.as<int>(); D.eLm = c.eLm.as<int>();
+  D.poseOf = c.poseOf.as<int>(); D.ptOf = c.ptOf.as<int>(); D.pairStart = c.pairStart.as<int>(); D.pairItems = c.pairB.as<int2>();
+  for (int i = 0; i < 2; i++) { D.poses[i] = c.poses[i].as<double>(); D.pts[i] = c.pts[i].as<double>(); }
+  D.err = c.err.as<double>(); D.partial = c.partial.as<double>(); D.Hll = c.Hll.as<double>(); D.bl = c.bl.as<double>(); D.Hpl = c.Hpl.as<double>();
+  D.BD = c.BD.as<double>(); D.Hpp = c.Hpp.as<double>(); D.S = c.S.as<double>(); D.diagL = c.diagL.as<double>(); D.diagInv = c.diagInv.as<double>();
+  D.Dinv = c.Dinv.as<double>(); D.db = c.db.as<double>(); D.xp = c.xp.as<double>(); D.yv = c.yv.as<double>(); D.xl = c.xl.as<double>();
+  D.scal = dScal; D.status = dStatus;
+  D.cam = J.run->cam; D.dM = J.O.delta_mono; D.dSt = J.O.delta_stereo;
+  D.nL = Y.nL; D.nPf = Y.nPf; D.Ea = Y.Ea; D.n = Y.n; D.nb = Y.nb; D.nBlkE = Y.nBlkE; D.nBuckets = Y.nBuckets;
+}
+
+int solveGroup(BatchPool& B, const YdBaProblem* probs, const YdBaOptions& Oin, YdBaResult* res, int n, int* rcEach) {
+  hipStream_t s = B.stream;
+  int rc;
+  if ((rc = B.dDev.ensure(sizeof(BaDev) * n)) || (rc = B.dScal.ensure((sizeof(double) * 8 + sizeof(int) * 2) * n))) return rc;
+  double* dScalAll = B.dScal.as<double>();
+  int* dStatusAll = reinterpret_cast<int*>(dScalAll + (size_t)8 * n);
+  std::vector<Job*> J(B.jobs.begin(), B.jobs.begin() + n);
+  auto fail = [&](int j, int code) { J[j]->rc = code; J[j]->done = true; if (rcEach) rcEach[j] = code; };
+
+  // stage transitions (per problem, on the shared stream) -----------------------------------------------------------------
+  std::function<void(int)> finalize, endStage;
+  auto startStage = [&](int j, int stage) {
+    Job& X = *J[j];
+    X.stage = stage; X.it = 0; X.qmax = 0; X.rho = 0; X.lastAccepted = true;
+    X.iterations = stage == 1 ? X.O.iters1 : X.O.iters2;
+    int r = prepareStage(*X.run, stage == 2);
+    if (r) { fail(j, r); return; }
+    if (X.run->sys.Ea == 0) { endStage(j); return; }
+    if (X.run->sys.n > kCholSolveMaxN) { set_error("reduced camera system of %d rows is wider than the solve kernel's LDS (max %d)", X.run->sys.n, kCholSolveMaxN); fail(j, YDORB_ERR_UNSUPPORTED); return; }
+    fillDev(X, B.hDev[j], dScalAll + (size_t)8 * j, dStatusAll + (size_t)2 * j);
+    if (!(X.it < X.iterations && !X.run->stopped())) { endStage(j); return; }   // `for (it = 0; it < iterations && !terminate(); ...)`
+    X.needBuild = true;
+  };
+  finalize = [&](int j) {
+    Job& X = *J[j];
+    int r = endSolve(*X.run);
+    if (r) { fail(j, r); return; }
+    X.done = true;
+  };
+  endStage = [&](int j) {
+    Job& X = *J[j];
+    X.needBuild = false;
+    int r;
+    if (X.stage == 1 && !(X.O.flags & YDORB_BA_SINGLE_STAGE)) {
+      if (!X.run->stopped()) {   // optimizer.cpp:290-314
+        if ((r = cullAfterFirstStage(*X.run))) { fail(j, r); return; }
+        startStage(j, 2);
+        return;
+      }
+      X.run->res->stopped = 1;
+    }
+    finalize(j);
+  };
+  // end of an outer iteration: the log entry and SolverResult::Terminate, as in optimize()
+  auto endIteration = [&](int j) {
+    Job& X = *J[j];
+    YdBaResult* r = X.run->res;
+    if (r->n_log < 32) {
+      r->log_chi2[r->n_log] = X.currentChi; r->log_lambda[r->n_log] = X.lambda; r->log_trials[r->n_log] = X.qmax; r->log_stage[r->n_log] = X.stage;
+      r->n_log++;
+    }
+    r->n_iterations++;
+    const bool terminate = X.qmax == X.O.max_trials || X.rho == 0 || !std::isfinite(X.lambda);
+    X.it++;
+    if (terminate || !(X.it < X.iterations && !X.run->stopped())) { endStage(j); return; }
+    X.needBuild = true; X.qmax = 0; X.rho = 0;
+  };
+
+  for (int j = 0; j < n; j++) {
+    Job& X = *J[j];
+    X.done = false; X.rc = YDORB_OK;
+    delete X.run; X.run = nullptr;
+    if (rcEach) rcEach[j] = YDORB_OK;
+    if ((rc = checkProblem(&probs[j], &Oin, &res[j], &X.O))) { fail(j, rc); continue; }
+    const YdBaProblem* P = &probs[j];
+    if (P->stop && *P->stop) { res[j].stopped = 1; X.done = true; continue; }
+    if (P->n_edges == 0 || P->n_poses == 0 || P->n_points == 0) { X.done = true; continue; }
+    X.ctx.device = Oin.device; X.ctx.stream = s;
+    X.run = new Run{&X.ctx, P, &X.O, &res[j]};
+    if ((rc = beginSolve(*X.run))) { fail(j, rc); continue; }
+    startStage(j, 1);
+  }
+
+  auto maxOver = [&](auto fn) { int m = 0; for (int j = 0; j < n; j++) if (!J[j]->done) m = std::max(m, fn(J[j]->run->sys)); return m; };
+  while (true) {
+    bool any = false;
+    for (int j = 0; j < n; j++) any = any || !J[j]->done;
+    if (!any) break;
+    // (a) iteration starts: chi2 of the current estimate where needed, H and b, initial lambda -----------------------------------
+    bool anyBuild = false, anyChi = false, anyDiag = false;
+    for (int j = 0; j < n; j++) {
+      Job& X = *J[j];
+      BaDev& D = B.hDev[j];
+      D.trial = 0;
+      D.build = !X.done && X.needBuild;
+      D.chi2 = D.build && (X.it == 0 || !X.lastAccepted);
+      D.maxdiag = D.build && X.it == 0;
+      D.cur = X.done ? 0 : X.run->cur;
+      D.lambda = X.lambda;
+      anyBuild = anyBuild || D.build; anyChi = anyChi || D.chi2; anyDiag = anyDiag || D.maxdiag;
+    }
+    const int gE = maxOver([](const Run::Sys& Y) { return Y.nBlkE; }), gL128 = maxOver([](const Run::Sys& Y) { return (Y.nL + 127) / 128; }),
+              gL256 = maxOver([](const Run::Sys& Y) { return (Y.nL + 255) / 256; }), gP = maxOver([](const Run::Sys& Y) { return Y.nPf; }),
+              gBk = maxOver([](const Run::Sys& Y) { return Y.nBuckets + 1; }), gNb = maxOver([](const Run::Sys& Y) { return Y.nb; }),
+              gUpd = maxOver([](const Run::Sys& Y) { return (std::max(Y.nPf, Y.nL) + 255) / 256; }),
+              gScale = maxOver([](const Run::Sys& Y) { return (6 * Y.nPf + 3 * Y.nL + 255) / 256; }), gN = maxOver([](const Run::Sys& Y) { return Y.n; });
+    const BaDev* dDev = B.dDev.as<BaDev>();
+    if (anyBuild) {
+      HIPCHK(hipMemcpyAsync(B.dDev.p, B.hDev, sizeof(BaDev) * n, hipMemcpyHostToDevice, s));
+      if (anyChi) {
+        hipLaunchKernelGGL(kb_errors, dim3(gE, 1, n), dim3(256), 0, s, dDev, 0);
+        hipLaunchKernelGGL(kb_sum_partials, dim3(1, 1, n), dim3(256), 0, s, dDev, 0);
+      }
+      hipLaunchKernelGGL(kb_build_points, dim3(gL128, 1, n), dim3(128), 0, s, dDev);
+      if (gP) hipLaunchKernelGGL(kb_build_poses, dim3(gP, 1, n), dim3(256), 0, s, dDev);
+      if (anyDiag) hipLaunchKernelGGL(kb_max_diag, dim3(1, 1, n), dim3(256), 0, s, dDev);
+      HIPCHK(hipGetLastError());
+      if (anyChi || anyDiag) {
+        HIPCHK(hipMemcpyAsync(B.hScal, dScalAll, sizeof(double) * 8 * n, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+      }
+      for (int j = 0; j < n; j++) {
+        Job& X = *J[j];
+        const BaDev& D = B.hDev[j];
+        if (!D.build) continue;
+        if (D.chi2) X.currentChi = B.hScal[8 * j + 0];
+        if (D.maxdiag) { X.lambda = 1e-5 * B.hScal[8 * j + 1]; X.ni = 2; }   // computeLambdaInit
+        X.needBuild = false;
+      }
+    }
+    // (b) one LM trial of every unfinished problem ----------------------------------------------------------------------------------
+    for (int j = 0; j < n; j++) {
+      Job& X = *J[j];
+      BaDev& D = B.hDev[j];
+      D.build = D.chi2 = D.maxdiag = 0;
+      D.trial = !X.done;
+      D.lambda = X.lambda;
+      D.cur = X.done ? 0 : X.run->cur;
+    }
+    HIPCHK(hipMemcpyAsync(B.dDev.p, B.hDev, sizeof(BaDev) * n, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(kb_dinv, dim3(gL256, 1, n), dim3(256), 0, s, dDev);
+    hipLaunchKernelGGL(kb_bd, dim3(gE, 1, n), dim3(256), 0, s, dDev);
+    if (gP) hipLaunchKernelGGL(kb_bs, dim3(gP, 1, n), dim3(256), 0, s, dDev);
+    hipLaunchKernelGGL(kb_schur_pairs, dim3(gBk, 1, n), dim3(64 * kSchurWaves), 0, s, dDev);
+    for (int kb = 0; kb < gNb; kb++)
+      hipLaunchKernelGGL(kb_chol_step, dim3((gNb - kb) * (gNb - kb + 1) / 2 + (kb > 0), 1, n), dim3(256), 0, s, dDev, kb);
+    {
+      const size_t dyn = sizeof(double) * (size_t)gN;
+      if (dyn > 48 * 1024)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kb_chol_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+      hipLaunchKernelGGL(kb_chol_solve, dim3(1, 1, n), dim3(1024), dyn, s, dDev);
+    }
+    hipLaunchKernelGGL(kb_backsub, dim3(gL128, 1, n), dim3(128), 0, s, dDev);
+    hipLaunchKernelGGL(kb_update, dim3(gUpd, 1, n), dim3(256), 0, s, dDev);
+    hipLaunchKernelGGL(kb_scale, dim3(gScale, 1, n), dim3(256), 0, s, dDev);
+    hipLaunchKernelGGL(kb_sum_partials, dim3(1, 1, n), dim3(256), 0, s, dDev, 2);
+    hipLaunchKernelGGL(kb_errors, dim3(gE, 1, n), dim3(256), 0, s, dDev, 1);
+    hipLaunchKernelGGL(kb_sum_partials, dim3(1, 1, n), dim3(256), 0, s, dDev, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(B.hScal, dScalAll, sizeof(double) * 8 * n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    // (c) the LM decision of every problem (optimization_algorithm_levenberg.cpp:95-146, as in optimize()) -----------------------------------
+    for (int j = 0; j < n; j++) {
+      Job& X = *J[j];
+      if (X.done) continue;
+      const double* hs = B.hScal + (size_t)8 * j;
+      double tempChi = hs[0];
+      const double scaleSum = hs[2];
+      const bool ok2 = (int)hs[6] == 0;
+      if (!ok2) tempChi = std::numeric_limits<double>::max();
+      X.rho = X.currentChi - tempChi;
+      const double scale = scaleSum + 1e-3;
+      X.rho /= scale;
+      bool lambdaBroke = false;
+      if (X.rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - pow((2 * X.rho - 1), 3);
+        alpha = std::min(alpha, 2. / 3.);
+        X.lambda *= std::max(1. / 3., alpha);
+        X.ni = 2;
+        X.currentChi = tempChi;
+        X.run->cur ^= 1;  // discardTop(): keep the updated estimate
+        X.lastAccepted = true;
+      } else {
+        X.lastAccepted = false;
+        X.lambda *= X.ni;
+        X.ni *= 2;  // pop(): the previous estimate is still in poses[cur]
+        if (!std::isfinite(X.lambda)) lambdaBroke = true;
+      }
+      X.qmax++;
+      X.run->res->n_trials++;
+      if (lambdaBroke || !(X.rho < 0 && X.qmax < X.O.max_trials && !X.run->stopped())) endIteration(j);
+    }
+  }
+  int first = YDORB_OK;
+  for (int j = 0; j < n; j++) if (J[j]->rc != YDORB_OK && first == YDORB_OK) first = J[j]->rc;
+  return first;
 }
 
 }  // namespace
@@ -431,28 +742,13 @@ void ydorb_ba_default_options(YdBaOptions* o) {
 }
 
 int ydorb_ba_solve(const YdBaProblem* P, const YdBaOptions* optIn, YdBaResult* res) {
-  if (!P || !res) { set_error("null argument"); return YDORB_ERR_INVALID_ARG; }
   YdBaOptions O;
-  if (optIn) O = *optIn; else ydorb_ba_default_options(&O);
-  uint8_t* outlier = res->edge_outlier;
-  memset(res, 0, sizeof(*res));
-  res->edge_outlier = outlier;
+  int rc = checkProblem(P, optIn, res, &O);
+  if (rc) return rc;
   const int K = P->n_poses, NP = P->n_points, E = P->n_edges;
-  if (K < 0 || NP < 0 || E < 0 || (K && (!P->poses || !P->pose_fixed)) || (NP && !P->points) ||
-      (E && (!P->edge_pose || !P->edge_point || !P->edge_meas || !P->edge_inv_sigma2)) || O.device < 0 || O.device >= 16 || O.max_trials < 1) {
-    set_error("invalid BA problem");
-    return YDORB_ERR_INVALID_ARG;
-  }
-  for (int e = 0; e < E; e++)
-    if (P->edge_pose[e] < 0 || P->edge_pose[e] >= K || P->edge_point[e] < 0 || P->edge_point[e] >= NP) {
-      set_error("edge %d references a vertex out of range", e);
-      return YDORB_ERR_INVALID_ARG;
-    }
-  if (outlier) memset(outlier, 0, E);
   if (P->stop && *P->stop) { res->stopped = 1; return YDORB_OK; }  // optimizer.cpp:284-286
   if (E == 0 || K == 0 || NP == 0) return YDORB_OK;
-  int rc = require_device(O.device);
-  if (rc) return rc;
+  if ((rc = require_device(O.device))) return rc;
   g_t0 = std::chrono::steady_clock::now();
   trace("solve: begin");
   int slot = -1;
@@ -471,64 +767,27 @@ int ydorb_ba_solve(const YdBaProblem* P, const YdBaOptions* optIn, YdBaResult* r
     HIPCHK(hipHostMalloc(&c.hPin, sizeof(double) * 16));
   }
   Run R_{&c, P, &O, res};
-  R_.level.assign(E, 0);
-  R_.robust.assign(E, (O.flags & YDORB_BA_NO_ROBUST) ? 0 : 1);
-  R_.err.assign((size_t)3 * E, 0.0);
-  R_.cam = Cam{P->fx, P->fy, P->cx, P->cy, P->bf};
-  for (int i = 0; i < 2; i++)
-    if ((rc = c.poses[i].ensure(sizeof(double) * 7 * K)) || (rc = c.pts[i].ensure(sizeof(double) * 3 * NP))) return rc;
-  if ((rc = c.ePoseAll.ensure(sizeof(int) * E)) || (rc = c.ePtAll.ensure(sizeof(int) * E)) || (rc = c.depth.ensure(sizeof(double) * E))) return rc;
-  {  // SE3Quat's 7-vector constructor normalises the rotation (se3quat.h:80-86)
-    std::vector<double> hp(P->poses, P->poses + (size_t)7 * K);
-    for (int k = 0; k < K; k++) {
-      double* q = &hp[7 * k + 3];
-      if (q[3] < 0) for (int d = 0; d < 4; d++) q[d] = -q[d];
-      const double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-      for (int d = 0; d < 4; d++) q[d] /= nrm;
-    }
-    HIPCHK(hipMemcpy(c.poses[0].p, hp.data(), sizeof(double) * 7 * K, hipMemcpyHostToDevice));
-  }
-  HIPCHK(hipMemcpy(c.pts[0].p, P->points, sizeof(double) * 3 * NP, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c.ePoseAll.p, P->edge_pose, sizeof(int) * E, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c.ePtAll.p, P->edge_point, sizeof(int) * E, hipMemcpyHostToDevice));
+  if ((rc = beginSolve(R_))) return rc;
   trace("solve: state uploaded");
   hipEvent_t t0 = c.ev[2 * PH_COUNT], t1 = c.ev[2 * PH_COUNT + 1];
   HIPCHK(hipEventRecord(t0, c.stream));
 
   if ((rc = optimize(R_, O.iters1, 1, false))) return rc;
-  auto chi2Of = [&](int e) {
-    const double* r = &R_.err[(size_t)3 * e];
-    return P->edge_inv_sigma2[e] * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-  };
-  std::vector<double> depth;
   if (O.flags & YDORB_BA_SINGLE_STAGE) {
     // bundleAdjust: one optimize() call, nothing culled
   } else if (!R_.stopped()) {  // optimizer.cpp:290-314
-    if ((rc = edgeDepths(R_, depth))) return rc;
+    if ((rc = cullAfterFirstStage(R_))) return rc;
     trace("solve: depths read");
-    for (int e = 0; e < E; e++) {
-      const double th = P->edge_meas[3 * e + 2] >= 0 ? O.chi2_stereo : O.chi2_mono;
-      if (chi2Of(e) > th || !(depth[e] > 0.0)) R_.level[e] = 1;
-      R_.robust[e] = 0;
-    }
     if ((rc = optimize(R_, O.iters2, 2, true))) return rc;
   } else {
     res->stopped = 1;
   }
-  if ((rc = edgeDepths(R_, depth))) return rc;
-  if (outlier)
-    for (int e = 0; e < E; e++) {
-      const double th = P->edge_meas[3 * e + 2] >= 0 ? O.chi2_stereo : O.chi2_mono;
-      outlier[e] = (chi2Of(e) > th || !(depth[e] > 0.0)) ? 1 : 0;
-    }
   HIPCHK(hipEventRecord(t1, c.stream));
-  HIPCHK(hipMemcpy(P->poses, c.poses[R_.cur].p, sizeof(double) * 7 * K, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(P->points, c.pts[R_.cur].p, sizeof(double) * 3 * NP, hipMemcpyDeviceToHost));
+  if ((rc = endSolve(R_))) return rc;
   (void)hipEventElapsedTime(&res->ms_total, t0, t1);
   trace("solve: results read back");
   res->ms_errors = (float)R_.phaseMs[PH_ERR]; res->ms_build = (float)R_.phaseMs[PH_BUILD]; res->ms_schur = (float)R_.phaseMs[PH_SCHUR];
   res->ms_solve = (float)R_.phaseMs[PH_SOLVE]; res->ms_update = (float)R_.phaseMs[PH_UPDATE];
-  if (R_.stopped()) res->stopped = 1;
   return YDORB_OK;
 }
 
@@ -594,26 +853,36 @@ int ydorb_pose_optimize(const YdPoseBatch* B, uint8_t* outlier, int32_t* n_inlie
 int ydorb_ba_solve_batch(const YdBaProblem* probs, int32_t n, const YdBaOptions* opt, YdBaResult* res, int32_t threads, int32_t* rcEach) {
   if (n < 0 || (n > 0 && (!probs || !res))) { set_error("invalid argument"); return YDORB_ERR_INVALID_ARG; }
   if (opt && opt->world > 1) { set_error("the batched form solves whole problems: no landmark sharding"); return YDORB_ERR_INVALID_ARG; }
-  const int nt = std::max(1, std::min<int>(std::min<int>(threads > 0 ? threads : kCtxPool, kCtxPool), n));
-  std::atomic<int> next{0}, firstRc{0};
-  std::mutex errMu;
-  std::string errText;
-  auto worker = [&]() {
-    for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
-      const int rc = ydorb_ba_solve(&probs[i], opt, &res[i]);
-      if (rcEach) rcEach[i] = rc;
-      if (rc != YDORB_OK) {
-        int expected = 0;
-        if (firstRc.compare_exchange_strong(expected, rc)) { std::lock_guard<std::mutex> g(errMu); errText = ydorb_last_error(); }
-      }
-    }
-  };
-  std::vector<std::thread> pool;
-  for (int t = 1; t < nt; t++) pool.emplace_back(worker);
-  worker();
-  for (std::thread& t : pool) t.join();
-  if (firstRc.load() != 0) { set_error("%s", errText.c_str()); return firstRc.load(); }
-  return YDORB_OK;
+  if (n == 0) return YDORB_OK;
+  YdBaOptions O;
+  if (opt) O = *opt; else ydorb_ba_default_options(&O);
+  if (O.device < 0 || O.device >= 16) { set_error("invalid device"); return YDORB_ERR_INVALID_ARG; }
+  int rc = require_device(O.device);
+  if (rc) return rc;
+  BatchPool& B = g_batch[O.device];
+  std::lock_guard<std::mutex> lock(B.mu);
+  HIPCHK(hipSetDevice(O.device));
+  if (!B.stream) HIPCHK(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
+  // `threads` is the number of problems advanced together (0 = as many as fit one group); the lock-step batch needs no host threads
+  const int group = std::max(1, std::min<int>(threads > 0 ? threads : kBatchGroup, kBatchGroup));
+  if (B.cap < group) {
+    if (B.hDev) (void)hipHostFree(B.hDev);
+    if (B.hScal) (void)hipHostFree(B.hScal);
+    B.hDev = nullptr; B.hScal = nullptr; B.cap = 0;
+    HIPCHK(hipHostMalloc(&B.hDev, sizeof(BaDev) * group));
+    HIPCHK(hipHostMalloc(&B.hScal, sizeof(double) * 8 * group));
+    B.cap = group;
+  }
+  while ((int)B.jobs.size() < group) B.jobs.push_back(new Job());
+  int first = YDORB_OK;
+  std::string firstText;
+  for (int at = 0; at < n; at += group) {
+    const int m = std::min(group, n - at);
+    rc = solveGroup(B, probs + at, O, res + at, m, rcEach ? rcEach + at : nullptr);
+    if (rc != YDORB_OK && first == YDORB_OK) { first = rc; firstText = ydorb_last_error(); }
+  }
+  if (first != YDORB_OK) set_error("%s", firstText.c_str());
+  return first;
 }
 
 int ydorb_ba_dense_solve(int32_t device, const double* A, int32_t n0, const double* b, double* x, int32_t* ok) {
