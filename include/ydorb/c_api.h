@@ -410,10 +410,12 @@ void ydorb_ba_default_options(YdBaOptions* opt);
  * sessions — may solve at once; a ninth concurrent caller waits.  Results do not depend on what else runs (fixed summation
  * orders).  The reference itself calls localBundleAdjust from one thread (localMapping.cpp:29). */
 int ydorb_ba_solve(const YdBaProblem* prob, const YdBaOptions* opt, YdBaResult* res);
-/* n independent problems (several maps / sessions / replayed windows) solved concurrently: up to `threads` host threads (0 = the
- * library's 8 pooled contexts per device), each problem on its own stream and scratch.  One solve is a latency chain that leaves most
- * of the GPU idle, so the aggregate rate grows almost freely with the number in flight.  res[i] / rc_each[i] (may be NULL) per
- * problem; returns the first non-zero status.  Same results as n calls of ydorb_ba_solve. */
+/* n independent problems (several maps / sessions / replayed windows) solved in LOCK STEP: one set of kernel launches per phase for
+ * all problems (blockIdx.z = problem), the LM state of every problem kept on the host exactly as in ydorb_ba_solve and decided once per
+ * round from ONE read-back.  One solve is a latency chain of ~35 small launches per LM trial that leaves most of the GPU idle; a
+ * batch costs about the time of its slowest member plus the throughput-bound kernels.  `threads` = problems advanced together
+ * (0 = up to 64 per group; larger batches run group after group).  The problems may differ in every size.  res[i] / rc_each[i]
+ * (may be NULL) per problem; returns the first non-zero status.  Every result is bit-identical to its own ydorb_ba_solve call. */
 int ydorb_ba_solve_batch(const YdBaProblem* probs, int32_t n, const YdBaOptions* opt, YdBaResult* res, int32_t threads, int32_t* rc_each);
 
 /* ------------------------------------------------------------------------------------------

@@ -99,7 +99,7 @@ int allreduce(Run& R_, void* d_buf, int64_t count, int op) {
 }
 
 // YDORB_BA_TRACE=1: host wall-clock marks of the solve on stderr (where the time between device phases goes)
-static bool g_trace = getenv("YDORB_BA_TRACE") != nullptr;
+static bool g_trace = getenv("YDORB_BA_TRACE") != nullptr && getenv("YDORB_BA_TRACE")[0] == '1';
 static std::chrono::steady_clock::time_point g_t0;
 static void trace(const char* what) {
   if (!g_trace) return;
@@ -507,18 +507,21 @@ struct Job {
   double lambda = 0, ni = 2, currentChi = 0, rho = 0;
   bool lastAccepted = true, needBuild = false, done = false;
   int rc = YDORB_OK;
+  std::string errText;
   ~Job() { delete run; }
 };
 struct BatchPool {   // per device: contexts, stream and staging of the lock-step batches (one batch at a time per device)
   std::mutex mu;
   hipStream_t stream = nullptr;
   std::vector<Job*> jobs;          // grown on demand; buffers are kept between calls
+  std::vector<hipStream_t> setupStreams;
   DBuf dDev, dScal;                // BaDev[B]; per problem 8 doubles (chi2, max diag, scale sum, ..., status copies) + 2 ints of status
   BaDev* hDev = nullptr;           // pinned
   double* hScal = nullptr;         // pinned
   int cap = 0;
 };
 BatchPool g_batch[16];
+constexpr int kSetupThreads = 8;   // host threads of a batch's set-up phase
 constexpr int kBatchGroup = 64;    // problems per lock-step group (C5-sized problems take ~40 MB each)
 
 void fillDev(Job& J, BaDev& D, double* dScal, int* dStatus) {
@@ -595,26 +598,57 @@ int solveGroup(BatchPool& B, const YdBaProblem* probs, const YdBaOptions& Oin, Y
     X.needBuild = true; X.qmax = 0; X.rho = 0;
   };
 
-  for (int j = 0; j < n; j++) {
-    Job& X = *J[j];
-    X.done = false; X.rc = YDORB_OK;
-    delete X.run; X.run = nullptr;
-    if (rcEach) rcEach[j] = YDORB_OK;
-    if ((rc = checkProblem(&probs[j], &Oin, &res[j], &X.O))) { fail(j, rc); continue; }
-    const YdBaProblem* P = &probs[j];
-    if (P->stop && *P->stop) { res[j].stopped = 1; X.done = true; continue; }
-    if (P->n_edges == 0 || P->n_poses == 0 || P->n_points == 0) { X.done = true; continue; }
-    X.ctx.device = Oin.device; X.ctx.stream = s;
-    X.run = new Run{&X.ctx, P, &X.O, &res[j]};
-    if ((rc = beginSolve(*X.run))) { fail(j, rc); continue; }
-    startStage(j, 1);
+  // Set-up of every problem (validation, edge ordering, uploads, pose-pair buckets): ~2 ms of host work and pageable copies per C5-sized
+  // problem, independent of the others, so it is spread over a few host threads, each on its own set-up stream; the lock-step
+  // rounds below then run on the batch's one stream.
+  {
+    const int nt = std::max(1, std::min(n, kSetupThreads));
+    while ((int)B.setupStreams.size() < nt) {
+      hipStream_t st = nullptr;
+      HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      B.setupStreams.push_back(st);
+    }
+    std::atomic<int> next{0};
+    auto worker = [&](int t) {
+      (void)hipSetDevice(Oin.device);
+      hipStream_t st = B.setupStreams[t];
+      for (int j = next.fetch_add(1); j < n; j = next.fetch_add(1)) {
+        Job& X = *J[j];
+        X.done = false; X.rc = YDORB_OK; X.errText.clear();
+        delete X.run; X.run = nullptr;
+        if (rcEach) rcEach[j] = YDORB_OK;
+        int r = checkProblem(&probs[j], &Oin, &res[j], &X.O);
+        const YdBaProblem* P = &probs[j];
+        if (!r) {
+          if (P->stop && *P->stop) { res[j].stopped = 1; X.done = true; continue; }
+          if (P->n_edges == 0 || P->n_poses == 0 || P->n_points == 0) { X.done = true; continue; }
+          X.ctx.device = Oin.device; X.ctx.stream = st;
+          X.run = new Run{&X.ctx, P, &X.O, &res[j]};
+          r = beginSolve(*X.run);
+        }
+        if (!r) {
+          startStage(j, 1);
+          r = X.rc;
+        }
+        if (r) { X.errText = ydorb_last_error(); fail(j, r); }
+        if (hipStreamSynchronize(st) != hipSuccess && !r) { X.errText = "hipStreamSynchronize failed"; fail(j, YDORB_ERR_HIP); }
+        X.ctx.stream = s;
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(worker, t);
+    worker(0);
+    for (std::thread& th : pool) th.join();
+    for (int j = 0; j < n; j++) if (J[j]->rc != YDORB_OK) set_error("%s", J[j]->errText.c_str());
   }
+  trace("batch: set-up done");
 
   auto maxOver = [&](auto fn) { int m = 0; for (int j = 0; j < n; j++) if (!J[j]->done) m = std::max(m, fn(J[j]->run->sys)); return m; };
   while (true) {
     bool any = false;
     for (int j = 0; j < n; j++) any = any || !J[j]->done;
     if (!any) break;
+    trace("batch: round begins");
     // (a) iteration starts: chi2 of the current estimate where needed, H and b, initial lambda -----------------------------------
     bool anyBuild = false, anyChi = false, anyDiag = false;
     for (int j = 0; j < n; j++) {
@@ -688,6 +722,7 @@ int solveGroup(BatchPool& B, const YdBaProblem* probs, const YdBaOptions& Oin, Y
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(B.hScal, dScalAll, sizeof(double) * 8 * n, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    trace("batch: round synchronised");
     // (c) the LM decision of every problem (optimization_algorithm_levenberg.cpp:95-146, as in optimize()) -----------------------------------
     for (int j = 0; j < n; j++) {
       Job& X = *J[j];
@@ -720,6 +755,7 @@ int solveGroup(BatchPool& B, const YdBaProblem* probs, const YdBaOptions& Oin, Y
       if (lambdaBroke || !(X.rho < 0 && X.qmax < X.O.max_trials && !X.run->stopped())) endIteration(j);
     }
   }
+  trace("batch: done");
   int first = YDORB_OK;
   for (int j = 0; j < n; j++) if (J[j]->rc != YDORB_OK && first == YDORB_OK) first = J[j]->rc;
   return first;
@@ -861,6 +897,7 @@ int ydorb_ba_solve_batch(const YdBaProblem* probs, int32_t n, const YdBaOptions*
   if (rc) return rc;
   BatchPool& B = g_batch[O.device];
   std::lock_guard<std::mutex> lock(B.mu);
+  g_t0 = std::chrono::steady_clock::now();
   HIPCHK(hipSetDevice(O.device));
   if (!B.stream) HIPCHK(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
   // `threads` is the number of problems advanced together (0 = as many as fit one group); the lock-step batch needs no host threads
