@@ -76,6 +76,18 @@ def cpu_info():
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 1
+    try:   # a container's CPU share (cgroup v2 cpu.max = "<quota> <period>" or "max <period>")
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            usable = max(1, min(usable, int(round(int(q) / int(per)))))
+    except (OSError, ValueError):
+        try:   # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                usable = max(1, min(usable, int(round(q / per))))
+        except (OSError, ValueError):
+            pass
     return model, os.cpu_count() or 1, usable
 
 
