@@ -318,6 +318,8 @@ def main():
     traffic, valu_busy, traffic_source = None, None, None
     stage_kernels = {"pyramid": ("k_pyr_level0", "k_pyr_resize", "k_pyr_borders"), "fast_cells": ("k_fast_cells",), "blur": ("k_blur",),
                      "quadtree_after_blur": ("k_quadtree_flat", "k_quadtree"), "orient_describe": ("k_orient_describe",)}
+    # The roofline line names the dominant EXTRACTOR kernel: the stage timers of the two pipelines overlap, and of the matcher's stages
+    # the resolve is serial by definition (one wave per pair) - neither is a bandwidth figure.
     try:
         import csv
         for tag in ("r02", "r01f"):
@@ -326,9 +328,11 @@ def main():
                 continue
             rows = {r["kernel"]: r for r in csv.DictReader(open(pth))}
             if dom in stage_kernels and all(k in rows for k in stage_kernels[dom]):
-                per_frame = sum(float(rows[k]["fetch_MB_per_frame_raw"]) * 1.33 + float(rows[k]["write_MB_per_frame"]) for k in stage_kernels[dom])
+                per_frame = sum(float(rows[k]["fetch_MB_per_frame_raw"]) * float(rows[k].get("fetch_correction") or 1.33) + float(rows[k]["write_MB_per_frame"])
+                                for k in stage_kernels[dom])
                 traffic = per_frame * 1e6 * FL
-                traffic_source = "profiles/%s_pmc_hbm_traffic.csv (separate rocprofv3 --pmc passes, per frame, scaled to %d frames per launch)" % (tag, FL)
+                traffic_source = ("profiles/%s_pmc_hbm_traffic.csv (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the extractor alone, FETCH calibrated "
+                                  "on k_pyr_level0's known read size, per frame, scaled to %d frames per launch; not collected in this run)" % (tag, FL))
             pth2 = os.path.join(ROOT, "profiles", "%s_pmc_sq_valu.csv" % tag)
             if os.path.exists(pth2):
                 for r in csv.DictReader(open(pth2)):
