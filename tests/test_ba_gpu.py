@@ -257,3 +257,44 @@ def test_stop_flag_set_from_another_thread_mid_solve():
         if (stage == 1 and j >= 1) or (stage == 2 and j - 5 >= 0):
             cands.append(y.Optimizer.local_bundle_adjust(prob, o))
     assert any(c["poses"].tobytes() == seen["poses"].tobytes() and c["points"].tobytes() == seen["points"].tobytes() for c in cands)
+
+
+def test_batch_with_mixed_sizes_empty_stopped_and_invalid_members(oracle_lib):
+    """The lock-step batch takes problems of any size side by side, including ones that have nothing to do (no edges, stop flag already set)
+    and invalid ones (reported per problem through rc_each, the others still solved); every solved member equals its single solve."""
+    import ctypes as C
+    import ydorbslam_amd as y
+    from ydorbslam_amd._lib import YdBaProblem, YdBaResult, lib
+    big = synth_ba_problem(40, 3000, 7, seed=31, outlier_frac=0.04, mono_frac=0.2)
+    small = synth_ba_problem(4, 30, 3, seed=32)
+    empty = dict(small); empty["edge_pose"] = np.zeros(0, np.int32); empty["edge_point"] = np.zeros(0, np.int32)
+    empty["meas"] = np.zeros((0, 3)); empty["info"] = np.zeros(0)
+    probs = [big, small, empty, synth_ba_problem(9, 300, 5, seed=33, n_fixed=3)]
+    single = [y.Optimizer.local_bundle_adjust(p) for p in probs]
+    batch = y.Optimizer.local_bundle_adjust_batch(probs)
+    for a, b in zip(single, batch):
+        assert a["poses"].tobytes() == b["poses"].tobytes() and a["points"].tobytes() == b["points"].tobytes()
+        assert np.array_equal(a["outlier"], b["outlier"]) and a["trials"] == b["trials"] and a["log"].tobytes() == b["log"].tobytes()
+    assert batch[2]["trials"] == 0
+    # global-BA options (single stage, no robust kernel) through the batch as well
+    go = y.Optimizer.global_options(6, False)
+    gs = [y.Optimizer.local_bundle_adjust(p, go) for p in probs[:2]]
+    gb = y.Optimizer.local_bundle_adjust_batch(probs[:2], go)
+    for a, b in zip(gs, gb):
+        assert a["poses"].tobytes() == b["poses"].tobytes() and a["log"].tobytes() == b["log"].tobytes()
+    # one invalid member (an edge that references a pose out of range): its rc is reported, the valid one is solved
+    bad = dict(small); bad["edge_pose"] = small["edge_pose"].copy(); bad["edge_pose"][0] = 99
+    L = lib()
+    keep, P, R = [], (YdBaProblem * 2)(), (YdBaResult * 2)()
+    for i, pr in enumerate((bad, small)):
+        arrs = [np.ascontiguousarray(pr["poses"], np.float64).copy(), np.ascontiguousarray(pr["fixed"], np.uint8), np.ascontiguousarray(pr["points"], np.float64).copy(),
+                np.ascontiguousarray(pr["edge_pose"], np.int32), np.ascontiguousarray(pr["edge_point"], np.int32), np.ascontiguousarray(pr["meas"], np.float64),
+                np.ascontiguousarray(pr["info"], np.float64), np.zeros(len(pr["edge_pose"]), np.uint8)]
+        keep.append(arrs)
+        P[i] = YdBaProblem(len(arrs[0]), len(arrs[2]), len(arrs[3]), *[a.ctypes.data_as(C.c_void_p) for a in arrs[:7]], *[float(v) for v in pr["camera"]], None)
+        R[i].edge_outlier = arrs[7].ctypes.data_as(C.c_void_p).value
+    rc_each = (C.c_int32 * 2)()
+    o = y.Optimizer.default_options()
+    rc = L.ydorb_ba_solve_batch(P, 2, C.byref(o), R, 0, rc_each)
+    assert rc != 0 and rc_each[0] != 0 and rc_each[1] == 0
+    assert keep[1][0].tobytes() == single[1]["poses"].tobytes() and R[1].n_trials == single[1]["trials"]

@@ -310,3 +310,33 @@ def test_hamming_topk_brute_force(oracle_lib, scene):
     out = d_out.cpu().numpy()
     assert np.array_equal(out[0, :len(da)], oracle_lib.hamming_topk(da, db).view(np.int32).reshape(-1, 6))
     assert np.array_equal(out[1, :len(db)], oracle_lib.hamming_topk(db, da).view(np.int32).reshape(-1, 6))
+
+
+def test_new_entry_points_on_empty_and_ragged_inputs(oracle_lib):
+    """Edge cases of the round-2 entry points: no queries, no targets, empty candidate lists, frames without keypoints in a pair list,
+    out-of-range pairs."""
+    import torch
+    import ydorbslam_amd as y
+    m = y.OrbMatcher()
+    rng = np.random.default_rng(1)
+    q = rng.integers(0, 256, (5, 32), dtype=np.uint8); t = rng.integers(0, 256, (7, 32), dtype=np.uint8)
+    assert len(m.hamming_topk(np.zeros((0, 32), np.uint8), t)) == 0
+    none = m.hamming_topk(q, np.zeros((0, 32), np.uint8))
+    assert all(r.tolist() == (256, -1, 256, -1, -1, -1) for r in none)
+    offs = np.array([0, 0, 3, 3, 4, 4], np.int32); cand = np.array([6, 0, 6, 2], np.int32)     # empty lists, a repeated candidate
+    assert m.hamming_topk(q, t, offs, cand).tobytes() == oracle_lib.hamming_topk(q, t, offs, cand).tobytes()
+    with pytest.raises(y.YdorbError):
+        m.hamming_topk(q, t, np.array([1, 1, 1, 1, 1, 1], np.int32), cand)                      # offsets must start at 0
+    dev = torch.device("cuda:0")
+    cap, F = 64, 3
+    kps = torch.zeros((F, cap, 7), dtype=torch.float32, device=dev); desc = torch.zeros((F, cap, 32), dtype=torch.uint8, device=dev)
+    n = torch.tensor([0, 5, 0], dtype=torch.int32, device=dev)
+    kps[1, :5, 0] = torch.arange(5, device=dev) * 20 + 30; kps[1, :5, 1] = 40
+    asg = torch.full((2, cap), 7, dtype=torch.int32, device=dev); cnt = torch.full((2,), 9, dtype=torch.int32, device=dev)
+    fs = (kps.data_ptr(), desc.data_ptr(), n.data_ptr(), F, cap)
+    sf = np.power(np.float32(1.2), np.arange(8)).astype(np.float32)
+    m.match_pairs_device(fs, fs, [(0, 1), (1, 2)], 640, 480, 15.0, sf, asg.data_ptr(), cnt.data_ptr())   # empty query frame; empty target frame
+    m.synchronize()
+    assert cnt.tolist() == [0, 0] and bool((asg == -1).all())
+    with pytest.raises(y.YdorbError):
+        m.match_pairs_device(fs, fs, [(0, 3)], 640, 480, 15.0, sf, asg.data_ptr(), cnt.data_ptr())
