@@ -776,11 +776,16 @@ __device__ __forceinline__ void b_chol_step(R* __restrict__ S, R* __restrict__ d
   const int i = kb + ri, j = kb + cj;          // tile (i, j), i >= j >= kb
   const bool panel = j == kb;
   CH_CLK(1);
-  R acc[4], accD[4] = {0, 0, 0, 0};
+  // The rank-32 update of the tile (and, on panel workgroups, of the diagonal tile) on the FP64 matrix core: wave w owns the 16 x 16
+  // quadrant (w >> 1, w & 1), D = C - A B with A[i][k] = L(i, kb-1) rows, B[k][j] = L(j, kb-1)^T, eight v_mfma_f64_16x16x4_f64 per
+  // quadrant.  Lane layout of the instruction: A and B element (i or j = lane % 16, k = lane / 16); D element (i = lane / 16 + 4 reg,
+  // j = lane % 16).  The operand tiles go through LDS once (coalesced loads) instead of 5 LDS reads per 4 multiply-adds.
+  const int mw = tid >> 6, ml = tid & 63, i16 = ml & 15, kq = ml >> 4, qr = 16 * (mw >> 1), qc = 16 * (mw & 1);
+  double4_t acc, accD = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int c = 0; c < 4; c++) {
-    acc[c] = S[(size_t)(i * NB + tr) * n + j * NB + tc4 + c];
-    if (panel) accD[c] = S[(size_t)(kb * NB + tr) * n + kb * NB + tc4 + c];
+  for (int reg = 0; reg < 4; reg++) {
+    acc[reg] = S[(size_t)(i * NB + qr + kq + 4 * reg) * n + j * NB + qc + i16];
+    if (panel) accD[reg] = S[(size_t)(kb * NB + qr + kq + 4 * reg) * n + kb * NB + qc + i16];
   }
   CH_CLK(2);
   if (kb > 0) {
@@ -791,29 +796,21 @@ __device__ __forceinline__ void b_chol_step(R* __restrict__ S, R* __restrict__ d
       if (panel) Lk[tr][tc4 + c] = S[(size_t)(kb * NB + tr) * n + (kb - 1) * NB + tc4 + c];
     }
     __syncthreads();
-#pragma unroll 8
-    for (int k = 0; k < NB; k++) {
-      const R a = La[tr][k];
 #pragma unroll
-      for (int c = 0; c < 4; c++) acc[c] -= a * Lb[tc4 + c][k];
-    }
+    for (int ks = 0; ks < NB; ks += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(0.0 - La[qr + i16][ks + kq], Lb[qc + i16][ks + kq], acc, 0, 0, 0);
     if (panel) {
-#pragma unroll 8
-      for (int k = 0; k < NB; k++) {
-        const R a = Lk[tr][k];
 #pragma unroll
-        for (int c = 0; c < 4; c++) accD[c] -= a * Lk[tc4 + c][k];
-      }
+      for (int ks = 0; ks < NB; ks += 4) accD = __builtin_amdgcn_mfma_f64_16x16x4f64(0.0 - Lk[qr + i16][ks + kq], Lk[qc + i16][ks + kq], accD, 0, 0, 0);
     }
   }
   CH_CLK(3);
   if (!panel) {
 #pragma unroll
-    for (int c = 0; c < 4; c++) S[(size_t)(i * NB + tr) * n + j * NB + tc4 + c] = acc[c];
+    for (int reg = 0; reg < 4; reg++) S[(size_t)(i * NB + qr + kq + 4 * reg) * n + j * NB + qc + i16] = acc[reg];
     return;
   }
 #pragma unroll
-  for (int c = 0; c < 4; c++) { Ta[tr][tc4 + c] = acc[c]; Dg[tr][tc4 + c] = accD[c]; }
+  for (int reg = 0; reg < 4; reg++) { Ta[qr + kq + 4 * reg][qc + i16] = acc[reg]; Dg[qr + kq + 4 * reg][qc + i16] = accD[reg]; }
   if (tid == 0) sOk = 1;
   __syncthreads();
   CH_CLK(4);
