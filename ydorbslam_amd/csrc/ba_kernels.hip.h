@@ -1370,13 +1370,14 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(int nFrames, con
 // problem that sits this phase out (finished, or waiting while others retry a rejected step) - leave at once.  The arithmetic and
 // its order are those of the single-problem launches, so a batched solve is bit-identical to its own single solve.
 // ---------------------------------------------------------------------------------------------------
+// Every buffer is named by its BYTE OFFSET from the BaDev array itself, not by a pointer: a pointer loaded from memory is a FLAT
+// pointer to the compiler (flat_load / flat_store, which count on the LDS counter too and serialise with the LDS traffic of the
+// Cholesky and Schur kernels), whereas `kernel argument + offset` keeps the global address space.
 struct BaDev {
-  EdgeSoA Ed;
-  const int *ptStart, *poseStart, *poseEdges, *eLm, *poseOf, *ptOf, *pairStart;
-  const int2* pairItems;
-  R *poses[2], *pts[2];
-  R *err, *partial, *Hll, *bl, *Hpl, *BD, *Hpp, *S, *diagL, *diagInv, *Dinv, *db, *xp, *yv, *xl, *scal;
-  int* status;
+  long long ePose, ePidx, ePt, eMeas, eInfo, eRobust;   // the EdgeSoA arrays
+  long long ptStart, poseStart, poseEdges, eLm, poseOf, ptOf, pairStart, pairItems;
+  long long poses[2], pts[2];
+  long long err, partial, Hll, bl, Hpl, BD, Hpp, S, diagL, diagInv, Dinv, db, xp, yv, xl, scal, status;
   Cam cam;
   R dM, dSt;
   int nL, nPf, Ea, n, nb, nBlkE, nBuckets;
@@ -1388,6 +1389,9 @@ struct BaDev {
   int maxdiag;    // ... and its initial lambda (first iteration of an optimize() call)
   int trial;      // takes part in the trial launches of this round
 };
+#define YD_BA_AT(T, off) (reinterpret_cast<T*>(const_cast<char*>(reinterpret_cast<const char*>(all)) + (off)))
+#define YD_BA_ED EdgeSoA{YD_BA_AT(const int, D.ePose), YD_BA_AT(const int, D.ePidx), YD_BA_AT(const int, D.ePt), YD_BA_AT(const R, D.eMeas), \
+                         YD_BA_AT(const R, D.eInfo), YD_BA_AT(const uint8_t, D.eRobust), D.Ea}
 #define YD_BA_PROB(flag)                         \
   const BaDev& D = all[blockIdx.z];              \
   if (!D.flag) return
@@ -1395,75 +1399,77 @@ __global__ __launch_bounds__(256) void kb_errors(const BaDev* __restrict__ all, 
   const BaDev& D = all[blockIdx.z];
   if (!(onTrial ? D.trial : (D.build && D.chi2)) || blockIdx.x >= (unsigned)D.nBlkE) return;
   const int buf = onTrial ? (D.cur ^ 1) : D.cur;
-  b_errors(D.Ed, D.poses[buf], D.pts[buf], D.cam, D.dM, D.dSt, D.err, D.partial);
+  b_errors(YD_BA_ED, YD_BA_AT(R, D.poses[buf]), YD_BA_AT(R, D.pts[buf]), D.cam, D.dM, D.dSt, YD_BA_AT(R, D.err), YD_BA_AT(R, D.partial));
 }
 // use 0: chi2 of the current estimate (no status), 1: chi2 of the trial estimate (+ factorisation status), 2: the scale sum
 __global__ __launch_bounds__(256) void kb_sum_partials(const BaDev* __restrict__ all, int use) {
   const BaDev& D = all[blockIdx.z];
   if (!(use == 0 ? (D.build && D.chi2) : D.trial)) return;
-  if (use == 2) b_sum_partials(D.partial + D.nBlkE, (6 * D.nPf + 3 * D.nL + 255) / 256, D.scal, 2, nullptr);
-  else b_sum_partials(D.partial, D.nBlkE, D.scal, 0, use == 1 ? D.status : nullptr);
+  if (use == 2) b_sum_partials(YD_BA_AT(R, D.partial) + D.nBlkE, (6 * D.nPf + 3 * D.nL + 255) / 256, YD_BA_AT(R, D.scal), 2, nullptr);
+  else b_sum_partials(YD_BA_AT(R, D.partial), D.nBlkE, YD_BA_AT(R, D.scal), 0, use == 1 ? YD_BA_AT(int, D.status) : nullptr);
 }
 __global__ __launch_bounds__(128) void kb_build_points(const BaDev* __restrict__ all) {
   YD_BA_PROB(build);
   if (blockIdx.x >= (unsigned)((D.nL + 127) / 128)) return;
-  b_build_points(D.Ed, D.ptStart, D.nL, D.poses[D.cur], D.pts[D.cur], D.cam, D.dM, D.dSt, D.err, D.Hll, D.bl, D.Hpl);
+  b_build_points(YD_BA_ED, YD_BA_AT(const int, D.ptStart), D.nL, YD_BA_AT(R, D.poses[D.cur]), YD_BA_AT(R, D.pts[D.cur]), D.cam, D.dM, D.dSt, YD_BA_AT(R, D.err), YD_BA_AT(R, D.Hll), YD_BA_AT(R, D.bl), YD_BA_AT(R, D.Hpl));
 }
 __global__ __launch_bounds__(256) void kb_build_poses(const BaDev* __restrict__ all) {
   YD_BA_PROB(build);
   if (blockIdx.x >= (unsigned)D.nPf) return;
-  b_build_poses(D.Ed, D.poseStart, D.poseEdges, D.poses[D.cur], D.pts[D.cur], D.cam, D.dM, D.dSt, D.err, D.Hpp, D.Hpp + (size_t)36 * D.nPf);
+  b_build_poses(YD_BA_ED, YD_BA_AT(const int, D.poseStart), YD_BA_AT(const int, D.poseEdges), YD_BA_AT(R, D.poses[D.cur]), YD_BA_AT(R, D.pts[D.cur]), D.cam, D.dM, D.dSt, YD_BA_AT(R, D.err), YD_BA_AT(R, D.Hpp), YD_BA_AT(R, D.Hpp) + (size_t)36 * D.nPf);
 }
 __global__ __launch_bounds__(256) void kb_max_diag(const BaDev* __restrict__ all) {
   const BaDev& D = all[blockIdx.z];
   if (!(D.build && D.maxdiag)) return;
-  b_max_diag(D.Hpp, D.nPf, D.Hll, D.nL, D.scal, 1);
+  b_max_diag(YD_BA_AT(R, D.Hpp), D.nPf, YD_BA_AT(R, D.Hll), D.nL, YD_BA_AT(R, D.scal), 1);
 }
 __global__ __launch_bounds__(256) void kb_dinv(const BaDev* __restrict__ all) {
   YD_BA_PROB(trial);
   if (blockIdx.x >= (unsigned)((D.nL + 255) / 256)) return;
-  b_dinv(D.Hll, D.bl, D.nL, D.lambda, D.Dinv, D.db, D.status);
+  b_dinv(YD_BA_AT(R, D.Hll), YD_BA_AT(R, D.bl), D.nL, D.lambda, YD_BA_AT(R, D.Dinv), YD_BA_AT(R, D.db), YD_BA_AT(int, D.status));
 }
 __global__ __launch_bounds__(256) void kb_bd(const BaDev* __restrict__ all) {
   YD_BA_PROB(trial);
   if (blockIdx.x >= (unsigned)D.nBlkE) return;
-  b_bd(D.Ed, D.eLm, D.Hpl, D.Dinv, D.BD);
+  b_bd(YD_BA_ED, YD_BA_AT(const int, D.eLm), YD_BA_AT(R, D.Hpl), YD_BA_AT(R, D.Dinv), YD_BA_AT(R, D.BD));
 }
 __global__ __launch_bounds__(256) void kb_bs(const BaDev* __restrict__ all) {
   YD_BA_PROB(trial);
   if (blockIdx.x >= (unsigned)D.nPf) return;
-  b_bs(D.Ed, D.poseStart, D.poseEdges, D.eLm, D.Hpl, D.db, D.Hpp + (size_t)36 * D.nPf, 1.0, D.S + (size_t)D.n * D.n);
+  b_bs(YD_BA_ED, YD_BA_AT(const int, D.poseStart), YD_BA_AT(const int, D.poseEdges), YD_BA_AT(const int, D.eLm), YD_BA_AT(R, D.Hpl), YD_BA_AT(R, D.db), YD_BA_AT(R, D.Hpp) + (size_t)36 * D.nPf, 1.0, YD_BA_AT(R, D.S) + (size_t)D.n * D.n);
 }
 __global__ __launch_bounds__(64 * kSchurWaves) void kb_schur_pairs(const BaDev* __restrict__ all) {
   YD_BA_PROB(trial);
   if (blockIdx.x >= (unsigned)(D.nBuckets + 1)) return;
-  b_schur_pairs(D.pairStart, D.pairItems, D.nPf, D.nBuckets, D.BD, D.Hpl, D.Hpp, D.lambda, 1.0, D.n, D.S, D.S + (size_t)D.n * D.n);
+  b_schur_pairs(YD_BA_AT(const int, D.pairStart), YD_BA_AT(const int2, D.pairItems), D.nPf, D.nBuckets, YD_BA_AT(R, D.BD), YD_BA_AT(R, D.Hpl), YD_BA_AT(R, D.Hpp), D.lambda, 1.0, D.n, YD_BA_AT(R, D.S), YD_BA_AT(R, D.S) + (size_t)D.n * D.n);
 }
 __global__ __launch_bounds__(256) void kb_chol_step(const BaDev* __restrict__ all, int kb) {
   YD_BA_PROB(trial);
   if (kb >= D.nb || blockIdx.x >= (unsigned)((D.nb - kb) * (D.nb - kb + 1) / 2 + (kb > 0))) return;
-  b_chol_step(D.S, D.diagL, D.diagInv, D.n, kb, D.status, D.S + (size_t)D.n * D.n, D.yv);
+  b_chol_step(YD_BA_AT(R, D.S), YD_BA_AT(R, D.diagL), YD_BA_AT(R, D.diagInv), D.n, kb, YD_BA_AT(int, D.status), YD_BA_AT(R, D.S) + (size_t)D.n * D.n, YD_BA_AT(R, D.yv));
 }
 __global__ __launch_bounds__(1024) void kb_chol_solve(const BaDev* __restrict__ all) {
   YD_BA_PROB(trial);
-  b_chol_solve(D.S, D.diagInv, D.n, D.yv, D.S + (size_t)D.n * D.n, D.xp);
+  b_chol_solve(YD_BA_AT(R, D.S), YD_BA_AT(R, D.diagInv), D.n, YD_BA_AT(R, D.yv), YD_BA_AT(R, D.S) + (size_t)D.n * D.n, YD_BA_AT(R, D.xp));
 }
 __global__ __launch_bounds__(128) void kb_backsub(const BaDev* __restrict__ all) {
   YD_BA_PROB(trial);
   if (blockIdx.x >= (unsigned)((D.nL + 127) / 128)) return;
-  b_backsub(D.Ed, D.ptStart, D.nL, D.Hpl, D.Dinv, D.bl, D.xp, D.xl);
+  b_backsub(YD_BA_ED, YD_BA_AT(const int, D.ptStart), D.nL, YD_BA_AT(R, D.Hpl), YD_BA_AT(R, D.Dinv), YD_BA_AT(R, D.bl), YD_BA_AT(R, D.xp), YD_BA_AT(R, D.xl));
 }
 __global__ __launch_bounds__(256) void kb_update(const BaDev* __restrict__ all) {
   YD_BA_PROB(trial);
   if (blockIdx.x >= (unsigned)((max(D.nPf, D.nL) + 255) / 256)) return;
-  b_update(D.poses[D.cur], D.pts[D.cur], D.poses[D.cur ^ 1], D.pts[D.cur ^ 1], D.poseOf, D.nPf, D.ptOf, D.nL, D.xp, D.xl);
+  b_update(YD_BA_AT(R, D.poses[D.cur]), YD_BA_AT(R, D.pts[D.cur]), YD_BA_AT(R, D.poses[D.cur ^ 1]), YD_BA_AT(R, D.pts[D.cur ^ 1]), YD_BA_AT(const int, D.poseOf), D.nPf, YD_BA_AT(const int, D.ptOf), D.nL, YD_BA_AT(R, D.xp), YD_BA_AT(R, D.xl));
 }
 __global__ __launch_bounds__(256) void kb_scale(const BaDev* __restrict__ all) {
   YD_BA_PROB(trial);
   if (blockIdx.x >= (unsigned)((6 * D.nPf + 3 * D.nL + 255) / 256)) return;
-  b_scale(D.xp, D.Hpp + (size_t)36 * D.nPf, 6 * D.nPf, D.xl, D.bl, 3 * D.nL, D.lambda, D.partial + D.nBlkE);
+  b_scale(YD_BA_AT(R, D.xp), YD_BA_AT(R, D.Hpp) + (size_t)36 * D.nPf, 6 * D.nPf, YD_BA_AT(R, D.xl), YD_BA_AT(R, D.bl), 3 * D.nL, D.lambda, YD_BA_AT(R, D.partial) + D.nBlkE);
 }
 #undef YD_BA_PROB
+#undef YD_BA_ED
+#undef YD_BA_AT
 
 }  // namespace ba
 }  // namespace ydorb

@@ -524,18 +524,19 @@ BatchPool g_batch[16];
 constexpr int kSetupThreads = 8;   // host threads of a batch's set-up phase
 constexpr int kBatchGroup = 64;    // problems per lock-step group (C5-sized problems take ~40 MB each)
 
-void fillDev(Job& J, BaDev& D, double* dScal, int* dStatus) {
+void fillDev(Job& J, BaDev& D, const BaDev* dDevBase, double* dScal, int* dStatus) {
   Ctx& c = J.ctx;
   const Run::Sys& Y = J.run->sys;
   memset(&D, 0, sizeof(D));
-  D.Ed = EdgeSoA{c.ePose.as<int>(), c.ePidx.as<int>(), c.ePt.as<int>(), c.eMeas.as<double>(), c.eInfo.as<double>(), c.eRobust.as<uint8_t>(), Y.Ea};
-  D.ptStart = c.ptStart.as<int>(); D.poseStart = c.poseStart.as<int>(); D.poseEdges = c.poseEdges.as<int>(); D.eLm = c.eLm.as<int>();
-  D.poseOf = c.poseOf.as<int>(); D.ptOf = c.ptOf.as<int>(); D.pairStart = c.pairStart.as<int>(); D.pairItems = c.pairB.as<int2>();
-  for (int i = 0; i < 2; i++) { D.poses[i] = c.poses[i].as<double>(); D.pts[i] = c.pts[i].as<double>(); }
-  D.err = c.err.as<double>(); D.partial = c.partial.as<double>(); D.Hll = c.Hll.as<double>(); D.bl = c.bl.as<double>(); D.Hpl = c.Hpl.as<double>();
-  D.BD = c.BD.as<double>(); D.Hpp = c.Hpp.as<double>(); D.S = c.S.as<double>(); D.diagL = c.diagL.as<double>(); D.diagInv = c.diagInv.as<double>();
-  D.Dinv = c.Dinv.as<double>(); D.db = c.db.as<double>(); D.xp = c.xp.as<double>(); D.yv = c.yv.as<double>(); D.xl = c.xl.as<double>();
-  D.scal = dScal; D.status = dStatus;
+  auto off = [&](const void* p) { return (long long)(reinterpret_cast<const char*>(p) - reinterpret_cast<const char*>(dDevBase)); };   // see BaDev
+  D.ePose = off(c.ePose.p); D.ePidx = off(c.ePidx.p); D.ePt = off(c.ePt.p); D.eMeas = off(c.eMeas.p); D.eInfo = off(c.eInfo.p); D.eRobust = off(c.eRobust.p);
+  D.ptStart = off(c.ptStart.p); D.poseStart = off(c.poseStart.p); D.poseEdges = off(c.poseEdges.p); D.eLm = off(c.eLm.p);
+  D.poseOf = off(c.poseOf.p); D.ptOf = off(c.ptOf.p); D.pairStart = off(c.pairStart.p); D.pairItems = off(c.pairB.p);
+  for (int i = 0; i < 2; i++) { D.poses[i] = off(c.poses[i].p); D.pts[i] = off(c.pts[i].p); }
+  D.err = off(c.err.p); D.partial = off(c.partial.p); D.Hll = off(c.Hll.p); D.bl = off(c.bl.p); D.Hpl = off(c.Hpl.p);
+  D.BD = off(c.BD.p); D.Hpp = off(c.Hpp.p); D.S = off(c.S.p); D.diagL = off(c.diagL.p); D.diagInv = off(c.diagInv.p);
+  D.Dinv = off(c.Dinv.p); D.db = off(c.db.p); D.xp = off(c.xp.p); D.yv = off(c.yv.p); D.xl = off(c.xl.p);
+  D.scal = off(dScal); D.status = off(dStatus);
   D.cam = J.run->cam; D.dM = J.O.delta_mono; D.dSt = J.O.delta_stereo;
   D.nL = Y.nL; D.nPf = Y.nPf; D.Ea = Y.Ea; D.n = Y.n; D.nb = Y.nb; D.nBlkE = Y.nBlkE; D.nBuckets = Y.nBuckets;
 }
@@ -559,7 +560,7 @@ int solveGroup(BatchPool& B, const YdBaProblem* probs, const YdBaOptions& Oin, Y
     if (r) { fail(j, r); return; }
     if (X.run->sys.Ea == 0) { endStage(j); return; }
     if (X.run->sys.n > kCholSolveMaxN) { set_error("reduced camera system of %d rows is wider than the solve kernel's LDS (max %d)", X.run->sys.n, kCholSolveMaxN); fail(j, YDORB_ERR_UNSUPPORTED); return; }
-    fillDev(X, B.hDev[j], dScalAll + (size_t)8 * j, dStatusAll + (size_t)2 * j);
+    fillDev(X, B.hDev[j], B.dDev.as<BaDev>(), dScalAll + (size_t)8 * j, dStatusAll + (size_t)2 * j);
     if (!(X.it < X.iterations && !X.run->stopped())) { endStage(j); return; }   // `for (it = 0; it < iterations && !terminate(); ...)`
     X.needBuild = true;
   };

@@ -18,12 +18,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #pragma clang fp contract(off)
 
 namespace ydorb {
 
 constexpr int kGridCols = 64, kGridRows = 48, kGridCells = kGridCols * kGridRows;  // frame.hpp:137-138
 constexpr int kHistLen = 30, kThHigh = 100, kThLow = 50;                             // orbMatcher.cpp:7-9
+
+// A pointer that a kernel reads out of a record in memory (CallDev, FrameDev, ...) is a FLAT pointer to the compiler: its loads and
+// stores become flat_* instructions, which count on the LDS counter as well, so every LDS read behind one waits for the memory
+// round trip.  G(p) re-types it as a global-address-space pointer (all these records only ever point into HBM).
+template <class T> using gptr = __attribute__((address_space(1))) T*;
+template <class T> __device__ __forceinline__ gptr<T> G(T* p) { return (gptr<T>)p; }
 
 struct KeyPointDev { float x, y, size, angle, response; int octave, class_id; };
 struct QueryDev {  // == YdQuery
@@ -129,6 +137,9 @@ struct CallDev {          // one search call (one target frame, one ordered quer
   int orbDist, checkOri;
   float invSigma2[8];     // mode 6: the keyframe's m_v_invScaleFactorSquares
   const KeyPointDev* qkps; // device-resident pair form: the query frame's keypoints (k_queries_from_keypoints builds `queries` from them)
+  uint2* qPre;            // [nq] or null: per query the best / second-best record among the candidates that are free BEFORE the call (gather
+                          // kernel): the ordered resolve takes them as they are unless one of the two was taken by an earlier query
+  int takenClear;         // the taken flags are all zero at the start of the call (device pipeline): the gather need not read them
 };
 __device__ __forceinline__ int call_nq(const CallDev& C) { return C.nqPtr ? *C.nqPtr : C.nq; }
 
@@ -143,6 +154,20 @@ __device__ __forceinline__ int call_nq(const CallDev& C) { return C.nqPtr ? *C.n
 // "dequeue" — and was the whole cost of the first version of this kernel.)
 // The grid cell of (ix, iy) is ix*48+iy, so the cells of one window COLUMN are contiguous in the CSR: the window is
 // nx <= 64 contiguous runs, visited in exactly the reference's (ix, iy, insertion) order.
+// wave-wide unsigned min with DPP (quad_perm xor 1/2, row_half_mirror, row_mirror, row_bcast15/31 -> lane 63): ~8 VALU
+// ops instead of six ds_bpermute round trips; this reduction runs twice per query on the serial resolve path.
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#define YD_DPP_MIN(ctrl, rmask) v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xF, false))
+  YD_DPP_MIN(0xB1, 0xF);   // quad_perm [1,0,3,2]
+  YD_DPP_MIN(0x4E, 0xF);   // quad_perm [2,3,0,1]
+  YD_DPP_MIN(0x141, 0xF);  // row_half_mirror
+  YD_DPP_MIN(0x140, 0xF);  // row_mirror
+  YD_DPP_MIN(0x142, 0xA);  // row_bcast15 into rows 1,3
+  YD_DPP_MIN(0x143, 0xC);  // row_bcast31 into rows 2,3
+#undef YD_DPP_MIN
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 constexpr int kSlot = 64;
 __global__ __launch_bounds__(256) void k_gather_projection(const CallDev* __restrict__ calls, const FrameDev* __restrict__ frames,
                                                            int maxQ, uint32_t* __restrict__ pool, unsigned* __restrict__ poolHeads,
@@ -236,6 +261,8 @@ __global__ __launch_bounds__(256) void k_gather_projection(const CallDev* __rest
         }
         if (ok && need > 0) {
           int written = 0;
+          unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, r1 = 0, r2 = 0;   // this lane's two smallest keys (dist << 23 | record position) and their records
+          const bool pre = C.qPre != nullptr, readTaken = pre && C.taken && !C.takenClear;
           const uint4* qd = reinterpret_cast<const uint4*>(C.qdesc + (size_t)q * 32);
           const uint4 qa = qd[0], qb = qd[1];
           for (int t0 = 0; t0 < total; t0 += 64) {
@@ -249,8 +276,27 @@ __global__ __launch_bounds__(256) void k_gather_projection(const CallDev* __rest
                      __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
             }
             const unsigned long long m = __ballot(pass);
-            if (pass) pool[base + written + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)dist << 16) | (uint32_t)idx;
+            if (pass) {
+              const int wpos = written + __popcll(m & ((1ull << lane) - 1ull));
+              const uint32_t rec = ((uint32_t)dist << 16) | (uint32_t)idx;
+              pool[base + wpos] = rec;
+              if (pre && !(readTaken && C.taken[idx])) {
+                const unsigned key = ((unsigned)dist << 23) | (unsigned)wpos;
+                if (key < k1) { k2 = k1; r2 = r1; k1 = key; r1 = rec; } else if (key < k2) { k2 = key; r2 = rec; }
+              }
+            }
             written += __popcll(m);
+          }
+          if (pre) {   // first minimum and first minimum of the rest over the wave (keys are distinct: the position is part of them)
+            const unsigned b1 = wave_min_u32(k1);
+            const bool own = k1 == b1 && b1 != 0xFFFFFFFFu;
+            const unsigned long long o1 = __ballot(own);
+            const unsigned br = o1 ? (unsigned)__builtin_amdgcn_readlane((int)r1, (int)__builtin_ctzll(o1)) : 0xFFFFFFFFu;
+            if (own) { k1 = k2; r1 = r2; }
+            const unsigned b2 = wave_min_u32(k1);
+            const unsigned long long o2 = __ballot(k1 == b2 && b2 != 0xFFFFFFFFu);
+            const unsigned sr = o2 ? (unsigned)__builtin_amdgcn_readlane((int)r1, (int)__builtin_ctzll(o2)) : 0xFFFFFFFFu;
+            if (lane == 0) C.qPre[q] = make_uint2(o1 ? br : 0xFFFFFFFFu, sr);
           }
           info = make_int2((int)base, written);
         }
@@ -332,19 +378,6 @@ __global__ __launch_bounds__(256) void k_gather_bow(BowCallDev B, uint32_t* __re
 // Phase 2: ordered replay.  best = first minimum over the not-taken candidates in scan order; second = first
 // minimum of the rest — which is exactly what the if / else-if chain at orbMatcher.cpp:44-53 leaves behind.
 // ---------------------------------------------------------------------------------------------------
-// wave-wide unsigned min with DPP (quad_perm xor 1/2, row_half_mirror, row_mirror, row_bcast15/31 -> lane 63): ~8 VALU
-// ops instead of six ds_bpermute round trips; this reduction runs twice per query on the serial resolve path.
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-#define YD_DPP_MIN(ctrl, rmask) v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xF, false))
-  YD_DPP_MIN(0xB1, 0xF);   // quad_perm [1,0,3,2]
-  YD_DPP_MIN(0x4E, 0xF);   // quad_perm [2,3,0,1]
-  YD_DPP_MIN(0x141, 0xF);  // row_half_mirror
-  YD_DPP_MIN(0x140, 0xF);  // row_mirror
-  YD_DPP_MIN(0x142, 0xA);  // row_bcast15 into rows 1,3
-  YD_DPP_MIN(0x143, 0xC);  // row_bcast31 into rows 2,3
-#undef YD_DPP_MIN
-  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
 
 // ---------------------------------------------------------------------------------------------------
 // MapPoint::computeDistinctiveDescriptors (reference src/mapPoint.cpp:191-213), a batch of map points: one wave per point.
@@ -392,24 +425,38 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
   extern __shared__ unsigned takenBits[];  // [takenWords]
   __shared__ int hist[kHistLen];
   __shared__ int3 live[kResolveWindow];    // (query, pool base, record count) of the window's non-empty queries, in order
+  __shared__ uint2 livePre[kResolveWindow]; // their pre-computed (best, second) records (projection family; see CallDev::qPre)
   const int lane = threadIdx.x;
+#ifdef RESOLVE_TIMING
+  long long tclk[6]; tclk[0] = wall_clock64();
+#define RS_CLK(i) tclk[i] = wall_clock64()
+#else
+#define RS_CLK(i) do { } while (0)
+#endif
   const CallDev C = calls[blockIdx.x];
   const int nq = call_nq(C);
   const bool bow = C.mode >= 3 && C.mode <= 5;
   const bool lastWins = C.mode == 5;
-  const KeyPointDev* kps = C.tkps;
+  const auto kps = G(C.tkps);
+  const auto gTaken = G(C.taken);
+  const auto gMatchQ = G(C.matchQ), gAssigned = G(C.assigned), gCount = G(C.count);
+  const auto gQInfo = G(reinterpret_cast<const int*>(C.qInfo));          // (HIP's vector classes cannot be copied out of a typed address space)
+  const auto gQPre = G(reinterpret_cast<const unsigned*>(C.qPre));
+  const auto gQueries = G(C.queries);
+  const auto gQAngle = G(C.qAngle);
   const int n = takenWords * 32;
   for (int w = lane; w < takenWords; w += 64) {
     unsigned bits = 0;
     for (int b = 0; b < 32; b++) {
       const int i = w * 32 + b;
-      if (C.taken && i < n && C.taken[i]) bits |= 1u << b;
+      if (C.taken && i < n && gTaken[i]) bits |= 1u << b;
     }
     takenBits[w] = bits;
   }
   if (lane < kHistLen) hist[lane] = 0;
-  for (int q = lane; q < nq; q += 64) C.matchQ[q] = -1;
+  for (int q = lane; q < nq; q += 64) gMatchQ[q] = -1;
   __syncthreads();
+  RS_CLK(1);
   int matchNum = 0;
   for (int w0 = 0; w0 < nq; w0 += kResolveWindow) {
     // stage the window's non-empty queries (ordered ballot compaction): the serial loop then touches LDS only
@@ -417,25 +464,58 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
     for (int q0 = w0; q0 < min(nq, w0 + kResolveWindow); q0 += 64) {
       const int q = q0 + lane;
       int2 info = make_int2(0, 0);
-      if (q < nq) info = C.qInfo[q];
+      if (q < nq) info = make_int2(gQInfo[2 * q], gQInfo[2 * q + 1]);
       const unsigned long long m = __ballot(info.y > 0);
-      if (info.y > 0) live[nLive + __popcll(m & ((1ull << lane) - 1ull))] = make_int3(q, info.x, info.y);
+      if (info.y > 0) {
+        const int slot = nLive + __popcll(m & ((1ull << lane) - 1ull));
+        // bit 30 of the query index: an accepted match marks its keypoint as taken (frame.m_v_sptrMapPoints[idx] with observations, :40 /
+        // :103): staged here so that the replay below never waits for a dependent global load
+        const int qflags = bow ? 3 : gQueries[q].flags;
+        live[slot] = make_int3(q | ((qflags & 2) ? (1 << 30) : 0), info.x, info.y);
+        if (C.qPre) livePre[slot] = make_uint2(gQPre[2 * q], gQPre[2 * q + 1]);
+      }
       nLive += __popcll(m);
     }
     __syncthreads();
+#ifdef RESOLVE_TIMING
+    tclk[5] = wall_clock64();
+#endif
+    // The replay proper, in two instantiations: with the gather kernel's pre-computed (best, second) - the projection searches - the
+    // common path runs no wave reduction and waits for no record load.  What is left is ~100 dependent instructions of ONE wave per
+    // query (a lone wave issues one every 4-8 cycles) and three LDS round trips: 0.4 us per query, 0.28 ms per 1000-query frame pair,
+    // measured with in-kernel stamps (-DRESOLVE_TIMING); the pairs of a call run side by side.
+    auto replay = [&](auto preTag) {
+    constexpr bool havePre = decltype(preTag)::value;
+    const bool needSecond = C.mode == 0;
     unsigned recNext = 0;
-    if (nLive > 0 && lane < live[0].z) recNext = pool[live[0].y + lane];
+    if (!havePre && nLive > 0 && lane < live[0].z) recNext = pool[live[0].y + lane];
     for (int e = 0; e < nLive; e++) {
       const int3 L3 = live[e];
-      const int q = L3.x;
+      const int q = L3.x & 0x3FFFFFFF;
+      const bool qObs = (L3.x >> 30) & 1;
+      unsigned best = 0xFFFFFFFFu, second = 0xFFFFFFFFu;  // key = dist(9) << 23 | scan position(23)
+      unsigned bestRec = 0, secondRec = 0;
+      bool reduce = true;
+      if (havePre) {
+        // The gather kernel left the best / second-best record among the candidates that were free before the call.  The free set
+        // only shrinks while the queries are replayed, so they still are the first minimum and the first minimum of the rest unless
+        // an earlier query took one of them: only then the records are reduced again (rare: ~50 of 1000 queries assign anything).
+        const uint2 pr = livePre[e];
+        const bool t1 = pr.x != 0xFFFFFFFFu && ((takenBits[(pr.x & 0xFFFFu) >> 5] >> (pr.x & 31u)) & 1u);
+        const bool t2 = needSecond && pr.y != 0xFFFFFFFFu && ((takenBits[(pr.y & 0xFFFFu) >> 5] >> (pr.y & 31u)) & 1u);
+        if (!t1 && !t2) {
+          reduce = false;
+          if (pr.x != 0xFFFFFFFFu) { best = (pr.x >> 16) << 23; bestRec = pr.x; }
+          if (pr.y != 0xFFFFFFFFu) { second = (pr.y >> 16) << 23; secondRec = pr.y; }
+        }
+      }
       unsigned recFirst = recNext;
-      if (e + 1 < nLive) {  // prefetch the next query's first 64 records while this one is reduced
+      if (!havePre && e + 1 < nLive) {  // prefetch the next query's first 64 records while this one is reduced
         const int3 N3 = live[e + 1];
         recNext = lane < N3.z ? pool[N3.y + lane] : 0u;
       }
-      unsigned best = 0xFFFFFFFFu, second = 0xFFFFFFFFu;  // key = dist(9) << 23 | scan position(23)
-      unsigned bestRec = 0, secondRec = 0;
-      for (int t0 = 0; t0 < L3.z; t0 += 64) {
+      if (havePre && reduce && lane < L3.z) recFirst = pool[L3.y + lane];
+      for (int t0 = 0; reduce && t0 < L3.z; t0 += 64) {
         const int t = t0 + lane;
         unsigned key = 0xFFFFFFFFu, rec = 0;
         if (t < L3.z) {
@@ -473,35 +553,38 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
         if (accept) {
           matchNum++;
           if (lane == 0) {
-            const int qflags = bow ? 3 : C.queries[q].flags;
-            if (C.mode == 4 || C.mode == 5) C.assigned[q] = bestIdx;   // out[firstIdx] = second-keyframe index; q is remapped by the host
-            else C.assigned[bestIdx] = q;
-            const bool nowTaken = C.mode == 6 ? false : C.mode >= 2 ? true : (qflags & 2) != 0;
+            if (C.mode == 4 || C.mode == 5) gAssigned[q] = bestIdx;   // out[firstIdx] = second-keyframe index; q is remapped by the host
+            else gAssigned[bestIdx] = q;
+            const bool nowTaken = C.mode == 6 ? false : C.mode >= 2 ? true : qObs;
             if (nowTaken) takenBits[bestIdx >> 5] |= 1u << (bestIdx & 31);
-            C.matchQ[q] = bestIdx;
+            gMatchQ[q] = bestIdx;
           }
-          __syncthreads();
+          // (one wave per call: LDS accesses of a wave are ordered, so the next query sees the bit; no barrier and no wait for the stores)
+          __builtin_amdgcn_wave_barrier();
         }
       }
     }
+    };
+    if (C.qPre) replay(std::true_type{}); else replay(std::false_type{});
     __syncthreads();
   }
   __threadfence_block();
   __syncthreads();
+  RS_CLK(2);
   // rotation histogram (orbMatcher.cpp:119-153): bin = round((a1 - a2 [+360]) / 30), keep the three largest bins
   if (C.mode != 0 && C.checkOri) {
     const float factor = (float)(1.0 / kHistLen);
     for (int q = lane; q < nq; q += 64) {
-      const int t = C.matchQ[q];
+      const int t = gMatchQ[q];
       if (t < 0) continue;
-      const float a1 = C.qAngle ? C.qAngle[q] : C.queries[q].angle;
+      const float a1 = C.qAngle ? gQAngle[q] : gQueries[q].angle;
       const float a2 = kps[t].angle;
       float rot = __fsub_rn(a1, a2);
       if (rot < 0.0f) rot = (float)((double)rot + 360.0);
       int bin = (int)roundf(__fmul_rn(rot, factor));
       if (bin == kHistLen) bin = 0;
       atomicAdd(&hist[bin], 1);
-      C.matchQ[q] = t | (bin << 24);
+      gMatchQ[q] = t | (bin << 24);
     }
     __syncthreads();
     int i1 = -1, i2 = -1, i3 = -1, max1 = 0, max2 = 0, max3 = 0;
@@ -515,11 +598,11 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
     else if (max3 < max1 / 10) { i3 = -1; }
     int culled = 0;
     for (int q = lane; q < nq; q += 64) {
-      const int v = C.matchQ[q];
+      const int v = gMatchQ[q];
       if (v < 0) continue;
       const int bin = v >> 24, t = v & 0xFFFFFF;
       if (bin != i1 && bin != i2 && bin != i3) {
-        if (C.mode == 4 || C.mode == 5) C.assigned[q] = -1; else C.assigned[t] = -1;
+        if (C.mode == 4 || C.mode == 5) gAssigned[q] = -1; else gAssigned[t] = -1;
         culled++;
       }
     }
@@ -528,12 +611,18 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
     matchNum -= culled;
   }
   __syncthreads();
+  RS_CLK(3);
   if (C.taken)
     for (int i = lane; i < n; i += 64) {
       const int w = i >> 5;
-      if (w < takenWords) C.taken[i] = (takenBits[w] >> (i & 31)) & 1u;
+      if (w < takenWords) gTaken[i] = (takenBits[w] >> (i & 31)) & 1u;
     }
-  if (lane == 0) *C.count = matchNum;
+  if (lane == 0) *gCount = matchNum;
+#ifdef RESOLVE_TIMING
+  RS_CLK(4);
+  if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) printf("resolve blk %d: init %.1f us, staging %.1f us, loop %.1f us, histogram %.1f us, tail %.1f us (nq %d, matches %d)\n", (int)blockIdx.x,
+      (tclk[1] - tclk[0]) / 100.0, (tclk[5] - tclk[1]) / 100.0 + 1000 * 0 + 0.0 * (tclk[2] - tclk[1]) + (tclk[2] - tclk[5]) / 100.0 * 0 + 0, (tclk[2] - tclk[5]) / 100.0, (tclk[3] - tclk[2]) / 100.0, (tclk[4] - tclk[3]) / 100.0, nq, matchNum);
+#endif
 }
 
 // queries for the device-resident consecutive-frame search (bench / streaming pipeline): the "projection" of a

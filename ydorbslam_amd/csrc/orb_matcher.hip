@@ -71,7 +71,7 @@ const char* kMatchStageNames[MS_COUNT] = {"grid_build", "gather_distances", "res
 struct ydorb_matcher {
   int device = 0;
   hipStream_t stream = nullptr;
-  Buf kps, desc, rightX, queries, qdesc, taken, assigned, matchQ, qInfo, cellStart, cellIdx, pool, frames, calls, misc, kps2,
+  Buf kps, desc, rightX, queries, qdesc, taken, assigned, matchQ, qInfo, qPre, cellStart, cellIdx, pool, frames, calls, misc, kps2,
       desc2, feat, valid, qFeat, qRange, qAngle, sf, heads, sortedKp, sortedDesc, kps1, good1, good2, stereoPar, stereoCnt, stereoOut;
   size_t poolRecords = 1u << 20;
   // cached descriptors of the last batched launch (re-uploaded only when they change)
@@ -171,7 +171,7 @@ void ydorb_matcher_destroy(ydorb_matcher_t* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   (void)hipStreamSynchronize(m->stream);
-  for (Buf* b : {&m->kps, &m->desc, &m->rightX, &m->queries, &m->qdesc, &m->taken, &m->assigned, &m->matchQ, &m->qInfo, &m->cellStart,
+  for (Buf* b : {&m->kps, &m->desc, &m->rightX, &m->queries, &m->qdesc, &m->taken, &m->assigned, &m->matchQ, &m->qInfo, &m->qPre, &m->cellStart,
                  &m->cellIdx, &m->pool, &m->frames, &m->calls, &m->misc, &m->kps2, &m->desc2, &m->feat, &m->valid, &m->qFeat, &m->qRange,
                  &m->qAngle, &m->sf, &m->heads, &m->sortedKp, &m->sortedDesc, &m->kps1, &m->good1, &m->good2, &m->stereoPar, &m->stereoCnt,
                  &m->stereoOut})
@@ -243,6 +243,7 @@ static int searchProjectionImpl(ydorb_matcher_t* m, int32_t mode, const YdFrameV
     if ((rc = uploadFrame(m, fv, &F))) return rc;
     if ((rc = m->queries.ensure(sizeof(YdQuery) * nq)) || (rc = m->qdesc.ensure((size_t)32 * nq)) || (rc = m->taken.ensure(n)) ||
         (rc = m->assigned.ensure(sizeof(int) * n)) || (rc = m->matchQ.ensure(sizeof(int) * nq)) || (rc = m->qInfo.ensure(sizeof(int2) * nq)) ||
+        (rc = m->qPre.ensure(sizeof(uint2) * nq)) ||
         (rc = m->pool.ensure(sizeof(uint32_t) * ((size_t)nq * kSlot + m->poolRecords))) || (rc = m->calls.ensure(sizeof(CallDev))) || (rc = resetMisc(m, m->stream)))
       return rc;
     HIPCHK(hipMemcpyAsync(m->queries.p, queries, sizeof(YdQuery) * nq, hipMemcpyHostToDevice, m->stream));
@@ -254,6 +255,7 @@ static int searchProjectionImpl(ydorb_matcher_t* m, int32_t mode, const YdFrameV
     C.frame = 0; C.tkps = F.kps; C.qAngle = nullptr;
     C.queries = m->queries.as<QueryDev>(); C.qdesc = m->qdesc.as<uint8_t>(); C.nqPtr = nullptr; C.nq = nq;
     C.qInfo = m->qInfo.as<int2>(); C.taken = m->taken.as<uint8_t>(); C.assigned = m->assigned.as<int>(); C.matchQ = m->matchQ.as<int>();
+    C.qPre = m->qPre.as<uint2>(); C.takenClear = taken ? 0 : 1;
     C.count = m->misc.as<int>() + 2; C.mode = mode; C.ratio = ratio; C.orbDist = orbDist; C.checkOri = checkOri;
     for (int i = 0; i < 8; i++) C.invSigma2[i] = (invSigma2 && i < nLevels) ? invSigma2[i] : 0.f;
     HIPCHK(hipMemcpyAsync(m->calls.p, &C, sizeof(CallDev), hipMemcpyHostToDevice, m->stream));
@@ -643,6 +645,7 @@ int ydorb_match_pairs_device(ydorb_matcher_t* m, const YdFrameSetDev* Q, const Y
   int rc;
   if ((rc = m->queries.ensure(sizeof(QueryDev) * (size_t)cap * nCalls)) || (rc = m->taken.ensure((size_t)cap * nCalls)) ||
       (rc = m->matchQ.ensure(sizeof(int) * (size_t)cap * nCalls)) || (rc = m->qInfo.ensure(sizeof(int2) * (size_t)cap * nCalls)) ||
+      (rc = m->qPre.ensure(sizeof(uint2) * (size_t)cap * nCalls)) ||
       (rc = m->cellStart.ensure(sizeof(int) * (size_t)(kGridCells + 1) * nFrames)) || (rc = m->cellIdx.ensure(sizeof(int) * (size_t)cap * nFrames)) ||
       (rc = m->pool.ensure(sizeof(uint32_t) * poolPerCall * nCalls)) || (rc = m->frames.ensure(sizeof(FrameDev) * nFrames)) ||
       (rc = m->calls.ensure(sizeof(CallDev) * nCalls)) || (rc = m->sf.ensure(sizeof(float) * 8 + sizeof(float) * 6 * nCalls)) || (rc = m->misc.ensure(64)) ||
@@ -667,6 +670,7 @@ int ydorb_match_pairs_device(ydorb_matcher_t* m, const YdFrameSetDev* Q, const Y
     C.frame = tf; C.tkps = hf[tf].kps; C.qAngle = nullptr; C.queries = m->queries.as<QueryDev>() + (size_t)c * cap;
     C.qkps = reinterpret_cast<const KeyPointDev*>(Q->d_kps) + (size_t)qf * cap;
     C.qdesc = Q->d_desc + (size_t)qf * cap * 32; C.nqPtr = Q->d_n + qf; C.nq = 0; C.qInfo = m->qInfo.as<int2>() + (size_t)c * cap;
+    C.qPre = m->qPre.as<uint2>() + (size_t)c * cap; C.takenClear = 1;
     C.taken = m->taken.as<uint8_t>() + (size_t)c * cap; C.assigned = d_assigned + (size_t)c * cap; C.matchQ = m->matchQ.as<int>() + (size_t)c * cap;
     C.count = d_counts + c; C.mode = 1; C.ratio = 0.9f; C.orbDist = 0; C.checkOri = checkOri;
     hc[c] = C;
