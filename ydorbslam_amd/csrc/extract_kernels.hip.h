@@ -70,7 +70,7 @@ typedef unsigned long long __attribute__((aligned(1))) u64_unaligned;
 // Workgroup = 64 x 4 threads; a thread writes one dword (4 px) in each of kPyrRows consecutive rows, so a workgroup covers
 // 256 B x 16 rows and the per-column tables are loaded once per thread (one-row workgroups were dispatch-bound).
 #ifndef PYR_ROWS
-#define PYR_ROWS 4
+#define PYR_ROWS 8
 #endif
 constexpr int kPyrRows = PYR_ROWS;
 // The level kernels write INTERIOR rows only, one dword per thread and row, every lane on the same (fast) path: a dword that
