@@ -573,7 +573,7 @@ def main():
                         "algorithmic_bytes_per_image": A_,
                         "pipeline_frac_of_hbm_peak": A_ * 2 * n_pairs / (res["extract_stereo_match"]["ms_per_step"] * 1e-3) / HBM_PEAK})
             return res
-        out["config3"] = stereo_config(1241, 376, 2000, 64, "KITTI-00-size 1241x376 stereo, 2000 feat/image: extract L+R, computeStereoMatches (as the reference writes it), consecutive left-frame search")
+        out["config3"] = stereo_config(1241, 376, 2000, 128, "KITTI-00-size 1241x376 stereo, 2000 feat/image: extract L+R, computeStereoMatches (as the reference writes it), consecutive left-frame search")
         out["config4"] = stereo_config(752, 480, 1000, 64, "EuRoC-MH-size 752x480 stereo batch, 1000 feat/image, one GPU's share: extract L+R, computeStereoMatches, consecutive left-frame search")
 
     # ---- brute-force N x M Hamming top-2 (north_star; SURVEY 8d secondary figure, against the integer-VALU peak) -------------------
