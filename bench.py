@@ -480,6 +480,9 @@ def main():
         h_assigned = torch.zeros((NPAIR, cap), dtype=torch.int32).pin_memory()
         h_counts = torch.zeros(NPAIR, dtype=torch.int32).pin_memory()
         p_img = torch.zeros_like(d_img)
+        # two handles of their own, alternating over the chunks: the copy of chunk c+1 and the extraction of chunk c overlap
+        pexs = [y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=cf) for _ in range(2)]
+        psts = [torch.cuda.Stream(device=dev) for _ in range(2)]
         s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
         ev_in = [torch.cuda.Event() for _ in range(CH)]
         ev_ex = [torch.cuda.Event() for _ in range(CH)]
@@ -490,10 +493,10 @@ def main():
                 with torch.cuda.stream(s_in):
                     p_img[a_:b_].copy_(h_img[a_:b_], non_blocking=True)
                     ev_in[c].record(s_in)
-                sA = sAs[c % NEX]
+                sA = psts[c % 2]
                 sA.wait_event(ev_in[c])
-                exs[c % NEX].extract_batch_device(p_img[a_].data_ptr(), W, H, W, W * H, cf, d_kps[0][a_].data_ptr(), d_desc[0][a_].data_ptr(), cap,
-                                                  d_n[0][a_:].data_ptr(), sA.cuda_stream)
+                pexs[c % 2].extract_batch_device(p_img[a_].data_ptr(), W, H, W, W * H, cf, d_kps[0][a_].data_ptr(), d_desc[0][a_].data_ptr(), cap,
+                                                 d_n[0][a_:].data_ptr(), sA.cuda_stream)
                 ev_ex[c].record(sA)
                 with torch.cuda.stream(s_out):
                     s_out.wait_event(ev_ex[c])
@@ -505,7 +508,7 @@ def main():
             with torch.cuda.stream(sB):
                 h_assigned.copy_(d_assigned[0], non_blocking=True)
                 h_counts.copy_(d_counts[0], non_blocking=True)
-        if F % CH == 0 and cf <= FL:
+        if F % CH == 0:
             pcie_step(); torch.cuda.synchronize()
             n_p = max(args.steps // 2, 3)
             tp = time.perf_counter()
@@ -518,7 +521,7 @@ def main():
                                      "host_to_device_MB_per_step": bytes_in / 1e6, "device_to_host_MB_per_step": bytes_out / 1e6,
                                      "note": "pinned host frames -> H2D on a copy stream (%d chunks per step, overlapped with the extraction of the previous chunk) -> extract -> "
                                              "match -> keypoints, descriptors, counts and match lists back to pinned host memory; never the headline value" % CH}
-        del h_img, h_kps, h_desc, h_assigned, p_img
+        del h_img, h_kps, h_desc, h_assigned, p_img, pexs
 
     # ---- configs 3 and 4: stereo streams (extract L + R, computeStereoMatches, consecutive left-frame search) ----------------------
     if extras:

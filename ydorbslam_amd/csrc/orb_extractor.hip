@@ -545,7 +545,10 @@ int ydorb_extractor_create(const YdExtractorConfig* cfg, ydorb_extractor_t** out
     // hardware queues; with one stream per level (8 + the handle's own + the caller's matcher stream) streams share queues and the
     // kernels of streams on one queue run one after the other.  Measured on the 512-frame pipeline with one handle: 8 side streams
     // 157 Mkeypoints/s, 4: 160, 2: 163, 1: 151 (the level-0 unit no longer overlaps the small levels).
-    static const int nQt = [] { const char* v = getenv("YDORB_QT_STREAMS"); const int n = v ? atoi(v) : 2; return std::max(1, std::min(n, (int)kMaxLevels)); }();
+    // A handle for single frames (max_batch <= 8: the adapter's use) keeps one stream per level: its launches are latency bound and the
+    // eight units of a frame then run side by side (0.27 ms per extractAndCompute against 0.33 ms with two).
+    const char* qtEnv = getenv("YDORB_QT_STREAMS");
+    const int nQt = std::max(1, std::min(qtEnv ? atoi(qtEnv) : (cfg->max_batch <= 8 ? (int)kMaxLevels : 2), (int)kMaxLevels));
     if (l < nQt) (void)hipStreamCreateWithFlags(&e->qtStream[l], hipStreamNonBlocking);
     else e->qtStream[l] = e->qtStream[l % nQt];
     (void)hipEventCreateWithFlags(&e->evJoin[l], hipEventDisableTiming);
