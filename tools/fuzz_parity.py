@@ -104,10 +104,16 @@ while time.time() - t0 < budget:
         n_bw += 1
     # ---- BA + pose
     if rng.random() < 0.3:
-        prob = synth_ba_problem(int(rng.integers(3, 40)), int(rng.integers(30, 1500)), int(rng.integers(2, 8)), seed=int(rng.integers(0, 1 << 30)),
-                                outlier_frac=float(rng.choice([0, 0.05, 0.2])), mono_frac=float(rng.choice([0, 0.3, 1.0])), n_fixed=int(rng.integers(1, 3)))
+        n_obs, mono = int(rng.integers(2, 8)), float(rng.choice([0, 0.3, 1.0]))
+        prob = synth_ba_problem(int(rng.integers(3, 40)), int(rng.integers(30, 1500)), n_obs, seed=int(rng.integers(0, 1 << 30)),
+                                outlier_frac=float(rng.choice([0, 0.05, 0.2])), mono_frac=mono, n_fixed=int(rng.integers(1, 3)))
         r = oo.ba_solve(prob); p = y.Optimizer.local_bundle_adjust(prob)
-        assert np.array_equal(p["outlier"], r["outlier"]) and len(p["log"]) == len(r["log"]) and np.allclose(p["log"][:, 0], r["log"][:, 0], rtol=1e-6), "ba"
+        # Two monocular observations per point leave the problem barely constrained: chi2 falls to ~1e-25 and the accept / reject
+        # sequence of the LM trials depends on the last bits of the sums (3 of 6383 such problems differed from the oracle's sequence
+        # in tools/fuzz_ba.py, with the pre-MFMA Cholesky as well); there only the outlier list and the float poses are compared.
+        if not (n_obs == 2 and mono == 1.0):
+            assert len(p["log"]) == len(r["log"]) and np.allclose(p["log"][:, 0], r["log"][:, 0], rtol=1e-6), "ba chi2"
+        assert np.array_equal(p["outlier"], r["outlier"]), "ba"
         assert np.allclose(p["poses"].astype(np.float32), r["poses"].astype(np.float32), rtol=1e-4, atol=1e-6), "ba poses"
         n_ba += 1
         pp = [synth_pose_problem(int(rng.integers(3, 1500)), seed=int(rng.integers(0, 1 << 30)), outlier_frac=float(rng.choice([0, 0.1, 0.4])),
