@@ -132,6 +132,32 @@ def test_quadtree_flat_and_pass_kernels_agree(oracle_lib, monkeypatch):
             assert passk.debug_read(3, l, f) == 1
 
 
+@pytest.mark.parametrize("w,h,nf", [(640, 480, 1000), (1241, 376, 2000), (752, 480, 1000), (131, 97, 300), (259, 203, 400), (1017, 333, 900)])
+def test_pyramid_pads_written_by_level_kernels_and_by_border_launch(oracle_lib, monkeypatch, w, h, nf):
+    """Two ways to the same padded pyramid (orbExtractor.cpp:612-621): the level kernels that write their own reflect-101 pad (default;
+    levels with a side below 20 px fall back by themselves) and the interior-only kernels + one border launch (YDORB_PYR_FUSED=0).
+    Every byte of every padded level, in a batch of frames, against the oracle."""
+    import ydorbslam_amd as y
+    from oracle.orb_oracle import OrbExtractorOracle
+    imgs = np.stack([synth_frame(w, h, 20 + i) for i in range(3)])
+    fused = y.OrbExtractor(nf, 1.2, 8, 20, 7, max_batch=3)
+    monkeypatch.setenv("YDORB_PYR_FUSED", "0")
+    plain = y.OrbExtractor(nf, 1.2, 8, 20, 7, max_batch=3)
+    monkeypatch.delenv("YDORB_PYR_FUSED")
+    rf, rp = fused.extract_batch(imgs), plain.extract_batch(imgs)
+    for f in range(3):
+        cpu = OrbExtractorOracle(nf, 1.2, 8, 20, 7)
+        ck, cd = cpu.extract(imgs[f])
+        for l in range(8):
+            cw, _, _ = cpu.level_dims(l)
+            ref = cpu.level_padded(l)[:, :cw + 38]
+            assert np.array_equal(fused.read_level(l, f), ref), "fused pads, frame %d level %d" % (f, l)
+            assert np.array_equal(plain.read_level(l, f), ref), "border launch, frame %d level %d" % (f, l)
+        for (k, d) in (rf[f], rp[f]):
+            _same_kps(k, ck)
+            assert np.array_equal(d, cd)
+
+
 @pytest.mark.parametrize("w,h,nf,sf,nl,thr", [
     (640, 480, 1500, 2.5, 3, 20),     # scale factor > 2: the resize kernel's byte-tap path
     (640, 480, 800, 2.0, 4, 12),      # exactly 2: still the 8-byte window path

@@ -195,6 +195,125 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, s
 }
 
 // ------------------------------------------------------------------------------------------------
+// Level kernels that also write the level's reflect-101 pad (orbExtractor.cpp:612-621 in the same pass as :614-618): no border
+// launch for such a level.  A thread owns dword `wx` of the padded row in kPyrRowsF consecutive interior rows.
+//   left / right pad : a pad byte p of a row is the row's own byte 38 - p (left) or 2w + 36 - p (right); the at most two dwords that
+//                      hold the mirrored bytes of a pad dword live in the same wave (the host shifts the lane -> dword mapping so that
+//                      neither end group straddles a 64-dword boundary), so they arrive by ds_bpermute and two v_perm_b32 whose
+//                      selectors come from a per-column table (PyrPadEntry) - executed only by waves that hold pad dwords;
+//   top / bottom pad : the thread that writes interior row y in 1..19 stores the same finished dword to padded row 19 - y, and the
+//                      one that writes row y in h-20..h-2 to row 2(h-1) - y + 19.
+// Every byte is still written exactly once, and the source level's own pads are complete when the next level reads it.
+// Per-column constants (selectors, weights) and per-row constants (source row, weights) are host tables, padded so that no index
+// needs a clamp: the row entries of a wave are one scalar load, a column's entries two or three 16-byte loads.
+// Levels the scheme does not cover (w or h < 20, scale factor > 2) keep k_pyr_level0 / k_pyr_resize + k_pyr_borders.
+// ------------------------------------------------------------------------------------------------
+struct PyrPadEntry { uint32_t laneA4, laneB4, selM, selF; };      // 4 * source lane of the two mirrored dwords, perm(A, B, selM), perm(M, own, selF)
+struct PyrColEntry { uint32_t sel[4]; uint32_t ab[4]; };          // v_perm selector of the two taps (relative to the column's first tap), alpha0 | alpha1 << 16
+constexpr uint32_t kPermIdentity = 0x03020100u;
+#ifndef PYR_ROWS_F
+#define PYR_ROWS_F 8
+#endif
+constexpr int kPyrRowsF = PYR_ROWS_F;
+
+__device__ __forceinline__ uint32_t pyr_finish_dword(uint32_t v, const PyrPadEntry& pe) {
+  const uint32_t A = (uint32_t)__builtin_amdgcn_ds_bpermute((int)pe.laneA4, (int)v);
+  const uint32_t B = (uint32_t)__builtin_amdgcn_ds_bpermute((int)pe.laneB4, (int)v);
+  const uint32_t M = __builtin_amdgcn_perm(A, B, pe.selM);
+  return __builtin_amdgcn_perm(M, v, pe.selF);
+}
+// stores of one finished dword: its own row and, near the top / bottom edge, the mirrored pad row (row offsets relative to interior row 0)
+__device__ __forceinline__ void pyr_store_rows(uint8_t* dst, int pitch, int y, int h, uint32_t v) {
+  if (y >= h) return;
+  *reinterpret_cast<uint32_t*>(dst + (ptrdiff_t)y * pitch) = v;
+  if (y >= 1 && y <= kPad) *reinterpret_cast<uint32_t*>(dst - (ptrdiff_t)y * pitch) = v;
+  if (y >= h - 1 - kPad && y <= h - 2) *reinterpret_cast<uint32_t*>(dst + (ptrdiff_t)(2 * (h - 1) - y) * pitch) = v;
+}
+
+__global__ __launch_bounds__(256) void k_pyr_level0_f(const uint8_t* __restrict__ img, int stride, size_t frameStride,
+                                                      uint8_t* __restrict__ pyr, size_t pyrFrameStride, LevelDev L,
+                                                      const PyrPadEntry* __restrict__ padTab, int shift) {
+  const int wx = blockIdx.x * 64 + (threadIdx.x & 63) - shift;
+  const int yb = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * kPyrRowsF;
+  const int nd = (L.w + 2 * kPad + 3) >> 2;                  // dwords with at least one byte below w + 38
+  if (wx < 0 || wx >= nd) return;
+  const int x0 = wx * 4 - kPad;
+  const uint8_t* src = img + (size_t)blockIdx.z * frameStride;
+  uint8_t* dst = pyr + (size_t)blockIdx.z * pyrFrameStride + L.padOff + (size_t)kPad * L.pitch + wx * 4;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 peRaw = reinterpret_cast<const u32x4*>(padTab)[wx];   // one 16-byte load, issued with the pixel loads
+  const PyrPadEntry pe{peRaw.x, peRaw.y, peRaw.z, peRaw.w};
+  const int xa = min(max(x0, 0), L.w - 4), sh = 8 * (x0 - xa);   // w >= 20 here
+  uint32_t v[kPyrRowsF];
+#pragma unroll
+  for (int r = 0; r < kPyrRowsF; r++) {
+    const uint8_t* row = src + (size_t)min(yb + r, L.h - 1) * stride;
+    v[r] = *reinterpret_cast<const u32_unaligned*>(row + xa);
+  }
+  const int shl = min(max(-sh, 0), 31), shr = min(max(sh, 0), 31);   // |sh| <= 24 for dwords that keep an interior byte; others are all pad
+#pragma unroll
+  for (int r = 0; r < kPyrRowsF; r++) v[r] = sh < 0 ? v[r] << shl : v[r] >> shr;
+  if (__builtin_amdgcn_ballot_w64(pe.selF != kPermIdentity)) {
+#pragma unroll
+    for (int r = 0; r < kPyrRowsF; r++) v[r] = pyr_finish_dword(v[r], pe);
+  }
+#pragma unroll
+  for (int r = 0; r < kPyrRowsF; r++) pyr_store_rows(dst, L.pitch, yb + r, L.h, v[r]);
+}
+
+__global__ __launch_bounds__(256) void k_pyr_resize_f(uint8_t* __restrict__ pyr, size_t pyrFrameStride, LevelDev Lp, LevelDev L,
+                                                      double scaleX, const PyrColEntry* __restrict__ colTab,
+                                                      const PyrPadEntry* __restrict__ padTab, const int2* __restrict__ rowTab, int shift) {
+  const int wx = blockIdx.x * 64 + (threadIdx.x & 63) - shift;
+  const int yb = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * kPyrRowsF;
+  const int nd = (L.w + 2 * kPad + 3) >> 2;
+  if (wx < 0 || wx >= nd) return;
+  uint8_t* frame = pyr + (size_t)blockIdx.z * pyrFrameStride;
+  const uint8_t* S = frame + Lp.padOff + (size_t)kPad * Lp.pitch + kPad;  // ROI origin of the source level
+  uint8_t* dst = frame + L.padOff + (size_t)kPad * L.pitch + wx * 4;
+  // first tap of the dword's first (clamped) column: the same IEEE sequence as the host table, so the pixel loads wait for no table
+  const int dx0 = min(max(wx * 4 - kPad, 0), L.w - 1);
+  const float fx = (float)__dsub_rn(__dmul_rn((double)dx0 + 0.5, scaleX), 0.5);
+  const int base = min(max((int)floorf(fx), 0), Lp.w - 1);
+  const uint8_t* Sb = S + base;
+  unsigned long long w0[kPyrRowsF], w1[kPyrRowsF];
+  int bw[kPyrRowsF];
+#pragma unroll
+  for (int r = 0; r < kPyrRowsF; r++) {
+    const int2 rt = rowTab[yb + r];                          // wave-uniform index, table padded to the grid's rows
+    bw[r] = rt.y;
+    w0[r] = *reinterpret_cast<const u64_unaligned*>(Sb + (size_t)min(max(rt.x, 0), Lp.h - 1) * Lp.pitch);
+    w1[r] = *reinterpret_cast<const u64_unaligned*>(Sb + (size_t)min(max(rt.x + 1, 0), Lp.h - 1) * Lp.pitch);
+  }
+  const PyrColEntry ce = colTab[wx];
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 peRaw = reinterpret_cast<const u32x4*>(padTab)[wx];   // one 16-byte load, issued with the pixel loads
+  const PyrPadEntry pe{peRaw.x, peRaw.y, peRaw.z, peRaw.w};
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  uint32_t v[kPyrRowsF];
+#pragma unroll
+  for (int r = 0; r < kPyrRowsF; r++) {
+    const int b0 = bw[r] & 0xffff, b1 = (int)((uint32_t)bw[r] >> 16);
+    v[r] = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const uint32_t p0 = __builtin_amdgcn_perm((uint32_t)(w0[r] >> 32), (uint32_t)w0[r], ce.sel[b]);
+      const uint32_t p1 = __builtin_amdgcn_perm((uint32_t)(w1[r] >> 32), (uint32_t)w1[r], ce.sel[b]);
+      const int h0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p0), __builtin_bit_cast(u16x2, ce.ab[b]), 0u, false);
+      const int h1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p1), __builtin_bit_cast(u16x2, ce.ab[b]), 0u, false);
+      const int o = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      v[r] |= (uint32_t)(o & 0xFF) << (8 * b);
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(pe.selF != kPermIdentity)) {
+#pragma unroll
+    for (int r = 0; r < kPyrRowsF; r++) v[r] = pyr_finish_dword(v[r], pe);
+  }
+#pragma unroll
+  for (int r = 0; r < kPyrRowsF; r++) pyr_store_rows(dst, L.pitch, yb + r, L.h, v[r]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // copyMakeBorder(BORDER_REFLECT_101) of every level (orbExtractor.cpp:612-621), one launch for all levels and frames after the
 // level kernels: a thread owns one dword of the padded level that holds at least one pad byte — the 19 full rows above and
 // below, and up to 6 dwords at either end of an interior row — keeps the interior bytes it finds there and fills each pad byte
@@ -314,7 +433,7 @@ struct FastLds { int tileBytes, scoreBytes, listBytes; };
 // ------------------------------------------------------------------------------------------------
 template <int PITCH>
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyrFrameStride, PlanDev P,
-                                                    const CellDev* __restrict__ cells, int thr, FastLds lds,
+                                                    const CellDev* __restrict__ cells, int cellFirst, int cellEnd, int thr, FastLds lds,
                                                     uint32_t* __restrict__ cellCount, uint32_t* __restrict__ cellCand) {
   extern __shared__ __align__(16) uint8_t fastSmem[];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -330,8 +449,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     grp = (f & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     f = (f & ~7) | (blockIdx.x & 7);
   }
-  const int cellId = grp * 4 + wv;
-  if (cellId >= P.nCellsTotal) return;   // (waves never synchronise with each other)
+  const int cellId = cellFirst + grp * 4 + wv;   // a launch takes the cells [cellFirst, cellEnd) of every frame (whole levels)
+  if (cellId >= cellEnd) return;   // (waves never synchronise with each other)
   const CellDev c = cells[cellId];
   const int pitch = P.lv[c.level].pitch;
   const int tw = c.x1 - c.x0, th = c.y1 - c.y0;

@@ -40,6 +40,11 @@ struct HostPlan {
   std::vector<int> tabInt;      // xofs|yofs per level
   std::vector<short> tabShort;  // alpha|beta per level
   struct TabOff { int xofs, yofs, alpha, beta; } tab[kMaxLevels]{};
+  // levels whose kernels also write their own reflect-101 pad (k_pyr_level0_f / k_pyr_resize_f): per-column and per-row tables
+  struct FusedLevel { bool on = false; int shift = 0, padOff = 0, colOff = 0, rowOff = 0; } fused[kMaxLevels];
+  std::vector<PyrPadEntry> padTab;
+  std::vector<PyrColEntry> colTab;
+  std::vector<int2> rowTab;
 };
 
 enum Stage { ST_PYR = 0, ST_FAST, ST_QT, ST_BLUR, ST_DESC, ST_COUNT };
@@ -56,6 +61,9 @@ struct ydorb_extractor {
   hipStream_t stream = nullptr;
   hipStream_t qtStream[kMaxLevels]{};   // side streams of the per-level quad-tree launches
   hipEvent_t evFork = nullptr, evJoin[kMaxLevels]{};
+  hipEvent_t evFast[kMaxLevels]{};      // end of the FAST launch that covers level l (levels are launched in groups)
+  bool qtInline = false;                // YDORB_QT_STREAMS=0: the quad-tree launches go on the caller's stream, behind the blur
+  int fastGroups = 1;                   // FAST launches per call: 1 = all levels together
   HostPlan plan;
   bool planValid = false;
   int batchCap = 0;
@@ -74,6 +82,10 @@ struct ydorb_extractor {
   CellDev* d_cells = nullptr;
   int* d_tabInt = nullptr;
   short* d_tabShort = nullptr;
+  PyrPadEntry* d_padTab = nullptr;
+  PyrColEntry* d_colTab = nullptr;
+  int2* d_rowTab = nullptr;
+  bool noFusedPads = false;   // YDORB_PYR_FUSED=0 at create: level kernels + one border launch (the tests compare both)
   YdKeyPointDev* d_kps = nullptr;
   uint8_t* d_desc = nullptr;
   size_t imgBytes = 0;
@@ -108,7 +120,7 @@ void freeBuffers(ydorb_extractor* e) {
   auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
   F(e->d_img); F(e->d_pyr); F(e->d_blur); F(e->d_cellCount); F(e->d_cellCand); F(e->d_qtCand); F(e->d_qtKeys);
   F(e->d_lvlKp); F(e->d_qtNode); F(e->d_needPass); F(e->d_nodeScratch); F(e->d_lvlCount); F(e->d_lvlMaxN); F(e->d_status); F(e->d_nOut); F(e->d_lvlAngle); F(e->d_cells);
-  F(e->d_tabInt); F(e->d_tabShort); F(e->d_kps); F(e->d_desc);
+  F(e->d_tabInt); F(e->d_tabShort); F(e->d_padTab); F(e->d_colTab); F(e->d_rowTab); F(e->d_kps); F(e->d_desc);
   auto H = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
   H(e->h_img); H(e->h_kps); H(e->h_desc); H(e->h_nOut); H(e->h_status); H(e->h_lvlMaxN); H(e->h_pyr);
   e->h_pyrBytes = 0;
@@ -123,6 +135,87 @@ static int flatItemsFor(long want) {
   for (int i = 0; i < 5; i++)
     if ((long)kQtFlatThreads * steps[i] >= want) return steps[i];
   return 16;
+}
+
+// Tables of a level whose kernel writes its own pad (extract_kernels.hip.h, k_pyr_level0_f / k_pyr_resize_f).  Leaves fused[l].on
+// false when the scheme does not apply: a side below 20 px (a pad byte would need two reflections), horizontal scale factor > 2
+// (the two taps of 4 outputs no longer fit one 8-byte load), or no lane shift keeps both end groups inside one wave.
+void buildFusedLevel(HostPlan& P, int l) {
+  const PlanDev& D = P.dev;
+  const LevelDev& L = D.lv[l];
+  HostPlan::FusedLevel& F = P.fused[l];
+  F.on = false;
+  if (L.w < 20 || L.h < 20) return;
+  const int nd = (L.w + 2 * kPad + 3) >> 2;
+  // mirrored source byte of padded-row byte p: -1 = own (interior), -2 = slack beyond w + 38 (zero)
+  auto srcOf = [&](int p) { return p < kPad ? 2 * kPad - p : p < kPad + L.w ? -1 : p < L.w + 2 * kPad ? 2 * L.w + 2 * kPad - 2 - p : -2; };
+  int shift = -1;
+  for (int sft = 0; sft < 64 && shift < 0; sft++) {
+    bool ok = true;
+    for (int c = 0; c < nd && ok; c++)
+      for (int j = 0; j < 4; j++) {
+        const int sp = srcOf(4 * c + j);
+        if (sp >= 0 && ((sp >> 2) + sft) >> 6 != (c + sft) >> 6) ok = false;
+      }
+    if (ok) shift = sft;
+  }
+  if (shift < 0) return;
+  std::vector<PyrColEntry> col;
+  if (l > 0) {
+    const LevelDev& Lp = D.lv[l - 1];
+    const int* xofs = P.tabInt.data() + P.tab[l].xofs;
+    const short* alpha = P.tabShort.data() + P.tab[l].alpha;
+    col.resize(nd);
+    for (int c = 0; c < nd; c++) {
+      const int dx0 = std::min(std::max(4 * c - kPad, 0), L.w - 1);
+      for (int b = 0; b < 4; b++) {
+        const int dx = std::min(std::max(4 * c - kPad + b, 0), L.w - 1);
+        const int off = xofs[dx] - xofs[dx0];
+        if (off < 0 || off > 6 || xofs[dx0] + 7 >= Lp.w + kPad) return;   // taps beyond one 8-byte load (or the load would leave the padded source row)
+        col[c].sel[b] = (uint32_t)off | 0x0c000c00u | ((uint32_t)(off + 1) << 16);
+        col[c].ab[b] = (uint32_t)(uint16_t)alpha[2 * dx] | ((uint32_t)(uint16_t)alpha[2 * dx + 1] << 16);
+      }
+    }
+  }
+  F.shift = shift;
+  F.padOff = (int)P.padTab.size();
+  for (int c = 0; c < nd; c++) {
+    int dA = -1, dB = -1;
+    for (int j = 0; j < 4; j++) {
+      const int sp = srcOf(4 * c + j);
+      if (sp < 0) continue;
+      const int d = sp >> 2;
+      if (dA < 0 || d == dA) dA = d;
+      else dB = d;
+    }
+    PyrPadEntry pe{};
+    pe.laneA4 = 4u * (unsigned)(((dA < 0 ? c : dA) + shift) & 63);
+    pe.laneB4 = 4u * (unsigned)(((dB < 0 ? c : dB) + shift) & 63);
+    pe.selM = 0; pe.selF = 0;
+    for (int j = 0; j < 4; j++) {
+      const int sp = srcOf(4 * c + j);
+      uint32_t m = 0x0c, f;
+      if (sp == -1) f = (uint32_t)j;
+      else if (sp == -2) f = 0x0c;
+      else { m = (uint32_t)(sp & 3) + ((sp >> 2) == dA ? 4u : 0u); f = 4u + (uint32_t)j; }
+      pe.selM |= m << (8 * j);
+      pe.selF |= f << (8 * j);
+    }
+    P.padTab.push_back(pe);
+  }
+  if (l > 0) {
+    F.colOff = (int)P.colTab.size();
+    P.colTab.insert(P.colTab.end(), col.begin(), col.end());
+    F.rowOff = (int)P.rowTab.size();
+    const int* yofs = P.tabInt.data() + P.tab[l].yofs;
+    const short* beta = P.tabShort.data() + P.tab[l].beta;
+    const int rows = alignUp(L.h, 4 * kPyrRowsF);
+    for (int y = 0; y < rows; y++) {
+      const int dy = std::min(y, L.h - 1);
+      P.rowTab.push_back(make_int2(yofs[dy], (int)((uint32_t)(uint16_t)beta[2 * dy] | ((uint32_t)(uint16_t)beta[2 * dy + 1] << 16))));
+    }
+  }
+  F.on = true;
 }
 
 int buildPlan(ydorb_extractor* e, int w, int h, HostPlan& P) {
@@ -220,9 +313,10 @@ int buildPlan(ydorb_extractor* e, int w, int h, HostPlan& P) {
     D.lv[l].candOff = candOff;
     candOff += D.lv[l].nCells * D.cellCap;
   }
+  for (int l = 0; l < D.nLevels && !e->noFusedPads; l++) buildFusedLevel(P, l);
   D.borderBegin[0] = 0;
-  for (int l = 0; l < kMaxLevels; l++)
-    D.borderBegin[l + 1] = D.borderBegin[l] + (l < D.nLevels ? alignUp(2 * kPad * (D.lv[l].pitch / 4) + 12 * D.lv[l].h, 256) : 0);
+  for (int l = 0; l < kMaxLevels; l++)   // fused levels have no border threads
+    D.borderBegin[l + 1] = D.borderBegin[l] + (l < D.nLevels && !P.fused[l].on ? alignUp(2 * kPad * (D.lv[l].pitch / 4) + 12 * D.lv[l].h, 256) : 0);
   D.blurTileBegin[0] = 0;
   for (int l = 0; l < kMaxLevels; l++)
     D.blurTileBegin[l + 1] = D.blurTileBegin[l] + (l < D.nLevels ? ((D.lv[l].w + kBlurTW - 1) / kBlurTW) * ((D.lv[l].h + kBlurTH - 1) / kBlurTH) : 0);
@@ -318,6 +412,12 @@ int ensurePlan(ydorb_extractor* e, int w, int h, int nFrames) {
   if (!P.cells.empty()) HIPCHK(hipMemcpyAsync(e->d_cells, P.cells.data(), sizeof(CellDev) * P.cells.size(), hipMemcpyHostToDevice, e->stream));
   if (!P.tabInt.empty()) HIPCHK(hipMemcpyAsync(e->d_tabInt, P.tabInt.data(), sizeof(int) * P.tabInt.size(), hipMemcpyHostToDevice, e->stream));
   if (!P.tabShort.empty()) HIPCHK(hipMemcpyAsync(e->d_tabShort, P.tabShort.data(), sizeof(short) * P.tabShort.size(), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMalloc(&e->d_padTab, sizeof(PyrPadEntry) * std::max<size_t>(P.padTab.size(), 1)));
+  HIPCHK(hipMalloc(&e->d_colTab, sizeof(PyrColEntry) * std::max<size_t>(P.colTab.size(), 1)));
+  HIPCHK(hipMalloc(&e->d_rowTab, sizeof(int2) * std::max<size_t>(P.rowTab.size(), 1)));
+  if (!P.padTab.empty()) HIPCHK(hipMemcpyAsync(e->d_padTab, P.padTab.data(), sizeof(PyrPadEntry) * P.padTab.size(), hipMemcpyHostToDevice, e->stream));
+  if (!P.colTab.empty()) HIPCHK(hipMemcpyAsync(e->d_colTab, P.colTab.data(), sizeof(PyrColEntry) * P.colTab.size(), hipMemcpyHostToDevice, e->stream));
+  if (!P.rowTab.empty()) HIPCHK(hipMemcpyAsync(e->d_rowTab, P.rowTab.data(), sizeof(int2) * P.rowTab.size(), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipMemsetAsync(e->d_status, 0, sizeof(int), e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   if (std::max(P.qtLdsMax, P.qtPassLds) > 48 * 1024)
@@ -372,18 +472,34 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   }
   {
     const LevelDev& L0 = D.lv[0];
-    dim3 g((L0.pitch / 4 + 63) / 64, (L0.h + 4 * kPyrRows - 1) / (4 * kPyrRows), nFrames);
-    hipLaunchKernelGGL(k_pyr_level0, g, dim3(256), 0, s, d_img, stride, frameStride, e->d_pyr, P.pyrFrameStride, L0);
+    auto fusedGrid = [&](const LevelDev& L, int shift) {
+      return dim3((((L.w + 2 * kPad + 3) >> 2) + shift + 63) / 64, (L.h + 4 * kPyrRowsF - 1) / (4 * kPyrRowsF), nFrames);
+    };
+    if (P.fused[0].on) {
+      hipLaunchKernelGGL(k_pyr_level0_f, fusedGrid(L0, P.fused[0].shift), dim3(256), 0, s, d_img, stride, frameStride, e->d_pyr, P.pyrFrameStride, L0,
+                         e->d_padTab + P.fused[0].padOff, P.fused[0].shift);
+    } else {
+      dim3 g((L0.pitch / 4 + 63) / 64, (L0.h + 4 * kPyrRows - 1) / (4 * kPyrRows), nFrames);
+      hipLaunchKernelGGL(k_pyr_level0, g, dim3(256), 0, s, d_img, stride, frameStride, e->d_pyr, P.pyrFrameStride, L0);
+    }
     for (int l = 1; l < D.nLevels; l++) {
       const LevelDev& L = D.lv[l];
-      dim3 gl((L.pitch / 4 + 63) / 64, (L.h + 4 * kPyrRows - 1) / (4 * kPyrRows), nFrames);
-      hipLaunchKernelGGL(k_pyr_resize, gl, dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, D.lv[l - 1], L,
-                         1. / ((double)L.w / D.lv[l - 1].w), e->d_tabShort + P.tab[l].alpha, e->d_tabInt + P.tab[l].yofs,
-                         e->d_tabShort + P.tab[l].beta);
+      const double scaleX = 1. / ((double)L.w / D.lv[l - 1].w);
+      if (P.fused[l].on) {
+        const HostPlan::FusedLevel& F = P.fused[l];
+        hipLaunchKernelGGL(k_pyr_resize_f, fusedGrid(L, F.shift), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, D.lv[l - 1], L, scaleX,
+                           e->d_colTab + F.colOff, e->d_padTab + F.padOff, e->d_rowTab + F.rowOff, F.shift);
+      } else {
+        dim3 gl((L.pitch / 4 + 63) / 64, (L.h + 4 * kPyrRows - 1) / (4 * kPyrRows), nFrames);
+        hipLaunchKernelGGL(k_pyr_resize, gl, dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, D.lv[l - 1], L, scaleX,
+                           e->d_tabShort + P.tab[l].alpha, e->d_tabInt + P.tab[l].yofs, e->d_tabShort + P.tab[l].beta);
+      }
     }
-    hipLaunchKernelGGL(k_pyr_borders, dim3(D.borderBegin[D.nLevels] / 256, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, D);
+    if (D.borderBegin[D.nLevels] > 0)
+      hipLaunchKernelGGL(k_pyr_borders, dim3(D.borderBegin[D.nLevels] / 256, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, D);
   }
   if (prof) HIPCHK(hipEventRecord(e->ev[1], s));
+  hipEvent_t fastEv[kMaxLevels]{};
   if (D.nCellsTotal > 0) {
     // one wave per cell, 4 cells per workgroup; the per-wave LDS (tile, score map, candidate list) is sized for the plan's largest cell
     const int maxT = P.maxCellDim + 6, maxB = P.maxCellDim;
@@ -395,13 +511,25 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
     fl.listBytes = alignUp(2 * maxB * maxB, 16);
     const size_t dyn = (size_t)4 * (fl.tileBytes + fl.scoreBytes + fl.listBytes);
     const int thr = std::min(std::max(e->cfg.ini_fast_thr, 0), 255);
-    const dim3 grid(((D.nCellsTotal + 3) / 4 + 7) / 8 * 8, nFrames);
-    if (narrow) {
-      if (dyn > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells<48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-      hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(256), dyn, s, e->d_pyr, P.pyrFrameStride, D, e->d_cells, thr, fl, e->d_cellCount, e->d_cellCand);
-    } else {
-      if (dyn > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells<80>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-      hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(256), dyn, s, e->d_pyr, P.pyrFrameStride, D, e->d_cells, thr, fl, e->d_cellCount, e->d_cellCand);
+    if (dyn > 48 * 1024) {
+      if (narrow) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells<48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+      else HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells<80>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    }
+    // The cells are launched in level groups - the first fastGroups - 1 levels each on their own, the rest together - so that the
+    // quad-tree of a big level (its own stream, below) starts while the cells of the smaller levels are still being searched.
+    int l0 = 0;
+    for (int g = 0; g < e->fastGroups && l0 < D.nLevels; g++) {
+      const int l1 = g == e->fastGroups - 1 ? D.nLevels : l0 + 1;
+      const int c0 = D.lv[l0].cellBegin, c1 = D.lv[l1 - 1].cellBegin + D.lv[l1 - 1].nCells;
+      if (c1 > c0) {
+        const dim3 grid(((c1 - c0 + 3) / 4 + 7) / 8 * 8, nFrames);
+        if (narrow) hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(256), dyn, s, e->d_pyr, P.pyrFrameStride, D, e->d_cells, c0, c1, thr, fl, e->d_cellCount, e->d_cellCand);
+        else hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(256), dyn, s, e->d_pyr, P.pyrFrameStride, D, e->d_cells, c0, c1, thr, fl, e->d_cellCount, e->d_cellCand);
+      }
+      HIPCHK(hipEventRecord(e->evFast[l0], s));
+      fastEv[l0] = e->evFast[l0];
+      for (int l = l0 + 1; l < l1; l++) fastEv[l] = e->evFast[l0];
+      l0 = l1;
     }
   }
   if (prof) HIPCHK(hipEventRecord(e->ev[2], s));
@@ -412,13 +540,14 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
                      P.blurFrameStride, D);
   bool anyFlat = false;
   for (int l = 0; l < D.nLevels; l++) {
-    HIPCHK(hipStreamWaitEvent(e->qtStream[l], e->evFork, 0));
+    const hipStream_t qs = e->qtInline ? s : e->qtStream[l];
+    if (!e->qtInline) HIPCHK(hipStreamWaitEvent(qs, fastEv[l] ? fastEv[l] : e->evFork, 0));
     const HostPlan::QtLevel& Q = P.qt[l];
     const uint8_t* needPass = nullptr;
     if (Q.flatItems && !e->forcePassQuadtree) {
       needPass = e->d_needPass;
 #define YD_QT_FLAT(IT)                                                                                                              \
-  hipLaunchKernelGGL(k_quadtree_flat<IT>, dim3(nFrames), dim3(kQtFlatThreads), Q.flatLds, e->qtStream[l], D, e->d_cellCount,        \
+  hipLaunchKernelGGL(k_quadtree_flat<IT>, dim3(nFrames), dim3(kQtFlatThreads), Q.flatLds, qs, D, e->d_cellCount,        \
                      e->d_cellCand, l, e->d_lvlKp, e->d_lvlCount, e->d_needPass, e->d_lvlMaxN)
       switch (Q.flatItems) {
         case 2: YD_QT_FLAT(2); break;
@@ -432,14 +561,14 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
     // pass algorithm on this level's stream only when the flat kernel is off for the level; otherwise the units the flat kernel
     // hands over (rare) are picked up by ONE launch over all levels after the join (below)
     if (!needPass)
-      hipLaunchKernelGGL(k_quadtree, dim3(1, nFrames), dim3(kQtThreads), Q.lds, e->qtStream[l], D, e->d_cellCount, e->d_cellCand,
+      hipLaunchKernelGGL(k_quadtree, dim3(1, nFrames), dim3(kQtThreads), Q.lds, qs, D, e->d_cellCount, e->d_cellCand,
                          e->d_qtCand, e->d_qtNode, P.qtFrameStride, Q.nodeCap, Q.candCap, l, e->d_lvlKp, e->d_lvlCount, e->d_status, needPass, e->d_nodeScratch);
     else
       anyFlat = true;
-    HIPCHK(hipEventRecord(e->evJoin[l], e->qtStream[l]));
+    if (!e->qtInline) HIPCHK(hipEventRecord(e->evJoin[l], qs));
   }
   if (prof) HIPCHK(hipEventRecord(e->ev[3], s));   // end of the blur; the quad-tree stage is the interval up to the join below
-  for (int l = 0; l < D.nLevels; l++) HIPCHK(hipStreamWaitEvent(s, e->evJoin[l], 0));
+  if (!e->qtInline) for (int l = 0; l < D.nLevels; l++) HIPCHK(hipStreamWaitEvent(s, e->evJoin[l], 0));
   if (anyFlat)   // hand-over units of every level: node table in LDS, candidates in HBM scratch (candCap 0); others exit at once
     hipLaunchKernelGGL(k_quadtree, dim3(D.nLevels, nFrames), dim3(kQtThreads), P.qtPassLds, s, D, e->d_cellCount, e->d_cellCand, e->d_qtCand,
                        e->d_qtNode, P.qtFrameStride, -std::max(P.qtPassNodes, 1), 0, 0, e->d_lvlKp, e->d_lvlCount, e->d_status, e->d_needPass, e->d_nodeScratch);
@@ -500,6 +629,7 @@ int ydorb_extractor_create(const YdExtractorConfig* cfg, ydorb_extractor_t** out
   ydorb_extractor* e = new ydorb_extractor();
   e->cfg = *cfg;
   if (const char* v = getenv("YDORB_QT_PASS")) e->forcePassQuadtree = v[0] == '1';
+  if (const char* v = getenv("YDORB_PYR_FUSED")) e->noFusedPads = v[0] == '0';
   e->cfg.min_fast_thr = cfg->ini_fast_thr;  // reference quirk, orbExtractor.cpp:318
   // constructor tables, orbExtractor.cpp:319-353
   const int L = cfg->n_levels;
@@ -548,10 +678,16 @@ int ydorb_extractor_create(const YdExtractorConfig* cfg, ydorb_extractor_t** out
     // A handle for single frames (max_batch <= 8: the adapter's use) keeps one stream per level: its launches are latency bound and the
     // eight units of a frame then run side by side (0.27 ms per extractAndCompute against 0.33 ms with two).
     const char* qtEnv = getenv("YDORB_QT_STREAMS");
+    e->qtInline = qtEnv && atoi(qtEnv) == 0;
     const int nQt = std::max(1, std::min(qtEnv ? atoi(qtEnv) : (cfg->max_batch <= 8 ? (int)kMaxLevels : 2), (int)kMaxLevels));
     if (l < nQt) (void)hipStreamCreateWithFlags(&e->qtStream[l], hipStreamNonBlocking);
     else e->qtStream[l] = e->qtStream[l % nQt];
     (void)hipEventCreateWithFlags(&e->evJoin[l], hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&e->evFast[l], hipEventDisableTiming);
+  }
+  {
+    const char* g = getenv("YDORB_FAST_GROUPS");
+    e->fastGroups = std::max(1, std::min(g ? atoi(g) : 1, (int)kMaxLevels));
   }
   *out = e;
   return YDORB_OK;
@@ -570,6 +706,7 @@ void ydorb_extractor_destroy(ydorb_extractor_t* e) {
       if (!shared) { (void)hipStreamSynchronize(e->qtStream[l]); (void)hipStreamDestroy(e->qtStream[l]); }
     }
     if (e->evJoin[l]) (void)hipEventDestroy(e->evJoin[l]);
+    if (e->evFast[l]) (void)hipEventDestroy(e->evFast[l]);
   }
   if (e->evFork) (void)hipEventDestroy(e->evFork);
   if (e->stream) (void)hipStreamDestroy(e->stream);
