@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--extractors", type=int, default=1,
                     help="extractor handles (each with its own stream) the frames of a step are split over; 1 is fastest with the matcher beside it "
                          "(4 hardware queues: more streams share queues and serialise): 163 Mkeypoints/s against 158 with 2 handles")
+    ap.add_argument("--alternate", type=int, default=int(os.environ.get("YDORB_BENCH_ALTERNATE", "0")),
+                    help="1: two extractor handles take alternate STEPS, each with its matcher on its own stream (no cross-stream events)")
     ap.add_argument("--ba-threads", type=int, default=64, help="problems of the lock-step batched local-BA figure (ydorb_ba_solve_batch)")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
@@ -175,7 +177,11 @@ def main():
     imgs, _ = stream_render(plan, own)
     NEX = max(1, min(args.extractors, F // 8))
     parts = [(i * F // NEX, (i + 1) * F // NEX) for i in range(NEX)]
-    exs = [y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=b - a) for a, b in parts]
+    if args.alternate:
+        NEX, parts = 2, [(0, F)]
+        exs = [y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=F) for _ in range(2)]
+    else:
+        exs = [y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=b - a) for a, b in parts]
     ex = exs[0]
     cap = ex.max_keypoints
     sf = ex.tables()["scale"]
@@ -206,7 +212,24 @@ def main():
     mts = [y.OrbMatcher(0.9, True, device=local_rank) for _ in range(2)]   # one matcher (own scratch) per output set
     step_no = [0]
 
+    def step_alternate():
+        # output set b belongs to handle b and stream b: step k's extraction AND matching run on stream k & 1, back to back; the two
+        # streams overlap freely (no events between them), so one stream's latency-bound kernels run beside the other's busy ones
+        b = step_no[0] & 1
+        step_no[0] += 1
+        sA = sAs[b]
+        exs[b].extract_batch_device(d_img.data_ptr(), W, H, W, W * H, F, d_kps[b].data_ptr(), d_desc[b].data_ptr(), cap, d_n[b].data_ptr(), sA.cuda_stream)
+        with torch.cuda.stream(sA):
+            if world > 1 or force_dist:
+                all_gather_inplace(g_kps[b], d_kps[b])
+                all_gather_inplace(g_desc[b], d_desc[b])
+                all_gather_inplace(g_n[b], d_n[b])
+            gs = (g_kps[b].data_ptr(), g_desc[b].data_ptr(), g_n[b].data_ptr(), G, cap)
+            mts[b].match_pairs_device(gs, gs, pairs, W, H, 15.0, sf, d_assigned[b].data_ptr(), d_counts[b].data_ptr(), d_aff.data_ptr(), sA.cuda_stream)
+
     def step():
+        if args.alternate:
+            return step_alternate()
         b = step_no[0] & 1
         step_no[0] += 1
         for i, (f0, f1) in enumerate(parts):
@@ -276,6 +299,11 @@ def main():
 
     # ---- extract only (both figures): the same launches without the matcher, after the timed region ------------------
     def extract_step():
+        if args.alternate:
+            b = step_no[0] & 1
+            step_no[0] += 1
+            exs[b].extract_batch_device(d_img.data_ptr(), W, H, W, W * H, F, d_kps[b].data_ptr(), d_desc[b].data_ptr(), cap, d_n[b].data_ptr(), sAs[b].cuda_stream)
+            return
         for i, (f0, f1) in enumerate(parts):
             exs[i].extract_batch_device(d_img[f0].data_ptr(), W, H, W, W * H, f1 - f0, d_kps[0][f0].data_ptr(), d_desc[0][f0].data_ptr(), cap,
                                         d_n[0][f0:].data_ptr(), sAs[i].cuda_stream)

@@ -158,6 +158,27 @@ def test_pyramid_pads_written_by_level_kernels_and_by_border_launch(oracle_lib, 
             assert np.array_equal(d, cd)
 
 
+@pytest.mark.parametrize("kpw", ["1", "2", "4"])
+def test_describe_kernel_keypoints_per_wave(oracle_lib, monkeypatch, kpw):
+    """k_orient_describe_n<KPW> interleaves KPW keypoints in one wave (batch handles use 4, single-frame handles 1): the same
+    keypoints, angles and descriptors whatever KPW is - also where a wave's slots straddle two levels or end past the last keypoint
+    (the half-empty and the nearly empty frame)."""
+    import ydorbslam_amd as y
+    from oracle.orb_oracle import OrbExtractorOracle
+    frames = [synth_frame(640, 480, 41), synth_frame(640, 480, 42).copy(), np.full((480, 640), 90, np.uint8)]
+    frames[1][:240] = 128
+    frames[2][100:150, 100:160] = synth_frame(640, 480, 43)[100:150, 100:160]
+    imgs = np.stack(frames)
+    monkeypatch.setenv("YDORB_DESC_KPW", kpw)
+    gpu = y.OrbExtractor(1000, 1.2, 8, 20, 7, max_batch=len(frames))
+    monkeypatch.delenv("YDORB_DESC_KPW")
+    res = gpu.extract_batch(imgs)
+    for f, img in enumerate(frames):
+        ck, cd = OrbExtractorOracle(1000, 1.2, 8, 20, 7).extract(img)
+        _same_kps(res[f][0], ck)
+        assert np.array_equal(res[f][1], cd)
+
+
 @pytest.mark.parametrize("w,h,nf,sf,nl,thr", [
     (640, 480, 1500, 2.5, 3, 20),     # scale factor > 2: the resize kernel's byte-tap path
     (640, 480, 800, 2.0, 4, 12),      # exactly 2: still the 8-byte window path

@@ -1401,4 +1401,160 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
   }
 }
 
+
+// The same kernel with KPW keypoints per wave, their phases interleaved: a keypoint is three dependent memory round trips (packed
+// keypoint + level counts, the orientation patch, the rotated test points) with little arithmetic between them, and a CU holds at
+// most 32 waves, so one keypoint per wave leaves the vector ALUs idle half of the time.  With KPW keypoints the loads of all of
+// them are in flight together.  Arithmetic per keypoint is unchanged (same operations in the same order).
+template <int KPW>
+__global__ __launch_bounds__(256) void k_orient_describe_n(const uint8_t* __restrict__ pyr, size_t pyrFrameStride,
+                                                           const uint8_t* __restrict__ blur, size_t blurFrameStride, PlanDev P,
+                                                           const uint32_t* __restrict__ lvlKp, const int* __restrict__ lvlCount,
+                                                           YdKeyPointDev* __restrict__ kps, uint8_t* __restrict__ desc, int cap,
+                                                           int* __restrict__ nOut, float* __restrict__ lvlAngle) {
+  const int lane = threadIdx.x & 63;
+  int bx = blockIdx.x, f = blockIdx.y;
+  if ((f | 7) < (int)gridDim.y) {   // XCD-aware (see k_fast_cells)
+    bx = (f & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    f = (f & ~7) | (blockIdx.x & 7);
+  }
+  const int slot0 = (bx * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * KPW;
+  if (slot0 >= P.sumQuota) return;
+  float4 pat[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) pat[t] = reinterpret_cast<const float4*>(kPatternDev)[t * 64 + lane];
+  int cnt[kMaxLevels], tot = 0;
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; l++) { cnt[l] = l < P.nLevels ? lvlCount[f * kMaxLevels + l] : 0; tot += cnt[l]; }
+  int level[KPW], outIdx[KPW];
+  uint32_t pk[KPW];
+  bool valid[KPW];
+#pragma unroll
+  for (int j = 0; j < KPW; j++) {
+    const int slot = min(slot0 + j, P.sumQuota - 1);
+    level[j] = 0;
+#pragma unroll
+    for (int l = 1; l < kMaxLevels; l++)
+      if (l < P.nLevels && slot >= P.lv[l].kpOff) level[j] = l;
+    pk[j] = __builtin_amdgcn_readfirstlane(lvlKp[(size_t)f * P.sumQuota + slot]);
+  }
+  if (slot0 == 0 && lane == 0) nOut[f] = min(tot, cap);
+  bool any = false;
+#pragma unroll
+  for (int j = 0; j < KPW; j++) {
+    int before = 0, mine = 0;
+#pragma unroll
+    for (int l = 0; l < kMaxLevels; l++) {
+      if (l < level[j]) before += cnt[l];
+      if (l == level[j]) mine = cnt[l];
+    }
+    const int k = slot0 + j - P.lv[level[j]].kpOff;
+    outIdx[j] = before + k;
+    valid[j] = slot0 + j < P.sumQuota && k < mine && outIdx[j] < cap;
+    any = any || valid[j];
+  }
+  if (!any) return;
+  // a slot without a keypoint repeats a valid one of the wave (same addresses: no extra traffic) and stores nothing
+  int firstValid = 0;
+#pragma unroll
+  for (int j = KPW - 1; j >= 0; j--) if (valid[j]) firstValid = j;
+#pragma unroll
+  for (int j = 0; j < KPW; j++)
+    if (!valid[j]) {
+#pragma unroll
+      for (int i = 0; i < KPW; i++) if (i == firstValid) { pk[j] = pk[i]; level[j] = level[i]; }
+    }
+  int kx[KPW], ky[KPW], pitch[KPW];
+  const uint8_t* org[KPW];
+#pragma unroll
+  for (int j = 0; j < KPW; j++) {
+    const LevelDev& L = P.lv[level[j]];
+    kx[j] = qt_x(pk[j]) + kBorder; ky[j] = qt_y(pk[j]) + kBorder;
+    pitch[j] = L.pitch;
+    const uint8_t* roi = pyr + (size_t)f * pyrFrameStride + L.padOff + (size_t)kPad * L.pitch + kPad;
+    org[j] = roi + (ptrdiff_t)(ky[j] - 15) * L.pitch + (kx[j] - 32);
+  }
+  const int u = lane - 32;
+  unsigned narrow = 0;
+#pragma unroll
+  for (int v = 1; v <= 15; v++) narrow |= (unsigned)(P.maxX[v] == 0) << v;
+  int m10[KPW], m01[KPW];
+#pragma unroll
+  for (int j = 0; j < KPW; j++) {
+    m10[j] = 0; m01[j] = 0;
+    if (u >= -15 && u <= 15) m10[j] = u * org[j][(unsigned)(15 * pitch[j] + lane)];
+    if (lane >= 1 && lane <= 15 && ((narrow >> lane) & 1u)) {
+      const int pos = org[j][(unsigned)((15 + lane) * pitch[j] + 32)], neg = org[j][(unsigned)((15 - lane) * pitch[j] + 32)];
+      m01[j] = lane * (pos - neg);
+    }
+  }
+#pragma unroll
+  for (int v = 1; v <= 15; v++) {
+    const int d = P.maxX[v];
+    if (d > 0 && u >= -d && u <= d) {
+#pragma unroll
+      for (int j = 0; j < KPW; j++) {
+        const int pos = org[j][(unsigned)((15 + v) * pitch[j] + lane)], neg = org[j][(unsigned)((15 - v) * pitch[j] + lane)];
+        m01[j] += v * (pos - neg);
+        m10[j] += u * (pos + neg);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+#pragma unroll
+    for (int j = 0; j < KPW; j++) {
+      m10[j] += __shfl_xor(m10[j], o, 64);
+      m01[j] += __shfl_xor(m01[j], o, 64);
+    }
+  }
+  constexpr int kBias = 24;
+  float angle[KPW];
+  int tA[KPW][4], tB[KPW][4];
+#pragma unroll
+  for (int j = 0; j < KPW; j++) {
+    const LevelDev& L = P.lv[level[j]];
+    angle[j] = fast_atan2_deg((float)m01[j], (float)m10[j]);
+    const float rad = __fmul_rn(angle[j], (float)(3.14159265358979323846 / 180.0));
+    float sinB, cosA;
+    sincos_det(rad, &sinB, &cosA);
+    const uint8_t* bl = blur + (size_t)f * blurFrameStride + L.blurOff + (ptrdiff_t)(ky[j] - kBias) * L.blurPitch + (kx[j] - kBias);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const float4 pt = pat[t];
+      const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(pt.x, sinB), __fmul_rn(pt.y, cosA)));
+      const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(pt.x, cosA), __fmul_rn(pt.y, sinB)));
+      const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(pt.z, sinB), __fmul_rn(pt.w, cosA)));
+      const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(pt.z, cosA), __fmul_rn(pt.w, sinB)));
+      tA[j][t] = bl[(unsigned)((r0 + kBias) * L.blurPitch + c0 + kBias)];
+      tB[j][t] = bl[(unsigned)((r1 + kBias) * L.blurPitch + c1 + kBias)];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < KPW; j++) {
+    unsigned long long words[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) words[t] = __ballot(tA[j][t] < tB[j][t]);
+    if (!valid[j]) continue;
+    const LevelDev& L = P.lv[level[j]];
+    if (lane < 4) {
+      unsigned long long w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
+      reinterpret_cast<unsigned long long*>(desc + ((size_t)f * cap + outIdx[j]) * 32)[lane] = w;
+    }
+    if (lane == 0) {
+      YdKeyPointDev kp;
+      kp.x = (float)kx[j];
+      kp.y = (float)ky[j];
+      if (level[j]) { kp.x = __fmul_rn(kp.x, L.scale); kp.y = __fmul_rn(kp.y, L.scale); }
+      kp.size = L.size;
+      kp.angle = angle[j];
+      kp.response = (float)qt_r(pk[j]);
+      kp.octave = level[j];
+      kp.class_id = -1;
+      kps[(size_t)f * cap + outIdx[j]] = kp;
+      lvlAngle[(size_t)f * P.sumQuota + slot0 + j] = angle[j];
+    }
+  }
+}
+
 }  // namespace ydorb
