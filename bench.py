@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--extractors", type=int, default=1,
                     help="extractor handles (each with its own stream) the frames of a step are split over; 1 is fastest with the matcher beside it "
                          "(4 hardware queues: more streams share queues and serialise): 163 Mkeypoints/s against 158 with 2 handles")
-    ap.add_argument("--alternate", type=int, default=int(os.environ.get("YDORB_BENCH_ALTERNATE", "0")),
+    ap.add_argument("--alternate", type=int, default=int(os.environ.get("YDORB_BENCH_ALTERNATE", "1")),
                     help="1: two extractor handles take alternate STEPS, each with its matcher on its own stream (no cross-stream events)")
     ap.add_argument("--ba-threads", type=int, default=64, help="problems of the lock-step batched local-BA figure (ydorb_ba_solve_batch)")
     ap.add_argument("--no-ba", action="store_true")
