@@ -8,7 +8,7 @@ q = collections.defaultdict(collections.Counter)
 for r in rows: q[(r['Queue_Id'], r['Stream_Id'])][nm(r)] += 1
 for k, v in q.items(): print(k, dict(v))
 idx = [i for i, r in enumerate(rows) if 'k_pyr_level0' in r['Kernel_Name'] and int(r['Grid_Size_Z']) >= 128]
-s, e = idx[nth], idx[nth + 1]
+s, e = idx[nth], idx[min(nth + (int(sys.argv[3]) if len(sys.argv) > 3 else 1), len(idx) - 1)]
 t0 = int(rows[s]['Start_Timestamp'])
 for r in rows[s:e]:
     print('%-30s q=%s st=%s start=%8.1f end=%8.1f dur=%7.1f' % (nm(r), r['Queue_Id'], r['Stream_Id'], (int(r['Start_Timestamp']) - t0) / 1e3,
