@@ -102,11 +102,13 @@ def main():
     ap.add_argument("--extractors", type=int, default=1,
                     help="extractor handles (each with its own stream) the frames of a step are split over; 1 is fastest with the matcher beside it "
                          "(4 hardware queues: more streams share queues and serialise): 163 Mkeypoints/s against 158 with 2 handles")
-    ap.add_argument("--alternate", type=int, default=int(os.environ.get("YDORB_BENCH_ALTERNATE", "1")),
-                    help="1: two extractor handles take alternate STEPS, each with its matcher on its own stream (no cross-stream events)")
+    ap.add_argument("--alternate", type=int, default=int(os.environ.get("YDORB_BENCH_ALTERNATE", "2")),
+                    help="N >= 2: N lanes (extractor handle + matcher + stream each) take consecutive STEPS, a step's extraction and matching back to "
+                         "back on its lane's stream, no events between lanes; 0: one handle, matcher on a second stream")
     ap.add_argument("--ba-threads", type=int, default=64, help="problems of the lock-step batched local-BA figure (ydorb_ba_solve_batch)")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--only", default="", help="with extras: run only these sections (comma list of single_call, pcie, config3, config4, rest)")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-call / PCIe-inclusive / config 3 / config 4 / brute-force sections")
     args = ap.parse_args()
 
@@ -177,9 +179,11 @@ def main():
     imgs, _ = stream_render(plan, own)
     NEX = max(1, min(args.extractors, F // 8))
     parts = [(i * F // NEX, (i + 1) * F // NEX) for i in range(NEX)]
+    NSET = max(2, args.alternate)      # output sets (= lanes with --alternate)
+    single = bool(int(os.environ.get("YDORB_BENCH_SINGLE_STREAM", "0")))
     if args.alternate:
-        NEX, parts = 2, [(0, F)]
-        exs = [y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=F) for _ in range(2)]
+        NEX, parts = NSET, [(0, F)]
+        exs = [y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=F, single_stream=single) for _ in range(NSET)]
     else:
         exs = [y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=b - a) for a, b in parts]
     ex = exs[0]
@@ -189,9 +193,9 @@ def main():
     # Two output sets + explicit streams: extraction of step k+1 overlaps the matching of step k.  An output set is laid out as the
     # GATHERED set [world * F][cap]; this rank's extractors write straight into its slice.
     # (The default stream's handle is 0, which the C ABI reads as "use the handle's own stream": always pass real streams.)
-    g_kps = [torch.zeros((G, cap, 7), dtype=torch.float32, device=dev) for _ in range(2)]
-    g_desc = [torch.zeros((G, cap, 32), dtype=torch.uint8, device=dev) for _ in range(2)]
-    g_n = [torch.zeros(G, dtype=torch.int32, device=dev) for _ in range(2)]
+    g_kps = [torch.zeros((G, cap, 7), dtype=torch.float32, device=dev) for _ in range(NSET)]
+    g_desc = [torch.zeros((G, cap, 32), dtype=torch.uint8, device=dev) for _ in range(NSET)]
+    g_n = [torch.zeros(G, dtype=torch.int32, device=dev) for _ in range(NSET)]
     lo = rank * F
     d_kps = [t[lo:lo + F] for t in g_kps]
     d_desc = [t[lo:lo + F] for t in g_desc]
@@ -202,20 +206,20 @@ def main():
     pair_aff = plan["predicted"][pred_idx]
     NPAIR = len(pairs)
     d_aff = torch.from_numpy(np.ascontiguousarray(pair_aff, np.float32)).to(dev)
-    d_assigned = [torch.zeros((NPAIR, cap), dtype=torch.int32, device=dev) for _ in range(2)]
-    d_counts = [torch.zeros(NPAIR, dtype=torch.int32, device=dev) for _ in range(2)]
+    d_assigned = [torch.zeros((NPAIR, cap), dtype=torch.int32, device=dev) for _ in range(NSET)]
+    d_counts = [torch.zeros(NPAIR, dtype=torch.int32, device=dev) for _ in range(NSET)]
     sAs, sB = [torch.cuda.Stream(device=dev) for _ in range(NEX)], torch.cuda.Stream(device=dev)
-    ev_extracted = [[torch.cuda.Event() for _ in range(NEX)] for _ in range(2)]
-    ev_matched = [torch.cuda.Event() for _ in range(2)]
+    ev_extracted = [[torch.cuda.Event() for _ in range(NEX)] for _ in range(NSET)]
+    ev_matched = [torch.cuda.Event() for _ in range(NSET)]
     for e in ev_matched:
         e.record(sB)
-    mts = [y.OrbMatcher(0.9, True, device=local_rank) for _ in range(2)]   # one matcher (own scratch) per output set
+    mts = [y.OrbMatcher(0.9, True, device=local_rank) for _ in range(NSET)]   # one matcher (own scratch) per output set
     step_no = [0]
 
     def step_alternate():
         # output set b belongs to handle b and stream b: step k's extraction AND matching run on stream k & 1, back to back; the two
         # streams overlap freely (no events between them), so one stream's latency-bound kernels run beside the other's busy ones
-        b = step_no[0] & 1
+        b = step_no[0] % NSET
         step_no[0] += 1
         sA = sAs[b]
         exs[b].extract_batch_device(d_img.data_ptr(), W, H, W, W * H, F, d_kps[b].data_ptr(), d_desc[b].data_ptr(), cap, d_n[b].data_ptr(), sA.cuda_stream)
@@ -300,7 +304,7 @@ def main():
     # ---- extract only (both figures): the same launches without the matcher, after the timed region ------------------
     def extract_step():
         if args.alternate:
-            b = step_no[0] & 1
+            b = step_no[0] % NSET
             step_no[0] += 1
             exs[b].extract_batch_device(d_img.data_ptr(), W, H, W, W * H, F, d_kps[b].data_ptr(), d_desc[b].data_ptr(), cap, d_n[b].data_ptr(), sAs[b].cuda_stream)
             return
@@ -463,10 +467,12 @@ def main():
                                        "note": "ydorb_ba_solve_batch, lock-step batch: independent copies of the same C5 problem, every result bit-identical to its single solve"}
 
     extras = world == 1 and not args.no_extras
+    only = [x for x in args.only.split(",") if x]
+    want = lambda name: extras and (not only or name in only)
     pprobs = spairs = vtree = bdescs = groups_d = best_d = None
 
     # ---- what ONE call of the drop-in sees, host to host (frame.cpp:129, tracking.cpp:456, localMapping.cpp:140) ---------------
-    if extras:
+    if want('single_call'):
         def med_ms(fn, n=15):
             fn()
             ts = []
@@ -498,7 +504,7 @@ def main():
         del ex1
 
     # ---- PCIe-inclusive: pinned host frames in, host keypoints / descriptors / matches out (SURVEY 8d "incl. H2D/D2H") -------------
-    if extras:
+    if want('pcie'):
         CH = 4                                              # chunks per step: copy of chunk c+1 overlaps the extraction of chunk c
         cf = F // CH
         h_img = torch.from_numpy(imgs).pin_memory()
@@ -552,7 +558,7 @@ def main():
         del h_img, h_kps, h_desc, h_assigned, p_img, pexs
 
     # ---- configs 3 and 4: stereo streams (extract L + R, computeStereoMatches, consecutive left-frame search) ----------------------
-    if extras:
+    if extras and (not only or "config3" in only or "config4" in only):
         def stereo_config(w, h, nf, n_pairs, label):
             pl = stream_plan(w, h, n_pairs, seed=7, segment=32)
             L_, R_ = stream_render(pl, range(n_pairs), stereo=True)
@@ -560,44 +566,44 @@ def main():
             mk = lambda *shape, dt=torch.float32: torch.zeros(shape, dtype=dt, device=dev)
             prs = np.array([(i, i + 1) for i in range(n_pairs - 1)], np.int32)
             daf = torch.from_numpy(np.ascontiguousarray(pl["predicted"], np.float32)).to(dev)
-            # Two complete sets (extractor pair, outputs, matchers): the association and the left-frame search of step k - a latency
-            # chain, the serial replay of frame.cpp:391-462 - run on their own stream while step k+1 is extracted into the other set
-            # (computeStereoMatches reads the pyramids of its extractors' last call, so a set's extractors wait for its association).
-            # Per eye one extractor instance, each on its own stream, as the reference runs them (frame.cpp:84-87).
+            # NSETS lanes, each a complete set (extractor pair, outputs, matchers) with ONE stream: a step's two extractions, its association
+            # (the serial replay of frame.cpp:391-462) and its left-frame search (ordered resolve) run back to back on the lane's stream,
+            # consecutive steps go to consecutive lanes, no events between lanes.  The two latency chains of a step (~5 ms at 2000
+            # features) then hide behind the extractions of the other lanes.  The handles are single-stream (YDORB_EXTRACTOR_SINGLE_STREAM):
+            # with side streams, 5+ streams share the device's 4 hardware queues and a stream that lands behind a chain stalls.
+            NSETS = int(os.environ.get("YDORB_BENCH_STEREO_SETS", "4"))
+            single = os.environ.get("YDORB_BENCH_STEREO_SINGLE_STREAM", "1") != "0"
             sets = []
-            for _ in range(2):
-                S_ = dict(xL=y.OrbExtractor(nf, 1.2, 8, 20, 7, device=local_rank, max_batch=n_pairs), xR=y.OrbExtractor(nf, 1.2, 8, 20, 7, device=local_rank, max_batch=n_pairs))
+            for _ in range(NSETS):
+                S_ = dict(xL=y.OrbExtractor(nf, 1.2, 8, 20, 7, device=local_rank, max_batch=n_pairs, single_stream=single),
+                          xR=y.OrbExtractor(nf, 1.2, 8, 20, 7, device=local_rank, max_batch=n_pairs, single_stream=single))
                 scap = S_["xL"].max_keypoints
                 S_.update(kL=mk(n_pairs, scap, 7), kR=mk(n_pairs, scap, 7), dL=mk(n_pairs, scap, 32, dt=torch.uint8), dR=mk(n_pairs, scap, 32, dt=torch.uint8),
                           nL=mk(n_pairs, dt=torch.int32), nR=mk(n_pairs, dt=torch.int32), rx=mk(n_pairs, scap), dp=mk(n_pairs, scap), kept=mk(n_pairs, dt=torch.int32),
                           asg=mk(n_pairs - 1, scap, dt=torch.int32), cnt=mk(n_pairs - 1, dt=torch.int32), sm=y.OrbMatcher(device=local_rank),
-                          mm=y.OrbMatcher(0.9, True, device=local_rank), evL=torch.cuda.Event(), evR=torch.cuda.Event(), evDone=torch.cuda.Event())
+                          mm=y.OrbMatcher(0.9, True, device=local_rank), st=torch.cuda.Stream(device=dev))
                 sets.append(S_)
             scap = sets[0]["xL"].max_keypoints
             ssf = sets[0]["xL"].tables()["scale"]
-            stL, stR, stS = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-            for S_ in sets:
-                S_["evDone"].record(stS)
             kstep = [0]
 
             def one(full=True):
-                S_ = sets[kstep[0] & 1]
+                S_ = sets[kstep[0] % NSETS]
+                st = S_["st"].cuda_stream
                 kstep[0] += 1
-                stL.wait_event(S_["evDone"]); stR.wait_event(S_["evDone"])      # this set's previous association has read its pyramids and outputs
-                S_["xL"].extract_batch_device(diL.data_ptr(), w, h, w, w * h, n_pairs, S_["kL"].data_ptr(), S_["dL"].data_ptr(), scap, S_["nL"].data_ptr(), stL.cuda_stream)
-                S_["xR"].extract_batch_device(diR.data_ptr(), w, h, w, w * h, n_pairs, S_["kR"].data_ptr(), S_["dR"].data_ptr(), scap, S_["nR"].data_ptr(), stR.cuda_stream)
-                S_["evL"].record(stL); S_["evR"].record(stR)
-                stS.wait_event(S_["evL"]); stS.wait_event(S_["evR"])
+                S_["xL"].extract_batch_device(diL.data_ptr(), w, h, w, w * h, n_pairs, S_["kL"].data_ptr(), S_["dL"].data_ptr(), scap, S_["nL"].data_ptr(), st)
+                S_["xR"].extract_batch_device(diR.data_ptr(), w, h, w, w * h, n_pairs, S_["kR"].data_ptr(), S_["dR"].data_ptr(), scap, S_["nR"].data_ptr(), st)
                 if full:
                     S_["sm"].stereo_matches_device(S_["xL"], S_["xR"], S_["kL"].data_ptr(), S_["dL"].data_ptr(), S_["nL"].data_ptr(), scap, S_["kR"].data_ptr(),
                                                    S_["dR"].data_ptr(), S_["nR"].data_ptr(), scap, n_pairs, 40.0, 0.1, S_["rx"].data_ptr(), S_["dp"].data_ptr(),
-                                                   S_["kept"].data_ptr(), None, False, (0, 1), (0, 1), stS.cuda_stream)
+                                                   S_["kept"].data_ptr(), None, False, (0, 1), (0, 1), st)
                     fs_ = (S_["kL"].data_ptr(), S_["dL"].data_ptr(), S_["nL"].data_ptr(), n_pairs, scap)
-                    S_["mm"].match_pairs_device(fs_, fs_, prs, w, h, 15.0, ssf, S_["asg"].data_ptr(), S_["cnt"].data_ptr(), daf.data_ptr(), stS.cuda_stream)
-                S_["evDone"].record(stS)
+                    S_["mm"].match_pairs_device(fs_, fs_, prs, w, h, 15.0, ssf, S_["asg"].data_ptr(), S_["cnt"].data_ptr(), daf.data_ptr(), st)
             res = {}
             for name, full in (("extract_stereo_match", True), ("extract_only", False)):
-                one(full); one(full); torch.cuda.synchronize()
+                for _ in range(NSETS):
+                    one(full)
+                torch.cuda.synchronize()
                 reps_ = max(args.steps // 2, 4)
                 t_ = time.perf_counter()
                 for _ in range(reps_):
@@ -610,15 +616,17 @@ def main():
             A_ = algorithmic_bytes_extract(w, h, nf)
             res.update({"workload": label, "stereo_pairs_per_step": n_pairs, "keypoints_per_image": float(sets[0]["nL"].float().mean().item()),
                         "stereo_measurements_per_pair": float(sets[0]["kept"].float().mean().item()), "matches_per_left_pair": float(sets[0]["cnt"].float().mean().item()),
-                        "algorithmic_bytes_per_image": A_, "pipelining": "step k's association + search overlap step k+1's extraction (two buffer sets)",
+                        "algorithmic_bytes_per_image": A_, "pipelining": "%d lanes (handle pair + matchers + one stream each) take consecutive steps; a step's extraction, association and search run back to back on its lane" % NSETS,
                         "pipeline_frac_of_hbm_peak": A_ * 2 * n_pairs / (res["extract_stereo_match"]["ms_per_step"] * 1e-3) / HBM_PEAK})
             del sets
             return res
-        out["config3"] = stereo_config(1241, 376, 2000, 128, "KITTI-00-size 1241x376 stereo, 2000 feat/image: extract L+R, computeStereoMatches (as the reference writes it), consecutive left-frame search")
-        out["config4"] = stereo_config(752, 480, 1000, 64, "EuRoC-MH-size 752x480 stereo batch, 1000 feat/image, one GPU's share: extract L+R, computeStereoMatches, consecutive left-frame search")
+        if not only or "config3" in only:
+            out["config3"] = stereo_config(1241, 376, 2000, 128, "KITTI-00-size 1241x376 stereo, 2000 feat/image: extract L+R, computeStereoMatches (as the reference writes it), consecutive left-frame search")
+        if not only or "config4" in only:
+            out["config4"] = stereo_config(752, 480, 1000, 64, "EuRoC-MH-size 752x480 stereo batch, 1000 feat/image, one GPU's share: extract L+R, computeStereoMatches, consecutive left-frame search")
 
     # ---- brute-force N x M Hamming top-2 (north_star; SURVEY 8d secondary figure, against the integer-VALU peak) -------------------
-    if extras and hasattr(y.OrbMatcher, "hamming_topk_device"):
+    if want("rest") and hasattr(y.OrbMatcher, "hamming_topk_device"):
         NB_ = min(F - 1, 255)
         mb = y.OrbMatcher(device=local_rank)
         d_best = torch.zeros((NB_, cap, 6), dtype=torch.int32, device=dev)

@@ -58,8 +58,12 @@ typedef struct YdExtractorConfig {
   int32_t min_fast_thr;  /* accepted and, like the reference (:318), replaced by ini_fast_thr */
   int32_t device;        /* HIP device ordinal */
   int32_t max_batch;     /* frames per launch the scratch is sized for (>=1) */
-  int32_t reserved;
+  int32_t flags;         /* YDORB_EXTRACTOR_* (0 = defaults) */
 } YdExtractorConfig;
+/* Every launch of a call goes on the one stream the call runs on (the quad-tree launches otherwise use two side streams of the handle
+ * and overlap the blur: ~5 % faster alone).  For callers that pipeline several handles on several streams: the device has 4 hardware
+ * queues, streams share them round-robin, and a side stream that lands behind another stream's long kernel stalls its handle. */
+#define YDORB_EXTRACTOR_SINGLE_STREAM 1
 
 typedef struct ydorb_extractor ydorb_extractor_t;
 

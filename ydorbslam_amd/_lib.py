@@ -30,7 +30,7 @@ class YdKeyPoint(C.Structure):
 class YdExtractorConfig(C.Structure):
     _fields_ = [("n_features", C.c_int32), ("scale_factor", C.c_float), ("n_levels", C.c_int32),
                 ("ini_fast_thr", C.c_int32), ("min_fast_thr", C.c_int32), ("device", C.c_int32),
-                ("max_batch", C.c_int32), ("reserved", C.c_int32)]
+                ("max_batch", C.c_int32), ("flags", C.c_int32)]
 
 
 # every symbol include/ydorb/c_api.h declares: (restype, argtypes)

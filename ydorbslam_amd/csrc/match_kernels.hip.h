@@ -433,6 +433,9 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
 #else
 #define RS_CLK(i) do { } while (0)
 #endif
+#ifndef YDORB_NO_SETPRIO
+  __builtin_amdgcn_s_setprio(3);   // one wave per call, serial by definition: its latency is the call's latency (see k_stereo)
+#endif
   const CallDev C = calls[blockIdx.x];
   const int nq = call_nq(C);
   const bool bow = C.mode >= 3 && C.mode <= 5;

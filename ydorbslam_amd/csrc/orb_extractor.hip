@@ -694,7 +694,7 @@ int ydorb_extractor_create(const YdExtractorConfig* cfg, ydorb_extractor_t** out
     // A handle for single frames (max_batch <= 8: the adapter's use) keeps one stream per level: its launches are latency bound and the
     // eight units of a frame then run side by side (0.27 ms per extractAndCompute against 0.33 ms with two).
     const char* qtEnv = getenv("YDORB_QT_STREAMS");
-    e->qtInline = qtEnv && atoi(qtEnv) == 0;
+    e->qtInline = (qtEnv && atoi(qtEnv) == 0) || (cfg->flags & YDORB_EXTRACTOR_SINGLE_STREAM);
     const int nQt = std::max(1, std::min(qtEnv ? atoi(qtEnv) : (cfg->max_batch <= 8 ? (int)kMaxLevels : 2), (int)kMaxLevels));
     if (l < nQt) (void)hipStreamCreateWithFlags(&e->qtStream[l], hipStreamNonBlocking);
     else e->qtStream[l] = e->qtStream[l % nQt];

@@ -595,25 +595,29 @@ int ydorb_stereo_matches(ydorb_matcher_t* m, const YdStereoSide* L, const YdSter
     const bool noLists = getenv("YDORB_STEREO_NO_ROW_LISTS") != nullptr;   // diagnostic: force the scan form (tests compare the two)
     if (!noLists && !(flags & YDORB_STEREO_INDEX_BY_KEYPOINT) && bytes <= 120 * 1024 && entries < (1u << 30)) { P.rowLists = (int)entries; ldsReplay = bytes; }
   }
-  HIPCHK(hipMemcpyAsync(m->stereoPar.p, &P, sizeof(P), hipMemcpyHostToDevice, s));
+  // P travels as a kernel argument: an asynchronous copy out of pageable host memory makes the host wait for everything queued on
+  // the stream before it - here the extraction the association waits for - and a caller that pipelines steps would run in lock step
   HIPCHK(hipMemsetAsync(m->stereoCnt.p, 0, sizeof(int) * 4 * nPairs, s));
   HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(P.rightX), 0xBF800000u, nl, s));   // -1.0f, :363-364
   HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(P.depth), 0xBF800000u, nl, s));
   const size_t lds = (size_t)R->cap * 8;
-  const StereoDev* dP = m->stereoPar.as<StereoDev>();
+  const StereoDev& dP = P;
   if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stereo<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (ldsReplay > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stereo<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsReplay));
   if (flags & YDORB_STEREO_INDEX_BY_KEYPOINT)
-    hipLaunchKernelGGL(k_stereo<false>, dim3((L->cap + kStereoChunk - 1) / kStereoChunk, nPairs), dim3(256), lds, s, dP);
-  else
-    hipLaunchKernelGGL(k_stereo<true>, dim3(1, nPairs), dim3(256), ldsReplay, s, dP);
-  hipLaunchKernelGGL(k_stereo_outliers, dim3(nPairs), dim3(256), 0, s, m->stereoPar.as<StereoDev>());
+    hipLaunchKernelGGL(k_stereo<false>, dim3((L->cap + kStereoChunk - 1) / kStereoChunk, nPairs), dim3(256), lds, s, dP, 0, 0);
+  else {
+    // slices of the serial walk (see k_stereo): a batch keeps every launch below ~0.5 ms; a single pair (the adapter's call) is one launch
+    static const int sliceEnv = getenv("YDORB_STEREO_SLICE") ? atoi(getenv("YDORB_STEREO_SLICE")) : 0;
+    const int slice = sliceEnv > 0 ? sliceEnv : (nPairs >= 8 ? 256 : L->cap);
+    for (int k0 = 0; k0 < L->cap; k0 += slice)
+      hipLaunchKernelGGL(k_stereo<true>, dim3(1, nPairs), dim3(256), ldsReplay, s, dP, k0, std::min(k0 + slice, L->cap));
+  }
+  hipLaunchKernelGGL(k_stereo_outliers, dim3(nPairs), dim3(256), 0, s, P);
   HIPCHK(hipGetLastError());
   if (dev) {
     if (nKept) HIPCHK(hipMemcpyAsync(nKept, P.keptOut, sizeof(int) * nPairs, hipMemcpyDeviceToDevice, s));
     if (status) HIPCHK(hipMemcpyAsync(status, P.statusOut, sizeof(int) * nPairs, hipMemcpyDeviceToDevice, s));
-    // the parameter block is read by the kernels after this call returns: it lives in the handle, the next call on the same
-    // handle overwrites it in stream order
     return YDORB_OK;
   }
   HIPCHK(hipMemcpyAsync(rightX, P.rightX, sizeof(float) * nl, hipMemcpyDeviceToHost, s));

@@ -208,11 +208,14 @@ __device__ __forceinline__ void stereo_right_table(const StereoDev& P, int pair,
 
 // grid (REPLAY ? 1 : ceil(capL / kStereoChunk), pairs), 256 threads, dynamic LDS = capR * 8 bytes.  Outputs were set to -1
 // (:363-364) by the host's fill.
+// Replay form in slices: launch [kBegin, kEnd) walks that range of left keypoints and hands the lagging index to the next launch
+// through counters[pair * 4 + 3].  One launch over a whole 2000-keypoint frame is a 3.8 ms single-wave kernel, and everything that
+// shares its hardware queue (the device has 4; streams are mapped onto them round-robin) waits behind it; slices of a few hundred
+// keypoints let the other streams' launches in between.  (The right-keypoint table and the row lists are rebuilt per slice: ~20 us.)
 template <bool REPLAY>
-__global__ __launch_bounds__(256) void k_stereo(const StereoDev* __restrict__ Pp) {
+__global__ __launch_bounds__(256) void k_stereo(const StereoDev P, int kBegin, int kEnd) {   // P by value: a kernel argument, no parameter copy for the stream to wait on
   extern __shared__ unsigned char stereoLds[];
   __shared__ unsigned short candList[4][128];   // per wave: indices of the right keypoints that passed the static tests
-  const StereoDev& P = *Pp;
   const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nL = min(P.nL[pair], P.capL), nR = min(P.nR[pair], P.capR);
   float* rx = reinterpret_cast<float*>(stereoLds);
@@ -273,13 +276,19 @@ __global__ __launch_bounds__(256) void k_stereo(const StereoDev* __restrict__ Pp
   float* outRx = P.rightX + (size_t)pair * P.capL;
   float* outDepth = P.depth + (size_t)pair * P.capL;
   if (REPLAY) {
-    if (wave != 0 || nL == 0) return;
-    int s = 0;
+    if (wave != 0 || nL == 0 || kBegin >= nL) return;
+    // a single wave whose latency is the call's latency: highest issue priority among the waves of its SIMD (the other streams'
+    // throughput kernels fill the CU and would otherwise get 7 of 8 issue slots)
+#ifndef YDORB_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    int s = kBegin > 0 ? P.counters[pair * 4 + 3] : 0;
     // one step ahead: keypoint k + 1 and descriptor row s + 1 (the row the next step needs is s or s + 1)
-    float kx = kl[0].x, ky = kl[0].y;
-    int o = kl[0].octave;
-    uint4 a0 = dl[0], a1 = dl[1];
-    for (int k = 0; k < nL; k++) {
+    float kx = kl[kBegin].x, ky = kl[kBegin].y;
+    int o = kl[kBegin].octave;
+    uint4 a0 = dl[2 * s], a1 = dl[2 * s + 1];
+    const int kStop = min(kEnd, nL);
+    for (int k = kBegin; k < kStop; k++) {
       const int kn = min(k + 1, nL - 1), sn = min(s + 1, nL - 1);
       const float nkx = kl[kn].x, nky = kl[kn].y;
       const int no = kl[kn].octave;
@@ -290,6 +299,7 @@ __global__ __launch_bounds__(256) void k_stereo(const StereoDev* __restrict__ Pp
       if (r.complete) { s++; a0 = n0; a1 = n1; }
       kx = nkx; ky = nky; o = no;
     }
+    if (lane == 0 && kStop < nL) P.counters[pair * 4 + 3] = s;
   } else {
     for (int k = k0 + wave; k < min(k1, nL); k += 4) {
       const StereoRes r = stereo_one(P, pair, kl[k].x, kl[k].y, kl[k].octave, dl[2 * k], dl[2 * k + 1], nR, rx, rinfo, candList[wave], lane);
@@ -306,8 +316,7 @@ __global__ __launch_bounds__(256) void k_stereo(const StereoDev* __restrict__ Pp
 
 // :464-472.  The sorted list is walked from its smallest entry and left at the first one below 2.1 x the median, so the
 // loop removes every measurement when the median block-match minimum is 0 and none otherwise.
-__global__ __launch_bounds__(256) void k_stereo_outliers(const StereoDev* __restrict__ Pp) {
-  const StereoDev& P = *Pp;
+__global__ __launch_bounds__(256) void k_stereo_outliers(const StereoDev P) {
   const int pair = blockIdx.x;
   const int kept = P.counters[pair * 4 + 0], zeros = P.counters[pair * 4 + 1];
   if (threadIdx.x == 0) {

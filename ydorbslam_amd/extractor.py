@@ -15,10 +15,10 @@ def _p(a):
 class OrbExtractor:
     """OrbExtractor(nFeatures, scaleFactor, nLevels, iniThFAST, minThFAST) — orbExtractor.cpp:315."""
 
-    def __init__(self, n_features=1000, scale_factor=1.2, n_levels=8, ini_th=20, min_th=7, device=0, max_batch=1):
+    def __init__(self, n_features=1000, scale_factor=1.2, n_levels=8, ini_th=20, min_th=7, device=0, max_batch=1, single_stream=False):
         self._L = lib()
         self._h = C.c_void_p()
-        cfg = YdExtractorConfig(n_features, scale_factor, n_levels, ini_th, min_th, device, max_batch, 0)
+        cfg = YdExtractorConfig(n_features, scale_factor, n_levels, ini_th, min_th, device, max_batch, 1 if single_stream else 0)   # YDORB_EXTRACTOR_SINGLE_STREAM
         check(self._L.ydorb_extractor_create(C.byref(cfg), C.byref(self._h)))
         self.n_levels = n_levels
         self.max_keypoints = self._L.ydorb_extractor_max_keypoints(self._h)
