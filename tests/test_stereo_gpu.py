@@ -219,3 +219,19 @@ def test_replay_with_and_without_row_lists(oracle_lib, monkeypatch):
     for got in (a, b):
         assert got[2][0] == okept and got[3][0] == ostatus
         assert np.array_equal(got[0][0].view(np.uint32), orx.view(np.uint32)) and np.array_equal(got[1][0].view(np.uint32), odepth.view(np.uint32))
+
+
+def test_row_lists_that_outgrow_their_reserved_room_fall_back_to_the_scan(oracle_lib):
+    """The LDS room for the per-row candidate lists is sized from the right extractor's level quotas (expected total + 25 %), not
+    for the worst case.  Right keypoints that all claim the top level (17 rows each instead of ~8 on average) overflow it: the pair must
+    then take the scan form by itself and still give the reference's result."""
+    import ydorbslam_amd as y
+    left, right, _ = synth_stereo_pair(640, 480, 43)
+    ex = y.OrbExtractor(1000, max_batch=2)
+    (kl, dl), (kr, dr) = ex.extract_batch(np.stack([left, right]))
+    kr2 = kr.copy()
+    kr2["octave"] = 7
+    got = y.OrbMatcher().stereo_matches(ex, ex, kl[None], dl[None], [len(kl)], kr2[None], dr[None], [len(kr2)], BF, B, left_frames=(0, 1), right_frames=(1, 1))
+    _, (orx, odepth, okept, ostatus) = _oracle_pair(oracle_lib, left, right, 1000, kl=kl, dl=dl, kr=kr2, dr=dr)
+    assert got[2][0] == okept and got[3][0] == ostatus
+    assert np.array_equal(got[0][0].view(np.uint32), orx.view(np.uint32)) and np.array_equal(got[1][0].view(np.uint32), odepth.view(np.uint32))

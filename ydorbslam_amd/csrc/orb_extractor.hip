@@ -623,6 +623,7 @@ int ydorb::extractor_pyramid_view(const ydorb_extractor* e, PyramidView* v) {
     v->roi[l] = e->d_pyr + L.padOff + (size_t)kPad * L.pitch + kPad;
     v->w[l] = L.w; v->h[l] = L.h; v->pitch[l] = L.pitch;
     v->scale[l] = e->sf[l]; v->invScale[l] = e->isf[l];
+    v->quota[l] = e->perLevel[l];
   }
   return YDORB_OK;
 }

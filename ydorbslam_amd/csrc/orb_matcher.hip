@@ -590,8 +590,16 @@ int ydorb_stereo_matches(ydorb_matcher_t* m, const YdStereoSide* L, const YdSter
   // replay form: room for the per-row candidate lists in LDS: every right keypoint covers at most 2*ceil(2*scale)+1 rows
   size_t ldsReplay = (size_t)R->cap * 8;
   {
+    // Room for the lists: a right keypoint of level l sits in 2 ceil(2 scale_l) + 1 rows (:372-377).  The worst case (every keypoint on
+    // the top level) is 80 KB at 2000 features and leaves one workgroup per CU - two such calls then fill the chip and everything
+    // else waits; the right extractor's level quotas give the expected total (+ 25 %), about half of that.  A pair whose lists do not
+    // fit at run time takes the scan form (same result).
     const int band = 2 * (int)std::ceil(2.0f * vl.scale[vl.nLevels - 1]) + 2;
-    const size_t entries = (size_t)R->cap * band, bytes = (size_t)R->cap * 8 + sizeof(int) * (2 * (size_t)vl.h[0] + 1) + 2 * entries + 16;
+    size_t expect = 0, quotaSum = 0;
+    for (int l = 0; l < vr.nLevels; l++) { expect += (size_t)vr.quota[l] * (2 * (size_t)std::ceil(2.0f * vr.scale[l]) + 1); quotaSum += (size_t)vr.quota[l]; }
+    if (quotaSum > 0) expect = expect * (size_t)R->cap / quotaSum;
+    const size_t entries = std::min((size_t)R->cap * band, expect + expect / 4 + 256);
+    const size_t bytes = (size_t)R->cap * 8 + sizeof(int) * (2 * (size_t)vl.h[0] + 1) + 2 * entries + 16;
     const bool noLists = getenv("YDORB_STEREO_NO_ROW_LISTS") != nullptr;   // diagnostic: force the scan form (tests compare the two)
     if (!noLists && !(flags & YDORB_STEREO_INDEX_BY_KEYPOINT) && bytes <= 120 * 1024 && entries < (1u << 30)) { P.rowLists = (int)entries; ldsReplay = bytes; }
   }
@@ -607,9 +615,9 @@ int ydorb_stereo_matches(ydorb_matcher_t* m, const YdStereoSide* L, const YdSter
   if (flags & YDORB_STEREO_INDEX_BY_KEYPOINT)
     hipLaunchKernelGGL(k_stereo<false>, dim3((L->cap + kStereoChunk - 1) / kStereoChunk, nPairs), dim3(256), lds, s, dP, 0, 0);
   else {
-    // slices of the serial walk (see k_stereo): a batch keeps every launch below ~0.5 ms; a single pair (the adapter's call) is one launch
+    // slices of the serial walk (see k_stereo): a batch keeps every launch below ~2 ms; a single pair (the adapter's call) is one launch
     static const int sliceEnv = getenv("YDORB_STEREO_SLICE") ? atoi(getenv("YDORB_STEREO_SLICE")) : 0;
-    const int slice = sliceEnv > 0 ? sliceEnv : (nPairs >= 8 ? 256 : L->cap);
+    const int slice = sliceEnv > 0 ? sliceEnv : (nPairs >= 8 ? 1024 : L->cap);
     for (int k0 = 0; k0 < L->cap; k0 += slice)
       hipLaunchKernelGGL(k_stereo<true>, dim3(1, nPairs), dim3(256), ldsReplay, s, dP, k0, std::min(k0 + slice, L->cap));
   }

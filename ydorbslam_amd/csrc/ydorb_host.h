@@ -16,6 +16,7 @@ struct PyramidView {
   const uint8_t* roi[8];
   int w[8], h[8], pitch[8];
   float scale[8], invScale[8];
+  int quota[8];   // keypoints per level the extractor returns at most (m_v_keyPointsNumsPerLevel)
   void* stream;
 };
 int extractor_pyramid_view(const ydorb_extractor* e, PyramidView* out);
