@@ -394,6 +394,9 @@ typedef struct YdBaOptions {
  * information), Huber kernels optional (_bIsRobust) and delta_mono = (double)(float)sqrt(5.99) — note 5.99, :37. */
 #define YDORB_BA_SINGLE_STAGE 1
 #define YDORB_BA_NO_ROBUST 2
+/* fill YdBaResult.ms_errors .. ms_update: a pair of stream events round every phase of every LM trial, ~10 us of stream time each
+ * (8 % of a 100-keyframe solve), so the breakdown is opt-in; ms_total is always measured */
+#define YDORB_BA_PHASE_TIMES 4
 
 typedef struct YdBaResult {
   int32_t n_trials;              /* LM trials executed (each = linearise/Schur/solve/update/chi2) */

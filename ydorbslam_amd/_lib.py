@@ -103,7 +103,7 @@ class YdBaOptions(C.Structure):
                 ("rank", _I), ("world", _I), ("flags", _I), ("reserved", _I)]
 
 
-BA_SINGLE_STAGE, BA_NO_ROBUST = 1, 2
+BA_SINGLE_STAGE, BA_NO_ROBUST, BA_PHASE_TIMES = 1, 2, 4
 
 
 class YdBaResult(C.Structure):

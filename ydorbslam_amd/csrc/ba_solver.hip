@@ -81,6 +81,7 @@ struct Run {
   int cur = 0;  // which of poses[2]/pts[2] holds the current estimate
   bool noRobust = false;   // YDORB_BA_NO_ROBUST
   Cam cam;
+  bool phaseTimes = false;   // YDORB_BA_PHASE_TIMES
   double phaseMs[PH_COUNT] = {0, 0, 0, 0, 0};
   bool pending[PH_COUNT] = {false, false, false, false, false};
   struct Sys { std::vector<int> act; int nL = 0, nPf = 0, Ea = 0, n = 0, nb = 0, nBlkE = 0, nBuckets = 0; } sys;   // stage 1's system, re-used by stage 2
@@ -108,7 +109,8 @@ static void trace(const char* what) {
 
 struct PhaseTimer {
   Run& r; int ph; hipEvent_t a, b; bool on;
-  PhaseTimer(Run& r_, int ph_) : r(r_), ph(ph_), a(r_.c->ev[2 * ph_]), b(r_.c->ev[2 * ph_ + 1]), on(true) {
+  PhaseTimer(Run& r_, int ph_) : r(r_), ph(ph_), a(r_.c->ev[2 * ph_]), b(r_.c->ev[2 * ph_ + 1]), on(r_.phaseTimes) {
+    if (!on) return;   // YDORB_BA_PHASE_TIMES not asked for: no events on the stream
     collect(r_, ph_);  // an earlier recording of this phase's events must be read before they are re-recorded
     (void)hipEventRecord(a, r.c->stream);
   }
@@ -441,6 +443,7 @@ int beginSolve(Run& R_) {
   const int K = P->n_poses, NP = P->n_points;
   int rc;
   R_.noRobust = (O.flags & YDORB_BA_NO_ROBUST) != 0;
+  R_.phaseTimes = (O.flags & YDORB_BA_PHASE_TIMES) != 0;
   R_.cam = Cam{P->fx, P->fy, P->cx, P->cy, P->bf};
   for (int i = 0; i < 2; i++)
     if ((rc = c.poses[i].ensure(sizeof(double) * 7 * K)) || (rc = c.pts[i].ensure(sizeof(double) * 3 * NP))) return rc;

@@ -14,10 +14,14 @@ def _p(a):
 
 class Optimizer:
     @staticmethod
-    def default_options(device=0):
+    def default_options(device=0, phase_times=False):
+        """phase_times: also fill the per-phase device times of the result (YDORB_BA_PHASE_TIMES: event pairs on the stream, ~8 % slower)."""
+        from ._lib import BA_PHASE_TIMES
         o = YdBaOptions()
         lib().ydorb_ba_default_options(C.byref(o))
         o.device = device
+        if phase_times:
+            o.flags |= BA_PHASE_TIMES
         return o
 
     @staticmethod
