@@ -363,27 +363,30 @@ def main():
     # 4-byte access pattern by 1.33x, calibrated on k_pyr_level0's known read size; WRITE_SIZE is exact), scaled to this run's frames
     # per launch; `traffic_source` names the file.
     traffic, valu_busy, traffic_source = None, None, None
-    stage_kernels = {"pyramid": ("k_pyr_level0", "k_pyr_resize", "k_pyr_borders"), "fast_cells": ("k_fast_cells",), "blur": ("k_blur",),
-                     "quadtree_after_blur": ("k_quadtree_flat", "k_quadtree"), "orient_describe": ("k_orient_describe",)}
+    # a stage's kernels = the rows of the counter CSV whose name starts with one of these (k_pyr_level0_f / k_pyr_resize_f, or the
+    # interior-only kernels + k_pyr_borders of a plan that cannot fuse its pads; k_orient_describe or k_orient_describe_n)
+    stage_kernels = {"pyramid": ("k_pyr_",), "fast_cells": ("k_fast_cells",), "blur": ("k_blur",),
+                     "quadtree_after_blur": ("k_quadtree",), "orient_describe": ("k_orient_describe",)}
     # The roofline line names the dominant EXTRACTOR kernel: the stage timers of the two pipelines overlap, and of the matcher's stages
     # the resolve is serial by definition (one wave per pair) - neither is a bandwidth figure.
     try:
         import csv
-        for tag in ("r02", "r01f"):
+        for tag in ("r02d", "r02", "r01f"):
             pth = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic.csv" % tag)
             if not os.path.exists(pth):
                 continue
             rows = {r["kernel"]: r for r in csv.DictReader(open(pth))}
-            if dom in stage_kernels and all(k in rows for k in stage_kernels[dom]):
+            mine = [k for k in rows if dom in stage_kernels and k.startswith(stage_kernels[dom])]
+            if mine:
                 per_frame = sum(float(rows[k]["fetch_MB_per_frame_raw"]) * float(rows[k].get("fetch_correction") or 1.33) + float(rows[k]["write_MB_per_frame"])
-                                for k in stage_kernels[dom])
+                                for k in mine)
                 traffic = per_frame * 1e6 * FL
                 traffic_source = ("profiles/%s_pmc_hbm_traffic.csv (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the extractor alone, FETCH calibrated "
                                   "on k_pyr_level0's known read size, per frame, scaled to %d frames per launch; not collected in this run)" % (tag, FL))
             pth2 = os.path.join(ROOT, "profiles", "%s_pmc_sq_valu.csv" % tag)
             if os.path.exists(pth2):
                 for r in csv.DictReader(open(pth2)):
-                    if dom in stage_kernels and r["kernel"] == stage_kernels[dom][0]:
+                    if dom in stage_kernels and r["kernel"].startswith(stage_kernels[dom]) and valu_busy is None:
                         valu_busy = float(r["VALU_busy_pct_of_SIMD_cycles"]) / 100.0
             if traffic is not None:
                 break
@@ -393,6 +396,10 @@ def main():
                 "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source, "valu_busy_frac": valu_busy,
                 "valu_busy_source": traffic_source and traffic_source.replace("hbm_traffic", "sq_valu"),
                 "pipeline_achieved_GBps": A_frame * F * args.steps / dt / 1e9, "pipeline_frac": A_frame * F * args.steps / dt / HBM_PEAK,
+                "stage_note": "a stage = every launch of its kernels in one extractor call over frames_per_extract_launch frames (fast_cells: two launches, "
+                              "level 0 then levels 1-7; pyramid: one launch per level), HIP events on the launch stream IN the pipelined run, where a "
+                              "second lane's kernels share the GPU (isolated = the same call with nothing else running); profiles/*_512frame_launches.txt "
+                              "has rocprofv3's per-launch durations of the same command",
                 "stage_ms_per_launch": {k: round(v, 4) for k, v in stages.items()},
                 "stage_ms_per_launch_isolated": {k: round(v, 4) for k, v in isolated.items()},
                 "frames_per_extract_launch": FL, "pairs_per_match_launch": NPAIR}

@@ -19,7 +19,8 @@ def last(name, counter):
         res[k] = sum(v[i] for i in ids[-n_per_batch:])
     return res
 fe, wr = last("fetch", "FETCH_SIZE"), last("write", "WRITE_SIZE")
-corr = (640 * 480 * frames) / (fe["k_pyr_level0"] * 1024.0)
+lvl0 = "k_pyr_level0_f" if "k_pyr_level0_f" in fe else "k_pyr_level0"   # the level-0 kernel of the plan in use
+corr = (640 * 480 * frames) / (fe[lvl0] * 1024.0)
 with open(out + "_pmc_hbm_traffic.csv", "w") as f:
     w = csv.writer(f)
     w.writerow(["kernel", "fetch_MB_per_frame_raw", "write_MB_per_frame", "fetch_correction", "frames_per_launch"])
