@@ -169,31 +169,57 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
 }
 
 constexpr int kSlot = 64;
+#ifndef GATHER_QPW
+#define GATHER_QPW 1
+#endif
+constexpr int kGatherQpw = GATHER_QPW;   // queries per wave (measured per 511 pairs x 1000 queries: 1 -> 0.268 ms, 2 -> 0.276, 4 -> 0.327: the registers of
+                                          // several queries in flight cost more occupancy than the prefetched window look-up saves)
 __global__ __launch_bounds__(256) void k_gather_projection(const CallDev* __restrict__ calls, const FrameDev* __restrict__ frames,
                                                            int maxQ, uint32_t* __restrict__ pool, unsigned* __restrict__ poolHeads,
                                                            unsigned poolPerCall, int* __restrict__ status) {
   __shared__ int pref[4][64];
   __shared__ int sStart[4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int q = blockIdx.x * 4 + wv;
+  const int q0 = (blockIdx.x * 4 + wv) * kGatherQpw;
   const CallDev C = calls[blockIdx.y];
-  if (q >= maxQ || q >= call_nq(C)) return;
+  const int nqAll = min(maxQ, call_nq(C));
+  if (q0 >= nqAll) return;
   const FrameDev F = frames[C.frame];
-  const QueryDev Q = C.queries[q];
-  int2 info = make_int2(0, 0);
-  if (Q.flags & 1) {
+  // A wave walks kGatherQpw consecutive queries; the cell bounds of the next query are requested before the current one is processed.
+  QueryDev Qs[kGatherQpw];
+#pragma unroll
+  for (int i = 0; i < kGatherQpw; i++) Qs[i] = C.queries[min(q0 + i, nqAll - 1)];
+  struct Window { bool ok; int nx, start, cnt; };
+  auto window = [&](const QueryDev& Q) -> Window {
+    Window W{false, 0, 0, 0};
+    if (!(Q.flags & 1)) return W;
     const int minCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.u, F.minX), Q.r), F.gridWInv)));
     const int maxCellX = min(kGridCols - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.u, F.minX), Q.r), F.gridWInv)));
     const int minCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.v, F.minY), Q.r), F.gridHInv)));
     const int maxCellY = min(kGridRows - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.v, F.minY), Q.r), F.gridHInv)));
-    if (minCellX < kGridCols && maxCellX >= 0 && minCellY < kGridRows && maxCellY >= 0 && minCellX <= maxCellX && minCellY <= maxCellY) {
-      const int nx = maxCellX - minCellX + 1;  // <= 64
-      int start = 0, cnt = 0;
-      if (lane < nx) {
-        const int c0 = (minCellX + lane) * kGridRows;
-        start = F.cellStart[c0 + minCellY];
-        cnt = F.cellStart[c0 + maxCellY + 1] - start;
-      }
+    if (!(minCellX < kGridCols && maxCellX >= 0 && minCellY < kGridRows && maxCellY >= 0 && minCellX <= maxCellX && minCellY <= maxCellY)) return W;
+    W.ok = true;
+    W.nx = maxCellX - minCellX + 1;  // <= 64
+    if (lane < W.nx) {
+      const int c0 = (minCellX + lane) * kGridRows;
+      W.start = F.cellStart[c0 + minCellY];
+      W.cnt = F.cellStart[c0 + maxCellY + 1] - W.start;
+    }
+    return W;
+  };
+  Window Wn = window(Qs[0]);
+#pragma unroll
+  for (int qi = 0; qi < kGatherQpw; qi++) {
+  const int q = q0 + qi;
+  if (q >= nqAll) break;
+  const QueryDev Q = Qs[qi];
+  const Window Wc = Wn;
+  if (qi + 1 < kGatherQpw && q + 1 < nqAll) Wn = window(Qs[qi + 1]);
+  int2 info = make_int2(0, 0);
+  if (Wc.ok) {
+    {
+      const int nx = Wc.nx;
+      const int start = Wc.start, cnt = Wc.cnt;
       int incl = cnt;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
@@ -304,6 +330,8 @@ __global__ __launch_bounds__(256) void k_gather_projection(const CallDev* __rest
     }
   }
   if (lane == 0) C.qInfo[q] = info;
+  __builtin_amdgcn_wave_barrier();   // pref / sStart are reused by the wave's next query
+  }
 }
 
 // BoW family, phase 1: the candidate list of a query is a vocabulary-node bucket of the other frame

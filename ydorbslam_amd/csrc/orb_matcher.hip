@@ -259,7 +259,7 @@ static int searchProjectionImpl(ydorb_matcher_t* m, int32_t mode, const YdFrameV
     C.count = m->misc.as<int>() + 2; C.mode = mode; C.ratio = ratio; C.orbDist = orbDist; C.checkOri = checkOri;
     for (int i = 0; i < 8; i++) C.invSigma2[i] = (invSigma2 && i < nLevels) ? invSigma2[i] : 0.f;
     HIPCHK(hipMemcpyAsync(m->calls.p, &C, sizeof(CallDev), hipMemcpyHostToDevice, m->stream));
-    hipLaunchKernelGGL(k_gather_projection, dim3((nq + 3) / 4, 1), dim3(256), 0, m->stream, m->calls.as<CallDev>(), m->frames.as<FrameDev>(), nq,
+    hipLaunchKernelGGL(k_gather_projection, dim3((nq + 4 * kGatherQpw - 1) / (4 * kGatherQpw), 1), dim3(256), 0, m->stream, m->calls.as<CallDev>(), m->frames.as<FrameDev>(), nq,
                        m->pool.as<uint32_t>(), m->misc.as<unsigned>(), (unsigned)((size_t)nq * kSlot + m->poolRecords), m->misc.as<int>() + 1);
     int hmisc[3];
     if (!recordsOut) {
@@ -717,7 +717,7 @@ int ydorb_match_pairs_device(ydorb_matcher_t* m, const YdFrameSetDev* Q, const Y
                      nLevels, minX, maxX, minY, maxY);
   { const int rcg = launchGridBuild(nFrames, cap, s, m->frames.as<FrameDev>()); if (rcg) return rcg; }
   if (prof) HIPCHK(hipEventRecord(m->ev[1], s));
-  hipLaunchKernelGGL(k_gather_projection, dim3((cap + 3) / 4, nCalls), dim3(256), 0, s, m->calls.as<CallDev>(), m->frames.as<FrameDev>(), cap,
+  hipLaunchKernelGGL(k_gather_projection, dim3((cap + 4 * kGatherQpw - 1) / (4 * kGatherQpw), nCalls), dim3(256), 0, s, m->calls.as<CallDev>(), m->frames.as<FrameDev>(), cap,
                      m->pool.as<uint32_t>(), m->heads.as<unsigned>(), (unsigned)poolPerCall, m->misc.as<int>() + 1);
   if (prof) HIPCHK(hipEventRecord(m->ev[2], s));
   const int takenWords = (cap + 31) / 32;
