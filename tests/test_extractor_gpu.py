@@ -264,3 +264,27 @@ def test_read_pyramid_single_transfer_equals_level_reads():
         assert len(lv) == 8
         for l in range(8):
             assert np.array_equal(lv[l], ex.read_level(l, f)), "frame %d level %d" % (f, l)
+
+
+@pytest.mark.parametrize("w,h,nf,grouped", [(640, 480, 1000, "0"), (752, 480, 1000, "0"), (640, 480, 1000, "1")])
+def test_batched_handle_paths_match_the_oracle(oracle_lib, monkeypatch, w, h, nf, grouped):
+    """A handle for more than 8 frames per call takes the throughput paths the headline bench runs: FAST cells launched in two level
+    groups, four keypoints per wave in the descriptor kernel, 64 x 58 blur tiles and - with YDORB_QT_GROUPED=1 - one quad-tree launch per
+    level group (k_quadtree_flat_levels) instead of one per level.  Twelve frames of
+    mixed content (textured, half empty, nearly empty) - twice, so that the second call runs with the retuned quad-tree footprints -
+    against the oracle, frame by frame."""
+    import ydorbslam_amd as y
+    from oracle.orb_oracle import OrbExtractorOracle
+    frames = [synth_frame(w, h, 50 + i) for i in range(12)]
+    frames[3] = frames[3].copy(); frames[3][: h // 2] = 128
+    frames[7] = np.full((h, w), 90, np.uint8); frames[7][100:150, 100:160] = synth_frame(w, h, 63)[100:150, 100:160]
+    imgs = np.stack(frames)
+    monkeypatch.setenv("YDORB_QT_GROUPED", grouped)
+    gpu = y.OrbExtractor(nf, 1.2, 8, 20, 7, max_batch=12)
+    monkeypatch.delenv("YDORB_QT_GROUPED")
+    gpu.extract_batch(imgs)
+    res = gpu.extract_batch(imgs)
+    for f, img in enumerate(frames):
+        ck, cd = OrbExtractorOracle(nf, 1.2, 8, 20, 7).extract(img)
+        _same_kps(res[f][0], ck)
+        assert np.array_equal(res[f][1], cd)

@@ -48,7 +48,12 @@ struct PlanDev {
   int borderBegin[kMaxLevels + 1];     // first border thread of each level in k_pyr_borders' flat per-frame list (multiples of 256)
   LevelDev lv[kMaxLevels];
 };
-constexpr int kBlurTW = 64, kBlurTH = 32;
+#ifndef BLUR_TH
+#define BLUR_TH 58
+#endif
+// 64 x 58 tiles: 58 + 6 = 64 source rows are 32 row pairs x 16 dword groups = exactly two full passes of the workgroup in the horizontal
+// stage (the 32-row tile of before ran 304 tasks on 2 x 256 threads) and the 6-row halo weighs 10 % instead of 19 %
+constexpr int kBlurTW = 64, kBlurTH = BLUR_TH;
 struct CellDev {            // FAST sub-image [x0,x1) x [y0,y1) in level coordinates (orbExtractor.cpp:562-581)
   short level, x0, y0, x1, y1, pad0;
   int srcOff;               // byte offset of the sub-image's first pixel inside a frame's pyramid block (host-computed)
@@ -828,10 +833,10 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 }
 
 template <int ITEMS>
-__global__ __launch_bounds__(kQtFlatThreads) void k_quadtree_flat(PlanDev P, const uint32_t* __restrict__ cellCount,
-                                                                  const uint32_t* __restrict__ cellCand, int level,
-                                                                  uint32_t* __restrict__ lvlKp, int* __restrict__ lvlCount,
-                                                                  uint8_t* __restrict__ needPass, int* __restrict__ lvlMaxN) {
+__device__ __forceinline__ void qt_flat_unit(const PlanDev& P, const uint32_t* __restrict__ cellCount,
+                                             const uint32_t* __restrict__ cellCand, int level, int frame,
+                                             uint32_t* __restrict__ lvlKp, int* __restrict__ lvlCount,
+                                             uint8_t* __restrict__ needPass, int* __restrict__ lvlMaxN) {
   constexpr int NT = kQtFlatThreads, CAP = NT * ITEMS;
   using Sort = rocprim::block_radix_sort<uint32_t, NT, ITEMS, uint32_t>;
   static_assert(sizeof(typename Sort::storage_type) + 4 * NT <= kQtFlatUnion && 4 * CAP <= kQtFlatUnion, "union region too small");
@@ -840,7 +845,7 @@ __global__ __launch_bounds__(kQtFlatThreads) void k_quadtree_flat(PlanDev P, con
   __shared__ unsigned long long w64[16];
   __shared__ unsigned long long sRed[4];
   __shared__ int sDiff[kQtPairDepth + 3], sLeaf[kQtPairDepth + 2];
-  const int f = blockIdx.x, tid = threadIdx.x;
+  const int f = frame, tid = threadIdx.x;
   const LevelDev L = P.lv[level];
   QT_LDS uint32_t* cand = (QT_LDS uint32_t*)smem;
   uint8_t* un = smem + 4 * CAP;
@@ -1134,6 +1139,35 @@ __global__ __launch_bounds__(kQtFlatThreads) void k_quadtree_flat(PlanDev P, con
   if (tid == 0) { needPass[unit] = 0; lvlCount[unit] = nOut; }
 }
 
+// one launch per level (single-frame handles: each level on its own stream) ...
+template <int ITEMS>
+__global__ __launch_bounds__(kQtFlatThreads) void k_quadtree_flat(PlanDev P, const uint32_t* __restrict__ cellCount,
+                                                                  const uint32_t* __restrict__ cellCand, int level,
+                                                                  uint32_t* __restrict__ lvlKp, int* __restrict__ lvlCount,
+                                                                  uint8_t* __restrict__ needPass, int* __restrict__ lvlMaxN) {
+  qt_flat_unit<ITEMS>(P, cellCount, cellCand, level, blockIdx.x, lvlKp, lvlCount, needPass, lvlMaxN);
+}
+// ... or ONE launch for a range of levels (YDORB_QT_GROUPED=1): grid (frames, levels), the big levels first.  Each level runs the
+// instantiation its candidate counts ask for, but the launch's LDS is the largest of them, which costs more occupancy than the shorter
+// launch chain gains (measured: 178 against 190 Mkeypoints/s in the two-lane pipeline) - kept as an option, off by default.
+struct QtItems { int items[kMaxLevels]; };
+__global__ __launch_bounds__(kQtFlatThreads) void k_quadtree_flat_levels(PlanDev P, const uint32_t* __restrict__ cellCount,
+                                                                         const uint32_t* __restrict__ cellCand, int levelFirst, QtItems it,
+                                                                         uint32_t* __restrict__ lvlKp, int* __restrict__ lvlCount,
+                                                                         uint8_t* __restrict__ needPass, int* __restrict__ lvlMaxN) {
+  const int level = levelFirst + blockIdx.y, frame = blockIdx.x;
+  int items = 0;
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; l++) if (l == level) items = it.items[l];
+  switch (items) {
+    case 2: qt_flat_unit<2>(P, cellCount, cellCand, level, frame, lvlKp, lvlCount, needPass, lvlMaxN); break;
+    case 4: qt_flat_unit<4>(P, cellCount, cellCand, level, frame, lvlKp, lvlCount, needPass, lvlMaxN); break;
+    case 8: qt_flat_unit<8>(P, cellCount, cellCand, level, frame, lvlKp, lvlCount, needPass, lvlMaxN); break;
+    case 12: qt_flat_unit<12>(P, cellCount, cellCand, level, frame, lvlKp, lvlCount, needPass, lvlMaxN); break;
+    default: qt_flat_unit<16>(P, cellCount, cellCand, level, frame, lvlKp, lvlCount, needPass, lvlMaxN); break;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // cv::GaussianBlur(level, 7x7, sigma 2, BORDER_REFLECT_101) in OpenCV's 8.8 fixed-point form
 // (orbExtractor.cpp:385-386).  The pyramid's own 19-px reflect-101 pad supplies the border.
@@ -1199,8 +1233,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, s
   __syncthreads();
   const int c4 = (threadIdx.x & 15) * 4;
 #pragma unroll
-  for (int half = 0; half < 2; half++) {
-    const int r = (threadIdx.x >> 4) + 16 * half;
+  for (int r = threadIdx.x >> 4; r < TH; r += 16) {
     const int gy = y0 + r;
     if (!(gy < L.h && x0 + c4 < L.blurPitch)) continue;
     // rows r .. r+6 live in row pairs r/2 .. r/2+3; an odd r starts in the upper half of its first pair

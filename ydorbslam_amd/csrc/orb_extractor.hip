@@ -63,6 +63,7 @@ struct ydorb_extractor {
   hipEvent_t evFork = nullptr, evJoin[kMaxLevels]{};
   hipEvent_t evFast[kMaxLevels]{};      // end of the FAST launch that covers level l (levels are launched in groups)
   int descKpw = 2;                      // keypoints per wave of k_orient_describe_n
+  bool qtGrouped = false;               // batched handles: one quad-tree launch per FAST level group instead of one per level
   bool qtInline = false;                // YDORB_QT_STREAMS=0: the quad-tree launches go on the caller's stream, behind the blur
   int fastGroups = 1;                   // FAST launches per call: 1 = all levels together
   HostPlan plan;
@@ -433,6 +434,7 @@ int ensurePlan(ydorb_extractor* e, int w, int h, int nFrames) {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_flat<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFlat));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_flat<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFlat));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_flat<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFlat));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_flat_levels), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFlat));
     }
   }
   e->planValid = true;
@@ -501,6 +503,7 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   }
   if (prof) HIPCHK(hipEventRecord(e->ev[1], s));
   hipEvent_t fastEv[kMaxLevels]{};
+  int grpFirst[kMaxLevels]{}, grpEnd[kMaxLevels]{}, nGroups = 0;   // level ranges of the FAST launches
   if (D.nCellsTotal > 0) {
     // one wave per cell, 4 cells per workgroup; the per-wave LDS (tile, score map, candidate list) is sized for the plan's largest cell
     const int maxT = P.maxCellDim + 6, maxB = P.maxCellDim;
@@ -529,6 +532,7 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
       }
       HIPCHK(hipEventRecord(e->evFast[l0], s));
       fastEv[l0] = e->evFast[l0];
+      grpFirst[nGroups] = l0; grpEnd[nGroups] = l1; nGroups++;
       for (int l = l0 + 1; l < l1; l++) fastEv[l] = e->evFast[l0];
       l0 = l1;
     }
@@ -540,6 +544,25 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   hipLaunchKernelGGL(k_blur, dim3((D.blurTileBegin[D.nLevels] + 7) / 8 * 8, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
                      P.blurFrameStride, D);
   bool anyFlat = false;
+  bool grouped = e->qtGrouped && !e->forcePassQuadtree && nGroups > 0;
+  for (int l = 0; l < D.nLevels && grouped; l++) grouped = P.qt[l].flatItems > 0;
+  if (grouped) {
+    // one quad-tree launch per FAST level group (k_quadtree_flat_levels), on the side streams in turn
+    for (int g = 0; g < nGroups; g++) {
+      const int l0 = grpFirst[g], l1 = grpEnd[g];
+      const hipStream_t qs = e->qtInline ? s : e->qtStream[g % kMaxLevels];
+      if (!e->qtInline) HIPCHK(hipStreamWaitEvent(qs, fastEv[l0], 0));
+      QtItems it{};
+      size_t lds = 0;
+      for (int l = l0; l < l1; l++) { it.items[l] = P.qt[l].flatItems; lds = std::max(lds, P.qt[l].flatLds); }
+      hipLaunchKernelGGL(k_quadtree_flat_levels, dim3(nFrames, l1 - l0), dim3(kQtFlatThreads), lds, qs, D, e->d_cellCount, e->d_cellCand, l0, it,
+                         e->d_lvlKp, e->d_lvlCount, e->d_needPass, e->d_lvlMaxN);
+      if (!e->qtInline) HIPCHK(hipEventRecord(e->evJoin[g], qs));
+    }
+    if (prof) HIPCHK(hipEventRecord(e->ev[3], s));
+    if (!e->qtInline) for (int g = 0; g < nGroups; g++) HIPCHK(hipStreamWaitEvent(s, e->evJoin[g], 0));
+    anyFlat = true;
+  } else {
   for (int l = 0; l < D.nLevels; l++) {
     const hipStream_t qs = e->qtInline ? s : e->qtStream[l];
     if (!e->qtInline) HIPCHK(hipStreamWaitEvent(qs, fastEv[l] ? fastEv[l] : e->evFork, 0));
@@ -570,6 +593,7 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   }
   if (prof) HIPCHK(hipEventRecord(e->ev[3], s));   // end of the blur; the quad-tree stage is the interval up to the join below
   if (!e->qtInline) for (int l = 0; l < D.nLevels; l++) HIPCHK(hipStreamWaitEvent(s, e->evJoin[l], 0));
+  }
   if (anyFlat)   // hand-over units of every level: node table in LDS, candidates in HBM scratch (candCap 0); others exit at once
     hipLaunchKernelGGL(k_quadtree, dim3(D.nLevels, nFrames), dim3(kQtThreads), P.qtPassLds, s, D, e->d_cellCount, e->d_cellCand, e->d_qtCand,
                        e->d_qtNode, P.qtFrameStride, -std::max(P.qtPassNodes, 1), 0, 0, e->d_lvlKp, e->d_lvlCount, e->d_status, e->d_needPass, e->d_nodeScratch);
@@ -703,6 +727,8 @@ int ydorb_extractor_create(const YdExtractorConfig* cfg, ydorb_extractor_t** out
     (void)hipEventCreateWithFlags(&e->evFast[l], hipEventDisableTiming);
   }
   {
+    const char* qg = getenv("YDORB_QT_GROUPED");
+    e->qtGrouped = qg && atoi(qg) != 0;   // off: measured slower (every unit then reserves the largest level's LDS: 178 vs 190 Mkeypoints/s)
     const char* g = getenv("YDORB_FAST_GROUPS");
     // batches: level 0 on its own, then the rest - the quad-tree of level 0 (the longest of the eight) starts ~0.5 ms earlier and the
     // chain no longer outlasts the blur when a second handle's kernels share the GPU (alternate-step pipelining: 188 -> 195 Mkeypoints/s)
