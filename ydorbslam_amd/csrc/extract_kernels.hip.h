@@ -49,10 +49,13 @@ struct PlanDev {
   LevelDev lv[kMaxLevels];
 };
 #ifndef BLUR_TH
-#define BLUR_TH 58
+#define BLUR_TH 32
 #endif
-// 64 x 58 tiles: 58 + 6 = 64 source rows are 32 row pairs x 16 dword groups = exactly two full passes of the workgroup in the horizontal
-// stage (the 32-row tile of before ran 304 tasks on 2 x 256 threads) and the 6-row halo weighs 10 % instead of 19 %
+// Tile height (any value with TH + 6 even).  64 x 58 tiles make 58 + 6 = 64 source rows = 32 row pairs x 16 dword groups = exactly two
+// full passes of the workgroup in the horizontal stage (a 32-row tile runs 304 tasks on 2 x 256 threads) with a 10 % halo instead of
+// 19 %: 0.69 -> 0.54 ms per 512 frames with nothing else on the GPU (0.49 with 90 rows).  In the two-lane pipeline the same build is
+// 3 % SLOWER (189 against 195 Mkeypoints/s, three alternating runs each): the blur then ends before the quad-tree chain it hides and the
+// lane's descriptor kernel starts no earlier, while fewer, longer blur workgroups leave the other lane's kernels less room.  32 it stays.
 constexpr int kBlurTW = 64, kBlurTH = BLUR_TH;
 struct CellDev {            // FAST sub-image [x0,x1) x [y0,y1) in level coordinates (orbExtractor.cpp:562-581)
   short level, x0, y0, x1, y1, pad0;
