@@ -63,6 +63,16 @@ struct Ctx {  // per-device scratch, reused across calls (localBundleAdjust runs
   hipEvent_t ev[2 * PH_COUNT + 2]{};
   bool evInit = false;
   double* hPin = nullptr;   // pinned read-back area: scal[8] + status[2] (one stream sync per LM trial)
+  uint8_t* hStage = nullptr;   // pinned staging of the ordered edge arrays on their way up and of the results on their way down: an
+  size_t hStageCap = 0;        // asynchronous copy out of / into pageable memory runs at ~8 GB/s and makes the host wait for the stream
+  int stage(size_t bytes) {
+    if (bytes <= hStageCap) return YDORB_OK;
+    if (hStage) { (void)hipHostFree(hStage); hStage = nullptr; hStageCap = 0; }
+    const size_t cap = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&hStage, cap) != hipSuccess) { hStage = nullptr; ydorb::set_error("hipHostMalloc(%zu) failed", cap); return YDORB_ERR_HIP; }
+    hStageCap = cap;
+    return YDORB_OK;
+  }
   DBuf pStart, pPoses, pX, pMeas, pInfo, pErr, pFlags, pOutlier, pInl, pChi, pTrials;   // pose-only batches
 };
 // A small pool of contexts per device: one localBundleAdjust at a time is the reference's use (LocalMapping thread), but the solve
@@ -209,14 +219,29 @@ int prepareStage(Run& R_, bool reuse) {
       return rc;
     // Hpp and bp are contiguous ([36 nPf | 6 nPf]) so one all-reduce covers both; bs follows S for the same reason
     trace("optimize: host ordering done");
-  #define UP(buf, vec, T) HIPCHK(hipMemcpyAsync(c.buf.p, vec.data(), sizeof(T) * vec.size(), hipMemcpyHostToDevice, s))
-    UP(ePose, hPose, int); UP(ePidx, hPidx, int); UP(ePt, hPt, int); UP(eLm, hLm, int); UP(eMeas, hMeas, double); UP(eInfo, hInfo, double);
-    UP(eInfo0, hInfo, double);   // the original information: the chi2 tests between and after the stages use it (k_cull)
-    HIPCHK(hipMemsetAsync(c.err.p, 0, sizeof(double) * 3 * Ea, s));   // an edge that is never evaluated (stop flag) has error 0
-    UP(eRobust, hRobust, uint8_t); UP(ptStart, hPtStart, int); UP(poseStart, hPoseStart, int); UP(ptOf, ptOf, int);
-    if (!hPoseEdges.empty()) UP(poseEdges, hPoseEdges, int);
-    if (nPf) UP(poseOf, poseOf, int);
+    {  // through the context's pinned staging area (true asynchronous copies at PCIe rate; the area is free again at the sync below)
+      auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+      const size_t total = 4 * al(sizeof(int) * Ea) + al(sizeof(double) * 3 * Ea) + al(sizeof(double) * Ea) + al(Ea) + al(sizeof(int) * (nL + 1)) +
+                           al(sizeof(int) * (nPf + 1)) + al(sizeof(int) * ptOf.size()) + al(sizeof(int) * hPoseEdges.size()) + al(sizeof(int) * poseOf.size());
+      if ((rc = c.stage(total))) return rc;
+      size_t off = 0;
+      auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+        if (!bytes) return hipSuccess;
+        memcpy(c.hStage + off, src, bytes);
+        const hipError_t e_ = hipMemcpyAsync(dst, c.hStage + off, bytes, hipMemcpyHostToDevice, s);
+        off += al(bytes);
+        return e_;
+      };
+  #define UP(buf, vec, T) HIPCHK(up(c.buf.p, vec.data(), sizeof(T) * vec.size()))
+      UP(ePose, hPose, int); UP(ePidx, hPidx, int); UP(ePt, hPt, int); UP(eLm, hLm, int); UP(eMeas, hMeas, double); UP(eInfo, hInfo, double);
+      // the original information: the chi2 tests between and after the stages use it (k_cull)
+      HIPCHK(hipMemcpyAsync(c.eInfo0.p, c.eInfo.p, sizeof(double) * Ea, hipMemcpyDeviceToDevice, s));
+      HIPCHK(hipMemsetAsync(c.err.p, 0, sizeof(double) * 3 * Ea, s));   // an edge that is never evaluated (stop flag) has error 0
+      UP(eRobust, hRobust, uint8_t); UP(ptStart, hPtStart, int); UP(poseStart, hPoseStart, int); UP(ptOf, ptOf, int);
+      if (!hPoseEdges.empty()) UP(poseEdges, hPoseEdges, int);
+      if (nPf) UP(poseOf, poseOf, int);
   #undef UP
+    }
     trace("optimize: uploads enqueued");
     // pose-pair buckets of the Schur complement (structure is fixed for this optimize() call)
     const int nBuckets = nPf * (nPf + 1) / 2;
@@ -485,12 +510,17 @@ int endSolve(Run& R_) {
   int rc = launchCull(R_, 1);
   if (rc) return rc;
   uint8_t* outlier = R_.res->edge_outlier;
-  std::vector<uint8_t> ho(Y.Ea);
-  if (outlier && Y.Ea) HIPCHK(hipMemcpyAsync(ho.data(), c.eOutlier.p, Y.Ea, hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipMemcpyAsync(P->poses, c.poses[R_.cur].p, sizeof(double) * 7 * P->n_poses, hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipMemcpyAsync(P->points, c.pts[R_.cur].p, sizeof(double) * 3 * P->n_points, hipMemcpyDeviceToHost, c.stream));
+  // down through the pinned staging area, then into the caller's (pageable) arrays
+  const size_t bPoses = sizeof(double) * 7 * P->n_poses, bPts = sizeof(double) * 3 * P->n_points, oPts = (bPoses + 255) & ~(size_t)255,
+               oOut = oPts + ((bPts + 255) & ~(size_t)255);
+  if ((rc = c.stage(oOut + Y.Ea))) return rc;
+  if (outlier && Y.Ea) HIPCHK(hipMemcpyAsync(c.hStage + oOut, c.eOutlier.p, Y.Ea, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipMemcpyAsync(c.hStage, c.poses[R_.cur].p, bPoses, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipMemcpyAsync(c.hStage + oPts, c.pts[R_.cur].p, bPts, hipMemcpyDeviceToHost, c.stream));
   HIPCHK(hipStreamSynchronize(c.stream));
-  if (outlier) for (int i = 0; i < Y.Ea; i++) outlier[Y.act[i]] = ho[i];   // device edges are in (landmark, pose) order
+  memcpy(P->poses, c.hStage, bPoses);
+  memcpy(P->points, c.hStage + oPts, bPts);
+  if (outlier) for (int i = 0; i < Y.Ea; i++) outlier[Y.act[i]] = c.hStage[oOut + i];   // device edges are in (landmark, pose) order
   if (R_.stopped()) R_.res->stopped = 1;
   return YDORB_OK;
 }
