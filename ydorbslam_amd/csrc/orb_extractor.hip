@@ -62,6 +62,7 @@ struct ydorb_extractor {
   hipStream_t qtStream[kMaxLevels]{};   // side streams of the per-level quad-tree launches
   hipEvent_t evFork = nullptr, evJoin[kMaxLevels]{};
   hipEvent_t evFast[kMaxLevels]{};      // end of the FAST launch that covers level l (levels are launched in groups)
+  bool descStage = false;               // YDORB_DESC_STAGE=1: descriptor test points from an LDS copy of the blurred neighbourhood
   int descKpw = 2;                      // keypoints per wave of k_orient_describe_n
   bool qtGrouped = false;               // batched handles: one quad-tree launch per FAST level group instead of one per level
   bool qtInline = false;                // YDORB_QT_STREAMS=0: the quad-tree launches go on the caller's stream, behind the blur
@@ -601,15 +602,14 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   {
     const int kpw = e->descKpw;   // keypoints per wave (YDORB_DESC_KPW: 1, 2 or 4)
     const dim3 gd(((D.sumQuota + 4 * kpw - 1) / (4 * kpw) + 7) / 8 * 8, nFrames);
+#define YD_DESC(K, ST) hipLaunchKernelGGL((k_orient_describe_n<K, ST>), gd, dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur, P.blurFrameStride, D, \
+                                         e->d_lvlKp, e->d_lvlCount, d_kps, d_desc, cap, d_nOut, e->d_lvlAngle)
     if (kpw == 1)
       hipLaunchKernelGGL(k_orient_describe, gd, dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
                          P.blurFrameStride, D, e->d_lvlKp, e->d_lvlCount, d_kps, d_desc, cap, d_nOut, e->d_lvlAngle);
-    else if (kpw == 2)
-      hipLaunchKernelGGL(k_orient_describe_n<2>, gd, dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
-                         P.blurFrameStride, D, e->d_lvlKp, e->d_lvlCount, d_kps, d_desc, cap, d_nOut, e->d_lvlAngle);
-    else
-      hipLaunchKernelGGL(k_orient_describe_n<4>, gd, dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
-                         P.blurFrameStride, D, e->d_lvlKp, e->d_lvlCount, d_kps, d_desc, cap, d_nOut, e->d_lvlAngle);
+    else if (kpw == 2) { if (e->descStage) YD_DESC(2, true); else YD_DESC(2, false); }
+    else { if (e->descStage) YD_DESC(4, true); else YD_DESC(4, false); }
+#undef YD_DESC
   }
   if (prof) { HIPCHK(hipEventRecord(e->ev[5], s)); e->profPending = true; }
   HIPCHK(hipMemcpyAsync(e->h_lvlMaxN, e->d_lvlMaxN, sizeof(int) * kMaxLevels, hipMemcpyDeviceToHost, s));
@@ -670,6 +670,7 @@ int ydorb_extractor_create(const YdExtractorConfig* cfg, ydorb_extractor_t** out
   // keypoints per wave of the orientation + descriptor kernel: 4 for batches (their loads overlap: 0.56 -> 0.47 ms per 512 frames); a
   // single-frame handle keeps one keypoint per wave (1000 short waves spread over the chip finish sooner than 250 long ones)
   e->descKpw = cfg->max_batch <= 8 ? 1 : 4;
+  if (const char* v = getenv("YDORB_DESC_STAGE")) e->descStage = atoi(v) != 0;
   if (const char* v = getenv("YDORB_DESC_KPW")) e->descKpw = atoi(v) == 1 ? 1 : atoi(v) == 4 ? 4 : 2;
   e->cfg.min_fast_thr = cfg->ini_fast_thr;  // reference quirk, orbExtractor.cpp:318
   // constructor tables, orbExtractor.cpp:319-353
