@@ -158,8 +158,8 @@ def test_pyramid_pads_written_by_level_kernels_and_by_border_launch(oracle_lib, 
             assert np.array_equal(d, cd)
 
 
-@pytest.mark.parametrize("kpw", ["1", "2", "4"])
-def test_describe_kernel_keypoints_per_wave(oracle_lib, monkeypatch, kpw):
+@pytest.mark.parametrize("kpw,stage", [("1", "0"), ("2", "0"), ("4", "0"), ("2", "1"), ("4", "1")])
+def test_describe_kernel_keypoints_per_wave(oracle_lib, monkeypatch, kpw, stage):
     """k_orient_describe_n<KPW> interleaves KPW keypoints in one wave (batch handles use 4, single-frame handles 1): the same
     keypoints, angles and descriptors whatever KPW is - also where a wave's slots straddle two levels or end past the last keypoint
     (the half-empty and the nearly empty frame)."""
@@ -170,8 +170,10 @@ def test_describe_kernel_keypoints_per_wave(oracle_lib, monkeypatch, kpw):
     frames[2][100:150, 100:160] = synth_frame(640, 480, 43)[100:150, 100:160]
     imgs = np.stack(frames)
     monkeypatch.setenv("YDORB_DESC_KPW", kpw)
+    monkeypatch.setenv("YDORB_DESC_STAGE", stage)   # 1: test points from an LDS copy of the blurred neighbourhood
     gpu = y.OrbExtractor(1000, 1.2, 8, 20, 7, max_batch=len(frames))
     monkeypatch.delenv("YDORB_DESC_KPW")
+    monkeypatch.delenv("YDORB_DESC_STAGE")
     res = gpu.extract_batch(imgs)
     for f, img in enumerate(frames):
         ck, cd = OrbExtractorOracle(1000, 1.2, 8, 20, 7).extract(img)
@@ -269,7 +271,7 @@ def test_read_pyramid_single_transfer_equals_level_reads():
 @pytest.mark.parametrize("w,h,nf,grouped", [(640, 480, 1000, "0"), (752, 480, 1000, "0"), (640, 480, 1000, "1")])
 def test_batched_handle_paths_match_the_oracle(oracle_lib, monkeypatch, w, h, nf, grouped):
     """A handle for more than 8 frames per call takes the throughput paths the headline bench runs: FAST cells launched in two level
-    groups, four keypoints per wave in the descriptor kernel, 64 x 58 blur tiles and - with YDORB_QT_GROUPED=1 - one quad-tree launch per
+    groups, four keypoints per wave in the descriptor kernel and - with YDORB_QT_GROUPED=1 - one quad-tree launch per
     level group (k_quadtree_flat_levels) instead of one per level.  Twelve frames of
     mixed content (textured, half empty, nearly empty) - twice, so that the second call runs with the retuned quad-tree footprints -
     against the oracle, frame by frame."""
