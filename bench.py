@@ -179,11 +179,15 @@ def main():
     imgs, _ = stream_render(plan, own)
     NEX = max(1, min(args.extractors, F // 8))
     parts = [(i * F // NEX, (i + 1) * F // NEX) for i in range(NEX)]
-    NSET = max(2, args.alternate)      # output sets (= lanes with --alternate)
+    LANES = max(2, args.alternate)
+    # YDORB_BENCH_RESOLVE_STREAM=1: the serial resolve of a step runs on a side stream, the lane goes on with its next step at once; a
+    # lane then alternates between two output sets (+ matchers), so the resolve of step k and the extraction of step k + LANES never share buffers
+    side_resolve = bool(int(os.environ.get("YDORB_BENCH_RESOLVE_STREAM", "0"))) and args.alternate > 0
+    NSET = LANES * (2 if side_resolve else 1)      # output sets
     single = bool(int(os.environ.get("YDORB_BENCH_SINGLE_STREAM", "0")))
     if args.alternate:
-        NEX, parts = NSET, [(0, F)]
-        exs = [y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=F, single_stream=single) for _ in range(NSET)]
+        NEX, parts = LANES, [(0, F)]
+        exs = [y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=F, single_stream=single) for _ in range(LANES)]
     else:
         exs = [y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=b - a) for a, b in parts]
     ex = exs[0]
@@ -216,13 +220,25 @@ def main():
     mts = [y.OrbMatcher(0.9, True, device=local_rank) for _ in range(NSET)]   # one matcher (own scratch) per output set
     step_no = [0]
 
+    s_res = torch.cuda.Stream(device=dev) if side_resolve else None
+    ev_res = [torch.cuda.Event() for _ in range(NSET)]
+    if side_resolve:
+        for m_ in mts:
+            m_.set_resolve_stream(s_res.cuda_stream)
+        for e_ in ev_res:
+            e_.record(s_res)
+
     def step_alternate():
         # output set b belongs to handle b and stream b: step k's extraction AND matching run on stream k & 1, back to back; the two
         # streams overlap freely (no events between them), so one stream's latency-bound kernels run beside the other's busy ones
-        b = step_no[0] % NSET
+        k_ = step_no[0]
         step_no[0] += 1
-        sA = sAs[b]
-        exs[b].extract_batch_device(d_img.data_ptr(), W, H, W, W * H, F, d_kps[b].data_ptr(), d_desc[b].data_ptr(), cap, d_n[b].data_ptr(), sA.cuda_stream)
+        lane = k_ % LANES
+        b = lane + LANES * ((k_ // LANES) & 1) if side_resolve else lane       # output set (and matcher) of this step
+        sA = sAs[lane]
+        if side_resolve:
+            sA.wait_event(ev_res[b])       # the resolve that last read this set (two of the lane's steps ago) is done
+        exs[lane].extract_batch_device(d_img.data_ptr(), W, H, W, W * H, F, d_kps[b].data_ptr(), d_desc[b].data_ptr(), cap, d_n[b].data_ptr(), sA.cuda_stream)
         with torch.cuda.stream(sA):
             if world > 1 or force_dist:
                 all_gather_inplace(g_kps[b], d_kps[b])
@@ -230,6 +246,8 @@ def main():
                 all_gather_inplace(g_n[b], d_n[b])
             gs = (g_kps[b].data_ptr(), g_desc[b].data_ptr(), g_n[b].data_ptr(), G, cap)
             mts[b].match_pairs_device(gs, gs, pairs, W, H, 15.0, sf, d_assigned[b].data_ptr(), d_counts[b].data_ptr(), d_aff.data_ptr(), sA.cuda_stream)
+        if side_resolve:
+            ev_res[b].record(s_res)
 
     def step():
         if args.alternate:
@@ -304,7 +322,7 @@ def main():
     # ---- extract only (both figures): the same launches without the matcher, after the timed region ------------------
     def extract_step():
         if args.alternate:
-            b = step_no[0] % NSET
+            b = step_no[0] % LANES
             step_no[0] += 1
             exs[b].extract_batch_device(d_img.data_ptr(), W, H, W, W * H, F, d_kps[b].data_ptr(), d_desc[b].data_ptr(), cap, d_n[b].data_ptr(), sAs[b].cuda_stream)
             return

@@ -315,6 +315,11 @@ int ydorb_hamming_topk(ydorb_matcher_t* h, const uint8_t* q, int32_t nq, const u
 int ydorb_hamming_topk_device(ydorb_matcher_t* h, const uint8_t* d_qdesc, const int32_t* d_nq, const uint8_t* d_tdesc, const int32_t* d_nt,
                               int32_t cap, int32_t n_pairs, YdMatch2* d_out, void* stream);
 int ydorb_matcher_synchronize(ydorb_matcher_t* h);
+/* Pipelined callers: the ordered resolve of ydorb_match_pairs_device / ydorb_match_consecutive_device (one wave per frame pair, serial by
+ * definition: a latency chain that uses next to nothing of the GPU) is launched on `stream` instead of the call's stream, behind an event, so
+ * that the call's stream is free for the next step at once.  d_assigned / d_counts and the target keypoints are then in use until that
+ * stream has run the resolve (ydorb_matcher_synchronize waits for everything).  NULL = back to the call's own stream. */
+int ydorb_matcher_set_resolve_stream(ydorb_matcher_t* h, void* stream);
 /* average device ms of grid build / gather / resolve over calls since enabling (HIP events on the launch stream) */
 int ydorb_matcher_set_profiling(ydorb_matcher_t* h, int32_t on);
 int ydorb_matcher_stage_times(ydorb_matcher_t* h, int32_t max_stages, const char** names, float* ms, int32_t* n_stages);

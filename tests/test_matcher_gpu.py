@@ -340,3 +340,41 @@ def test_new_entry_points_on_empty_and_ragged_inputs(oracle_lib):
     assert cnt.tolist() == [0, 0] and bool((asg == -1).all())
     with pytest.raises(y.YdorbError):
         m.match_pairs_device(fs, fs, [(0, 3)], 640, 480, 15.0, sf, asg.data_ptr(), cnt.data_ptr())
+
+
+def test_resolve_on_a_side_stream_gives_the_same_matches():
+    """ydorb_matcher_set_resolve_stream: the ordered resolve of the device-resident search runs on another stream behind an event
+    (pipelined callers keep the call's stream free); match lists and counts equal those of the plain call."""
+    import torch
+    import ydorbslam_amd as y
+    from ydorbslam_amd.synth import synth_frame
+    W, H, NF, F = 640, 480, 1000, 5
+    base = synth_frame(W + 32, H + 32, 61)
+    imgs = np.stack([np.ascontiguousarray(base[16 + 2 * i:16 + 2 * i + H, 16 + 3 * i:16 + 3 * i + W]) for i in range(F)])
+    ex = y.OrbExtractor(NF, max_batch=F)
+    cap = ex.max_keypoints
+    dev = torch.device("cuda:0")
+    d_img = torch.from_numpy(imgs).to(dev)
+    d_kps = torch.zeros((F, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((F, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(F, dtype=torch.int32, device=dev)
+    ex.extract_batch_device(d_img.data_ptr(), W, H, W, W * H, F, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr())
+    ex.synchronize()
+    sf = ex.tables()["scale"]
+    out = []
+    side = torch.cuda.Stream(device=dev)
+    main = torch.cuda.Stream(device=dev)
+    for use_side in (False, True, False):
+        m = y.OrbMatcher(0.9, True)
+        if use_side:
+            m.set_resolve_stream(side.cuda_stream)
+        a = torch.zeros((F - 1, cap), dtype=torch.int32, device=dev)
+        c = torch.zeros(F - 1, dtype=torch.int32, device=dev)
+        for _ in range(2):   # twice: the second call reuses the handle's scratch behind the first resolve
+            m.match_consecutive_device(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, F, W, H, 15.0, sf, a.data_ptr(), c.data_ptr(),
+                                       stream=main.cuda_stream)
+            m.synchronize()
+        out.append((a.cpu().numpy(), c.cpu().numpy()))
+    assert out[0][1].sum() > 100
+    for a, c in out[1:]:
+        assert np.array_equal(a, out[0][0]) and np.array_equal(c, out[0][1])
