@@ -411,7 +411,11 @@ def main():
     except Exception:  # noqa: BLE001
         pass
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source, "valu_busy_frac": valu_busy,
+                "frac": achieved / HBM_PEAK,
+                # the same kernel with nothing else on the GPU (one handle, one stream; HIP events, measured after the timed region)
+                "achieved_alone": (kbytes.get(dom, A_frame) * launch_frames / (isolated[dom] * 1e-3) / 1e9) if isolated.get(dom) else None,
+                "frac_alone": (kbytes.get(dom, A_frame) * launch_frames / (isolated[dom] * 1e-3) / HBM_PEAK) if isolated.get(dom) else None,
+                "traffic": traffic, "traffic_source": traffic_source, "valu_busy_frac": valu_busy,
                 "valu_busy_source": traffic_source and traffic_source.replace("hbm_traffic", "sq_valu"),
                 "pipeline_achieved_GBps": A_frame * F * args.steps / dt / 1e9, "pipeline_frac": A_frame * F * args.steps / dt / HBM_PEAK,
                 "stage_note": "a stage = every launch of its kernels in one extractor call over frames_per_extract_launch frames (fast_cells: two launches, "

@@ -662,10 +662,14 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
 // non-backward branch of orbMatcher.cpp:95-101.
 __global__ __launch_bounds__(256) void k_queries_from_keypoints(const CallDev* __restrict__ calls, int cap, const float* __restrict__ affine, float th,
                                                                 const float* __restrict__ scaleFactors, int nLevels,
-                                                                float minX, float maxX, float minY, float maxY) {
+                                                                float minX, float maxX, float minY, float maxY, unsigned* __restrict__ poolHeads) {
   const int f = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= cap) return;
+  // the call's clean slate rides along (three memset launches on the stream otherwise): nothing assigned, nothing taken, empty overflow pool
+  calls[f].assigned[i] = -1;
+  calls[f].taken[i] = 0;
+  if (i == 0 && poolHeads) poolHeads[f] = 0;
   const KeyPointDev* __restrict__ kps = calls[f].qkps;
   QueryDev* __restrict__ out = const_cast<QueryDev*>(calls[f].queries);
   QueryDev Q{};

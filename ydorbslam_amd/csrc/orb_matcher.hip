@@ -713,12 +713,11 @@ int ydorb_match_pairs_device(ydorb_matcher_t* m, const YdFrameSetDev* Q, const Y
   const float* aff = d_affine ? d_affine : m->sf.as<float>() + 8;
   const bool prof = m->profiling;
   collect(m);
-  HIPCHK(hipMemsetAsync(m->heads.p, 0, sizeof(unsigned) * nCalls, s));  // per-call pool heads; the overflow status (misc[1]) is sticky until synchronize reads it
-  HIPCHK(hipMemsetAsync(m->taken.p, 0, (size_t)cap * nCalls, s));
-  HIPCHK(hipMemsetAsync(d_assigned, 0xFF, sizeof(int) * (size_t)cap * nCalls, s));
+  // per-call pool heads, taken flags and the all -1 assignment are written by k_queries_from_keypoints (the overflow status, misc[1], is
+  // sticky until synchronize reads it)
   if (prof) HIPCHK(hipEventRecord(m->ev[0], s));
   hipLaunchKernelGGL(k_queries_from_keypoints, dim3((cap + 255) / 256, nCalls), dim3(256), 0, s, m->calls.as<CallDev>(), cap, aff, th, m->sf.as<float>(),
-                     nLevels, minX, maxX, minY, maxY);
+                     nLevels, minX, maxX, minY, maxY, m->heads.as<unsigned>());
   { const int rcg = launchGridBuild(nFrames, cap, s, m->frames.as<FrameDev>()); if (rcg) return rcg; }
   if (prof) HIPCHK(hipEventRecord(m->ev[1], s));
   hipLaunchKernelGGL(k_gather_projection, dim3((cap + 4 * kGatherQpw - 1) / (4 * kGatherQpw), nCalls), dim3(256), 0, s, m->calls.as<CallDev>(), m->frames.as<FrameDev>(), cap,
