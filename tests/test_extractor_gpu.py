@@ -268,11 +268,13 @@ def test_read_pyramid_single_transfer_equals_level_reads():
             assert np.array_equal(lv[l], ex.read_level(l, f)), "frame %d level %d" % (f, l)
 
 
-@pytest.mark.parametrize("w,h,nf,grouped", [(640, 480, 1000, "0"), (752, 480, 1000, "0"), (640, 480, 1000, "1")])
-def test_batched_handle_paths_match_the_oracle(oracle_lib, monkeypatch, w, h, nf, grouped):
+@pytest.mark.parametrize("w,h,nf,grouped,single", [(640, 480, 1000, "0", False), (752, 480, 1000, "0", False), (640, 480, 1000, "1", False),
+                                                   (640, 480, 1000, "0", True)])
+def test_batched_handle_paths_match_the_oracle(oracle_lib, monkeypatch, w, h, nf, grouped, single):
     """A handle for more than 8 frames per call takes the throughput paths the headline bench runs: FAST cells launched in two level
     groups, four keypoints per wave in the descriptor kernel and - with YDORB_QT_GROUPED=1 - one quad-tree launch per
-    level group (k_quadtree_flat_levels) instead of one per level.  Twelve frames of
+    level group (k_quadtree_flat_levels) instead of one per level; `single` = a YDORB_EXTRACTOR_SINGLE_STREAM handle (every launch on the
+    call's stream: what bench.py's stereo lanes use).  Twelve frames of
     mixed content (textured, half empty, nearly empty) - twice, so that the second call runs with the retuned quad-tree footprints -
     against the oracle, frame by frame."""
     import ydorbslam_amd as y
@@ -282,7 +284,7 @@ def test_batched_handle_paths_match_the_oracle(oracle_lib, monkeypatch, w, h, nf
     frames[7] = np.full((h, w), 90, np.uint8); frames[7][100:150, 100:160] = synth_frame(w, h, 63)[100:150, 100:160]
     imgs = np.stack(frames)
     monkeypatch.setenv("YDORB_QT_GROUPED", grouped)
-    gpu = y.OrbExtractor(nf, 1.2, 8, 20, 7, max_batch=12)
+    gpu = y.OrbExtractor(nf, 1.2, 8, 20, 7, max_batch=12, single_stream=single)
     monkeypatch.delenv("YDORB_QT_GROUPED")
     gpu.extract_batch(imgs)
     res = gpu.extract_batch(imgs)
