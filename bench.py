@@ -170,6 +170,9 @@ def main():
     import ydorbslam_amd as y
     from ydorbslam_amd.synth import stream_plan, stream_render, synth_ba_problem
 
+    # The working streams are created FIRST, before any handle creates streams of its own: the device runs 4 hardware queues and HIP deals
+    # streams onto them in creation order, so the first four land on four different queues (profiles/r02d_queue_overlap.txt).
+    early_streams = [torch.cuda.Stream(device=dev) for _ in range(8)]
     F = args.frames
     G = F * world                                   # frames of the global stream per step
     # every frame distinct; frame g+1 = frame g after a small known motion (scene cut every --segment frames).
@@ -212,7 +215,19 @@ def main():
     d_aff = torch.from_numpy(np.ascontiguousarray(pair_aff, np.float32)).to(dev)
     d_assigned = [torch.zeros((NPAIR, cap), dtype=torch.int32, device=dev) for _ in range(NSET)]
     d_counts = [torch.zeros(NPAIR, dtype=torch.int32, device=dev) for _ in range(NSET)]
-    sAs, sB = [torch.cuda.Stream(device=dev) for _ in range(NEX)], torch.cuda.Stream(device=dev)
+    side_mode = int(os.environ.get("YDORB_BENCH_SIDE_STREAMS", "0")) if args.alternate == 2 else 0   # 1-3: caller-provided quad-tree side streams (no gain measured: 186-191 against 191-198 Mkeypoints/s)
+    if side_mode:
+        # two lanes + one caller-provided quad-tree side stream per lane = the four queues
+        sAs, sB = early_streams[:2], early_streams[4]
+        for i_, h_ in enumerate(exs):
+            if side_mode == 1:     # one side stream per lane
+                h_.set_side_streams([early_streams[2 + i_].cuda_stream])
+            elif side_mode == 2:   # two side streams shared by both lanes
+                h_.set_side_streams([early_streams[2].cuda_stream, early_streams[3].cuda_stream])
+            else:                  # 3: two side streams per lane, the second pair on the queues of the first (creation order 6, 7 -> queues of 2, 3)
+                h_.set_side_streams([early_streams[2 + 4 * i_].cuda_stream, early_streams[3 + 4 * i_].cuda_stream])
+    else:
+        sAs, sB = [torch.cuda.Stream(device=dev) for _ in range(NEX)], torch.cuda.Stream(device=dev)
     ev_extracted = [[torch.cuda.Event() for _ in range(NEX)] for _ in range(NSET)]
     ev_matched = [torch.cuda.Event() for _ in range(NSET)]
     for e in ev_matched:

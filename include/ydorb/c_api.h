@@ -71,6 +71,13 @@ typedef struct ydorb_extractor ydorb_extractor_t;
 int ydorb_extractor_create(const YdExtractorConfig* cfg, ydorb_extractor_t** out);
 void ydorb_extractor_destroy(ydorb_extractor_t* h);
 
+/* Side streams of the caller's choosing for the per-level quad-tree launches (level l uses streams[l % n]; n = 0: every launch on the call's
+ * stream, as YDORB_EXTRACTOR_SINGLE_STREAM).  The streams are not owned by the handle and must outlive it or be replaced first.  Why: the
+ * device runs 4 hardware queues and HIP assigns streams to them in creation order; a pipelined caller that creates its few streams first
+ * (lane streams + these) keeps them on distinct queues, whereas a handle's own side streams may land on the queue of the very stream they
+ * are meant to overlap (profiles/r02d_queue_overlap.txt). */
+int ydorb_extractor_set_side_streams(ydorb_extractor_t* h, void* const* streams, int32_t n);
+
 /* getScaleFactors / getInvScaleFactors / getScaleFactorSquares / getInvScaleFactorSquares and the
  * per-level keypoint quotas (src/orbExtractor.hpp:42-49, orbExtractor.cpp:325-339).  Each output may
  * be NULL; arrays hold n_levels entries. */

@@ -60,6 +60,8 @@ struct ydorb_extractor {
   int sumQuota = 0;
   hipStream_t stream = nullptr;
   hipStream_t qtStream[kMaxLevels]{};   // side streams of the per-level quad-tree launches
+  bool userSide = false;                // qtStream[] are the caller's (ydorb_extractor_set_side_streams): not destroyed here
+  std::vector<hipStream_t> ownedSide;   // the handle's own side streams after they were replaced
   hipEvent_t evFork = nullptr, evJoin[kMaxLevels]{};
   hipEvent_t evFast[kMaxLevels]{};      // end of the FAST launch that covers level l (levels are launched in groups)
   bool descStage = false;               // YDORB_DESC_STAGE=1: descriptor test points from an LDS copy of the blurred neighbourhood
@@ -746,7 +748,7 @@ void ydorb_extractor_destroy(ydorb_extractor_t* e) {
   freeBuffers(e);
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   for (int l = 0; l < kMaxLevels; l++) {
-    if (e->qtStream[l]) {
+    if (e->qtStream[l] && !e->userSide) {
       bool shared = false;
       for (int k = 0; k < l; k++) shared = shared || e->qtStream[k] == e->qtStream[l];
       if (!shared) { (void)hipStreamSynchronize(e->qtStream[l]); (void)hipStreamDestroy(e->qtStream[l]); }
@@ -754,9 +756,28 @@ void ydorb_extractor_destroy(ydorb_extractor_t* e) {
     if (e->evJoin[l]) (void)hipEventDestroy(e->evJoin[l]);
     if (e->evFast[l]) (void)hipEventDestroy(e->evFast[l]);
   }
+  {
+    std::vector<hipStream_t> seen;
+    for (hipStream_t st : e->ownedSide) {
+      bool dup = false;
+      for (hipStream_t t : seen) dup = dup || t == st;
+      if (!dup) { seen.push_back(st); (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    }
+  }
   if (e->evFork) (void)hipEventDestroy(e->evFork);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
+}
+
+int ydorb_extractor_set_side_streams(ydorb_extractor_t* e, void* const* streams, int32_t n) {
+  if (!e || n < 0 || n > kMaxLevels || (n > 0 && !streams)) { set_error("invalid argument"); return YDORB_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(e->cfg.device));
+  // the handle's own side streams stay alive (they may still carry work) and are destroyed with the handle
+  for (int l = 0; l < kMaxLevels; l++) if (e->qtStream[l] && !e->userSide) e->ownedSide.push_back(e->qtStream[l]);
+  e->userSide = true;
+  e->qtInline = n == 0;
+  for (int l = 0; l < kMaxLevels; l++) e->qtStream[l] = n ? (hipStream_t)streams[l % n] : nullptr;
+  return YDORB_OK;
 }
 
 int ydorb_extractor_tables(const ydorb_extractor_t* e, float* scale, float* inv_scale, float* scale_sq, float* inv_scale_sq,
