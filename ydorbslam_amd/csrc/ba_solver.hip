@@ -539,6 +539,7 @@ struct Job {
   int stage = 1, it = 0, iterations = 0, qmax = 0;
   double lambda = 0, ni = 2, currentChi = 0, rho = 0;
   bool lastAccepted = true, needBuild = false, done = false;
+  bool pendingEnd = false;   // finished its LM schedule: final cull + read-back still to do (all of a group together, on the set-up threads)
   int rc = YDORB_OK;
   std::string errText;
   ~Job() { delete run; }
@@ -597,11 +598,9 @@ int solveGroup(BatchPool& B, const YdBaProblem* probs, const YdBaOptions& Oin, Y
     if (!(X.it < X.iterations && !X.run->stopped())) { endStage(j); return; }   // `for (it = 0; it < iterations && !terminate(); ...)`
     X.needBuild = true;
   };
-  finalize = [&](int j) {
-    Job& X = *J[j];
-    int r = endSolve(*X.run);
-    if (r) { fail(j, r); return; }
-    X.done = true;
+  finalize = [&](int j) {   // the final cull, read-back and outlier scatter of a problem (~0.1 ms each, mostly host): deferred, see the end
+    J[j]->pendingEnd = true;
+    J[j]->done = true;
   };
   endStage = [&](int j) {
     Job& X = *J[j];
@@ -648,7 +647,7 @@ int solveGroup(BatchPool& B, const YdBaProblem* probs, const YdBaOptions& Oin, Y
       hipStream_t st = B.setupStreams[t];
       for (int j = next.fetch_add(1); j < n; j = next.fetch_add(1)) {
         Job& X = *J[j];
-        X.done = false; X.rc = YDORB_OK; X.errText.clear();
+        X.done = false; X.pendingEnd = false; X.rc = YDORB_OK; X.errText.clear();
         delete X.run; X.run = nullptr;
         if (rcEach) rcEach[j] = YDORB_OK;
         int r = checkProblem(&probs[j], &Oin, &res[j], &X.O);
@@ -788,6 +787,28 @@ int solveGroup(BatchPool& B, const YdBaProblem* probs, const YdBaOptions& Oin, Y
       X.run->res->n_trials++;
       if (lambdaBroke || !(X.rho < 0 && X.qmax < X.O.max_trials && !X.run->stopped())) endIteration(j);
     }
+  }
+  {  // endSolve of every finished problem, spread over the set-up threads and streams (the lock-step stream has drained)
+    HIPCHK(hipStreamSynchronize(s));
+    const int nt = std::max(1, std::min(n, (int)B.setupStreams.size()));
+    std::atomic<int> next{0};
+    auto worker = [&](int t) {
+      (void)hipSetDevice(Oin.device);
+      for (int j = next.fetch_add(1); j < n; j = next.fetch_add(1)) {
+        Job& X = *J[j];
+        if (!X.pendingEnd) continue;
+        X.pendingEnd = false;
+        X.ctx.stream = B.setupStreams[t];
+        const int r = endSolve(*X.run);
+        X.ctx.stream = s;
+        if (r) { X.errText = ydorb_last_error(); fail(j, r); }
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(worker, t);
+    worker(0);
+    for (std::thread& th : pool) th.join();
+    for (int j = 0; j < n; j++) if (J[j]->rc != YDORB_OK && !J[j]->errText.empty()) set_error("%s", J[j]->errText.c_str());
   }
   trace("batch: done");
   int first = YDORB_OK;
