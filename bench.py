@@ -558,37 +558,49 @@ def main():
         h_n = torch.zeros(F, dtype=torch.int32).pin_memory()
         h_assigned = torch.zeros((NPAIR, cap), dtype=torch.int32).pin_memory()
         h_counts = torch.zeros(NPAIR, dtype=torch.int32).pin_memory()
-        p_img = torch.zeros_like(d_img)
+        p_img = [torch.zeros_like(d_img) for _ in range(2)]   # device image buffers: the upload of step k+1 runs under the extraction of step k
         # two handles of their own, alternating over the chunks: the copy of chunk c+1 and the extraction of chunk c overlap
         pexs = [y.OrbExtractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=cf) for _ in range(2)]
         psts = [torch.cuda.Stream(device=dev) for _ in range(2)]
         s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-        ev_in = [torch.cuda.Event() for _ in range(CH)]
-        ev_ex = [torch.cuda.Event() for _ in range(CH)]
+        ev_in = [torch.cuda.Event() for _ in range(CH)]   # (re-recorded per step: a stream waits for the latest record at the time of the wait call)
+        ev_ex = [torch.cuda.Event() for _ in range(2 * CH)]
+        ev_pm = [torch.cuda.Event() for _ in range(2)]       # matcher + read-back of an output set done
+        for e_ in ev_ex:
+            e_.record(sB)
+        for e_ in ev_pm:
+            e_.record(sB)
+        pstep = [0]
 
         def pcie_step():
+            b = pstep[0] & 1                                 # output set of this step: the matcher of step k reads set b while step k+1 fills the other
+            pstep[0] += 1
+            gsb = (g_kps[b].data_ptr(), g_desc[b].data_ptr(), g_n[b].data_ptr(), G, cap)
             for c in range(CH):
                 a_, b_ = c * cf, (c + 1) * cf
                 with torch.cuda.stream(s_in):
-                    p_img[a_:b_].copy_(h_img[a_:b_], non_blocking=True)
+                    s_in.wait_event(ev_ex[b * CH + c])       # the extraction that last read this chunk of this image buffer (two steps ago) is done
+                    p_img[b][a_:b_].copy_(h_img[a_:b_], non_blocking=True)
                     ev_in[c].record(s_in)
                 sA = psts[c % 2]
                 sA.wait_event(ev_in[c])
-                pexs[c % 2].extract_batch_device(p_img[a_].data_ptr(), W, H, W, W * H, cf, d_kps[0][a_].data_ptr(), d_desc[0][a_].data_ptr(), cap,
-                                                 d_n[0][a_:].data_ptr(), sA.cuda_stream)
-                ev_ex[c].record(sA)
+                sA.wait_event(ev_pm[b])                      # the matcher that last read this output set (two steps ago) is done
+                pexs[c % 2].extract_batch_device(p_img[b][a_].data_ptr(), W, H, W, W * H, cf, d_kps[b][a_].data_ptr(), d_desc[b][a_].data_ptr(), cap,
+                                                 d_n[b][a_:].data_ptr(), sA.cuda_stream)
+                ev_ex[b * CH + c].record(sA)
                 with torch.cuda.stream(s_out):
-                    s_out.wait_event(ev_ex[c])
-                    h_kps[a_:b_].copy_(d_kps[0][a_:b_], non_blocking=True)
-                    h_desc[a_:b_].copy_(d_desc[0][a_:b_], non_blocking=True)
-                    h_n[a_:b_].copy_(d_n[0][a_:b_], non_blocking=True)
-                sB.wait_event(ev_ex[c])
-            mts[0].match_pairs_device(gs0, gs0, pairs, W, H, 15.0, sf, d_assigned[0].data_ptr(), d_counts[0].data_ptr(), d_aff.data_ptr(), sB.cuda_stream)
+                    s_out.wait_event(ev_ex[b * CH + c])
+                    h_kps[a_:b_].copy_(d_kps[b][a_:b_], non_blocking=True)
+                    h_desc[a_:b_].copy_(d_desc[b][a_:b_], non_blocking=True)
+                    h_n[a_:b_].copy_(d_n[b][a_:b_], non_blocking=True)
+                sB.wait_event(ev_ex[b * CH + c])
+            mts[b].match_pairs_device(gsb, gsb, pairs, W, H, 15.0, sf, d_assigned[b].data_ptr(), d_counts[b].data_ptr(), d_aff.data_ptr(), sB.cuda_stream)
             with torch.cuda.stream(sB):
-                h_assigned.copy_(d_assigned[0], non_blocking=True)
-                h_counts.copy_(d_counts[0], non_blocking=True)
+                h_assigned.copy_(d_assigned[b], non_blocking=True)
+                h_counts.copy_(d_counts[b], non_blocking=True)
+            ev_pm[b].record(sB)
         if F % CH == 0:
-            pcie_step(); torch.cuda.synchronize()
+            pcie_step(); pcie_step(); torch.cuda.synchronize()
             n_p = max(args.steps // 2, 3)
             tp = time.perf_counter()
             for _ in range(n_p):
@@ -598,8 +610,9 @@ def main():
             bytes_in, bytes_out = F * W * H, F * cap * 60 + F * 4 + NPAIR * cap * 4 + NPAIR * 4
             out["pcie_inclusive"] = {"value": float(h_n.sum().item()) / tp / 1e6, "unit": "Mkeypoints/s", "ms_per_step": tp * 1e3,
                                      "host_to_device_MB_per_step": bytes_in / 1e6, "device_to_host_MB_per_step": bytes_out / 1e6,
-                                     "note": "pinned host frames -> H2D on a copy stream (%d chunks per step, overlapped with the extraction of the previous chunk) -> extract -> "
-                                             "match -> keypoints, descriptors, counts and match lists back to pinned host memory; never the headline value" % CH}
+                                     "note": "pinned host frames -> H2D on a copy stream (%d chunks per step into one of two device image buffers, overlapped with the extraction of "
+                                             "earlier chunks) -> extract into one of two output sets -> match -> keypoints, descriptors, counts and match lists back to "
+                                             "pinned host memory; every buffer reuse ordered by events; never the headline value" % CH}
         del h_img, h_kps, h_desc, h_assigned, p_img, pexs
 
     # ---- configs 3 and 4: stereo streams (extract L + R, computeStereoMatches, consecutive left-frame search) ----------------------
