@@ -446,6 +446,9 @@ def main():
            "dtype": "u8", "data": "synthetic", "parity": "partial", "parity_note": PARITY_NOTE,
            "config": {"workload": "TUM-fr1-size 640x480 mono stream, 1000 feat/frame, extract + consecutive-frame searchByProjection (th 15); frames resident in HBM",
                       "frames_per_step_per_gpu": F, "extractor_handles": NEX, "distinct_frames": F * world, "frames_per_scene": args.segment,
+                      "pipelining": ("%d lanes (extractor handle + matcher + stream each) take consecutive steps; a step's extraction and matching run back to back "
+                                     "on its lane's stream, no events between lanes" % NEX) if args.alternate else
+                                    "one extractor handle; the matcher of step k on a second stream under the extraction of step k + 1",
                       "motion": "per frame: roll within +-3 deg, shift within +-8 px (bounded walk); prediction = true motion + N(0,1.5^2) px on the translation",
                       "keypoints_per_frame": n_kp_frame, "matches_per_pair": matched_local / max(NPAIR, 1),
                       "parallelism": ("frames dealt round-robin x%d, all-gather of [kp|desc|n] per step, local match against the gathered set" % world)
