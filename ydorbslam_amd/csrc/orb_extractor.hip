@@ -32,6 +32,7 @@ struct HostPlan {
   std::vector<CellDev> cells;
   size_t pyrFrameStride = 0, blurFrameStride = 0, qtFrameStride = 0;
   int maxCellDim = 0;   // largest FAST cell (without its 6-px halo): sizes the per-wave LDS of k_fast_cells
+  int levelCellDim[kMaxLevels]{};   // ... per level: a launch group takes the tile pitch and LDS of ITS largest cell
   // quad-tree launch geometry per level: node table for 4*quota nodes, LDS-resident candidates up to candCap (HBM beyond)
   struct QtLevel { int nodeCap, candCap; size_t lds; int flatItems; size_t flatLds; bool passOk; } qt[kMaxLevels]{};
   size_t qtLdsMax = 0;
@@ -258,6 +259,7 @@ int buildPlan(ydorb_extractor* e, int w, int h, HostPlan& P) {
     if (colsNum > 0 && rowsNum > 0) {
       const int cellW = (int)ceilf(width / colsNum), cellH = (int)ceilf(height / rowsNum);
       maxCellDim = std::max(maxCellDim, std::max(cellW, cellH));
+      P.levelCellDim[l] = std::max(cellW, cellH);
       for (int i = 0; i < rowsNum; i++) {
         const float iniY = (float)(minB + i * cellH);
         float maxY = iniY + cellH + 6;
@@ -509,18 +511,27 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   int grpFirst[kMaxLevels]{}, grpEnd[kMaxLevels]{}, nGroups = 0;   // level ranges of the FAST launches
   if (D.nCellsTotal > 0) {
     // one wave per cell, 4 cells per workgroup; the per-wave LDS (tile, score map, candidate list) is sized for the plan's largest cell
-    const int maxT = P.maxCellDim + 6, maxB = P.maxCellDim;
-    const bool narrow = maxT <= 44;
-    const int pitch = narrow ? 48 : 80;
-    FastLds fl;
-    fl.tileBytes = alignUp((maxT + 3) * pitch, 16);                 // + 3 rows: lanes outside the band still read (and discard) a ring
-    fl.scoreBytes = alignUp((maxB + 2) * (maxB + 2) + 4, 16);
-    fl.listBytes = alignUp(2 * maxB * maxB, 16);
-    const size_t dyn = (size_t)4 * (fl.tileBytes + fl.scoreBytes + fl.listBytes);
     const int thr = std::min(std::max(e->cfg.ini_fast_thr, 0), 255);
-    if (dyn > 48 * 1024) {
-      if (narrow) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells<48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-      else HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells<80>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    // LDS of a launch: sized for the largest cell of the levels it covers (one level with 40-px cells - 1241 x 376: level 5 - would
+    // otherwise put every launch on the 80-byte tile pitch and 66 KB per workgroup)
+    auto fastGeom = [&](int la, int lb, FastLds& fl, bool& narrow) -> size_t {
+      int dim = 1;
+      for (int l = la; l < lb; l++) dim = std::max(dim, P.levelCellDim[l]);
+      const int maxT = dim + 6, maxB = dim;
+      narrow = maxT <= 44;
+      const int pitch = narrow ? 48 : 80;
+      fl.tileBytes = alignUp((maxT + 3) * pitch, 16);                 // + 3 rows: lanes outside the band still read (and discard) a ring
+      fl.scoreBytes = alignUp((maxB + 2) * (maxB + 2) + 4, 16);
+      fl.listBytes = alignUp(2 * maxB * maxB, 16);
+      return (size_t)4 * (fl.tileBytes + fl.scoreBytes + fl.listBytes);
+    };
+    {
+      FastLds flAll; bool nAll;
+      const size_t dynAll = fastGeom(0, D.nLevels, flAll, nAll);
+      if (dynAll > 48 * 1024) {   // the largest any group can ask for
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells<48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynAll));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells<80>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynAll));
+      }
     }
     // The cells are launched in level groups - the first fastGroups - 1 levels each on their own, the rest together - so that the
     // quad-tree of a big level (its own stream, below) starts while the cells of the smaller levels are still being searched.
@@ -529,6 +540,8 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
       const int l1 = g == e->fastGroups - 1 ? D.nLevels : l0 + 1;
       const int c0 = D.lv[l0].cellBegin, c1 = D.lv[l1 - 1].cellBegin + D.lv[l1 - 1].nCells;
       if (c1 > c0) {
+        FastLds fl; bool narrow;
+        const size_t dyn = fastGeom(l0, l1, fl, narrow);
         const dim3 grid(((c1 - c0 + 3) / 4 + 7) / 8 * 8, nFrames);
         if (narrow) hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(256), dyn, s, e->d_pyr, P.pyrFrameStride, D, e->d_cells, c0, c1, thr, fl, e->d_cellCount, e->d_cellCand);
         else hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(256), dyn, s, e->d_pyr, P.pyrFrameStride, D, e->d_cells, c0, c1, thr, fl, e->d_cellCount, e->d_cellCand);
