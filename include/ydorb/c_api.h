@@ -71,13 +71,6 @@ typedef struct ydorb_extractor ydorb_extractor_t;
 int ydorb_extractor_create(const YdExtractorConfig* cfg, ydorb_extractor_t** out);
 void ydorb_extractor_destroy(ydorb_extractor_t* h);
 
-/* Side streams of the caller's choosing for the per-level quad-tree launches (level l uses streams[l % n]; n = 0: every launch on the call's
- * stream, as YDORB_EXTRACTOR_SINGLE_STREAM).  The streams are not owned by the handle and must outlive it or be replaced first.  Why: the
- * device runs 4 hardware queues and HIP assigns streams to them in creation order; a pipelined caller that creates its few streams first
- * (lane streams + these) keeps them on distinct queues, whereas a handle's own side streams may land on the queue of the very stream they
- * are meant to overlap (profiles/r02d_queue_overlap.txt). */
-int ydorb_extractor_set_side_streams(ydorb_extractor_t* h, void* const* streams, int32_t n);
-
 /* getScaleFactors / getInvScaleFactors / getScaleFactorSquares / getInvScaleFactorSquares and the
  * per-level keypoint quotas (src/orbExtractor.hpp:42-49, orbExtractor.cpp:325-339).  Each output may
  * be NULL; arrays hold n_levels entries. */
@@ -322,11 +315,6 @@ int ydorb_hamming_topk(ydorb_matcher_t* h, const uint8_t* q, int32_t nq, const u
 int ydorb_hamming_topk_device(ydorb_matcher_t* h, const uint8_t* d_qdesc, const int32_t* d_nq, const uint8_t* d_tdesc, const int32_t* d_nt,
                               int32_t cap, int32_t n_pairs, YdMatch2* d_out, void* stream);
 int ydorb_matcher_synchronize(ydorb_matcher_t* h);
-/* Pipelined callers: the ordered resolve of ydorb_match_pairs_device / ydorb_match_consecutive_device (one wave per frame pair, serial by
- * definition: a latency chain that uses next to nothing of the GPU) is launched on `stream` instead of the call's stream, behind an event, so
- * that the call's stream is free for the next step at once.  d_assigned / d_counts and the target keypoints are then in use until that
- * stream has run the resolve (ydorb_matcher_synchronize waits for everything).  NULL = back to the call's own stream. */
-int ydorb_matcher_set_resolve_stream(ydorb_matcher_t* h, void* stream);
 /* average device ms of grid build / gather / resolve over calls since enabling (HIP events on the launch stream) */
 int ydorb_matcher_set_profiling(ydorb_matcher_t* h, int32_t on);
 int ydorb_matcher_stage_times(ydorb_matcher_t* h, int32_t max_stages, const char** names, float* ms, int32_t* n_stages);

@@ -158,8 +158,8 @@ def test_pyramid_pads_written_by_level_kernels_and_by_border_launch(oracle_lib, 
             assert np.array_equal(d, cd)
 
 
-@pytest.mark.parametrize("kpw,stage", [("1", "0"), ("2", "0"), ("4", "0"), ("2", "1"), ("4", "1")])
-def test_describe_kernel_keypoints_per_wave(oracle_lib, monkeypatch, kpw, stage):
+@pytest.mark.parametrize("kpw", ["1", "2", "4"])
+def test_describe_kernel_keypoints_per_wave(oracle_lib, monkeypatch, kpw):
     """k_orient_describe_n<KPW> interleaves KPW keypoints in one wave (batch handles use 4, single-frame handles 1): the same
     keypoints, angles and descriptors whatever KPW is - also where a wave's slots straddle two levels or end past the last keypoint
     (the half-empty and the nearly empty frame)."""
@@ -170,10 +170,8 @@ def test_describe_kernel_keypoints_per_wave(oracle_lib, monkeypatch, kpw, stage)
     frames[2][100:150, 100:160] = synth_frame(640, 480, 43)[100:150, 100:160]
     imgs = np.stack(frames)
     monkeypatch.setenv("YDORB_DESC_KPW", kpw)
-    monkeypatch.setenv("YDORB_DESC_STAGE", stage)   # 1: test points from an LDS copy of the blurred neighbourhood
     gpu = y.OrbExtractor(1000, 1.2, 8, 20, 7, max_batch=len(frames))
     monkeypatch.delenv("YDORB_DESC_KPW")
-    monkeypatch.delenv("YDORB_DESC_STAGE")
     res = gpu.extract_batch(imgs)
     for f, img in enumerate(frames):
         ck, cd = OrbExtractorOracle(1000, 1.2, 8, 20, 7).extract(img)
@@ -292,35 +290,3 @@ def test_batched_handle_paths_match_the_oracle(oracle_lib, monkeypatch, w, h, nf
         ck, cd = OrbExtractorOracle(nf, 1.2, 8, 20, 7).extract(img)
         _same_kps(res[f][0], ck)
         assert np.array_equal(res[f][1], cd)
-
-
-@pytest.mark.parametrize("n_side", [0, 1, 3])
-def test_caller_provided_side_streams(oracle_lib, n_side):
-    """ydorb_extractor_set_side_streams: the per-level quad-tree launches on the caller's streams (level l -> streams[l % n]; none =
-    everything on the call's stream).  Same keypoints and descriptors; the handle's own side streams are retired, not leaked."""
-    import torch
-    import ydorbslam_amd as y
-    from oracle.orb_oracle import OrbExtractorOracle
-    dev = torch.device("cuda:0")
-    side = [torch.cuda.Stream(device=dev) for _ in range(n_side)]
-    main = torch.cuda.Stream(device=dev)
-    imgs = np.stack([synth_frame(640, 480, 70 + i) for i in range(10)])
-    ex = y.OrbExtractor(1000, 1.2, 8, 20, 7, max_batch=10)
-    ex.set_side_streams([s.cuda_stream for s in side])
-    cap = ex.max_keypoints
-    d_img = torch.from_numpy(imgs).to(dev)
-    d_kps = torch.zeros((10, cap, 7), dtype=torch.float32, device=dev)
-    d_desc = torch.zeros((10, cap, 32), dtype=torch.uint8, device=dev)
-    d_n = torch.zeros(10, dtype=torch.int32, device=dev)
-    for _ in range(2):
-        ex.extract_batch_device(d_img.data_ptr(), 640, 480, 640, 640 * 480, 10, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(), main.cuda_stream)
-    ex.synchronize()
-    torch.cuda.synchronize()
-    n = d_n.cpu().numpy()
-    kps = d_kps.cpu().numpy().view(np.uint8).reshape(10, cap, 28).view(y.KP_DTYPE).reshape(10, cap)
-    desc = d_desc.cpu().numpy()
-    for f in (0, 4, 9):
-        ck, cd = OrbExtractorOracle(1000, 1.2, 8, 20, 7).extract(imgs[f])
-        _same_kps(kps[f, :n[f]], ck)
-        assert np.array_equal(desc[f, :n[f]], cd)
-    del ex

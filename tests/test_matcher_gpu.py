@@ -342,9 +342,10 @@ def test_new_entry_points_on_empty_and_ragged_inputs(oracle_lib):
         m.match_pairs_device(fs, fs, [(0, 3)], 640, 480, 15.0, sf, asg.data_ptr(), cnt.data_ptr())
 
 
-def test_resolve_on_a_side_stream_gives_the_same_matches():
-    """ydorb_matcher_set_resolve_stream: the ordered resolve of the device-resident search runs on another stream behind an event
-    (pipelined callers keep the call's stream free); match lists and counts equal those of the plain call."""
+def test_back_to_back_calls_on_one_handle_without_synchronize():
+    """Two device-resident searches issued back to back on ONE handle and ONE stream, no synchronize between them, different output
+    buffers: the second call reuses the handle's scratch (queries, record pool, taken flags) behind the first call's resolve in stream
+    order, so both outputs equal those of separately synchronized calls."""
     import torch
     import ydorbslam_amd as y
     from ydorbslam_amd.synth import synth_frame
@@ -361,20 +362,16 @@ def test_resolve_on_a_side_stream_gives_the_same_matches():
     ex.extract_batch_device(d_img.data_ptr(), W, H, W, W * H, F, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr())
     ex.synchronize()
     sf = ex.tables()["scale"]
-    out = []
-    side = torch.cuda.Stream(device=dev)
     main = torch.cuda.Stream(device=dev)
-    for use_side in (False, True, False):
-        m = y.OrbMatcher(0.9, True)
-        if use_side:
-            m.set_resolve_stream(side.cuda_stream)
-        a = torch.zeros((F - 1, cap), dtype=torch.int32, device=dev)
-        c = torch.zeros(F - 1, dtype=torch.int32, device=dev)
-        for _ in range(2):   # twice: the second call reuses the handle's scratch behind the first resolve
-            m.match_consecutive_device(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, F, W, H, 15.0, sf, a.data_ptr(), c.data_ptr(),
-                                       stream=main.cuda_stream)
-            m.synchronize()
-        out.append((a.cpu().numpy(), c.cpu().numpy()))
-    assert out[0][1].sum() > 100
-    for a, c in out[1:]:
-        assert np.array_equal(a, out[0][0]) and np.array_equal(c, out[0][1])
+    m = y.OrbMatcher(0.9, True)
+    ref_a = torch.zeros((F - 1, cap), dtype=torch.int32, device=dev)
+    ref_c = torch.zeros(F - 1, dtype=torch.int32, device=dev)
+    m.match_consecutive_device(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, F, W, H, 15.0, sf, ref_a.data_ptr(), ref_c.data_ptr(), stream=main.cuda_stream)
+    m.synchronize()
+    outs = [(torch.zeros_like(ref_a), torch.zeros_like(ref_c)) for _ in range(3)]
+    for a, c in outs:
+        m.match_consecutive_device(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, F, W, H, 15.0, sf, a.data_ptr(), c.data_ptr(), stream=main.cuda_stream)
+    m.synchronize()
+    assert int(ref_c.sum()) > 100
+    for a, c in outs:
+        assert torch.equal(a, ref_a) and torch.equal(c, ref_c)

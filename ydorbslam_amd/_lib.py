@@ -74,8 +74,6 @@ SYMBOLS = {
     "ydorb_hamming_topk_device": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
     "ydorb_matcher_synchronize": (C.c_int, [_VP]),
     "ydorb_matcher_set_profiling": (C.c_int, [_VP, _I]),
-    "ydorb_matcher_set_resolve_stream": (C.c_int, [_VP, _VP]),
-    "ydorb_extractor_set_side_streams": (C.c_int, [_VP, C.POINTER(_VP), _I]),
     "ydorb_matcher_stage_times": (C.c_int, [_VP, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_I)]),
     "ydorb_ba_default_options": (None, [_VP]),
     "ydorb_ba_solve": (C.c_int, [_VP, _VP, _VP]),

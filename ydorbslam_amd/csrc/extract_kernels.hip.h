@@ -48,15 +48,8 @@ struct PlanDev {
   int borderBegin[kMaxLevels + 1];     // first border thread of each level in k_pyr_borders' flat per-frame list (multiples of 256)
   LevelDev lv[kMaxLevels];
 };
-#ifndef BLUR_TH
-#define BLUR_TH 32
-#endif
-// Tile height (any value with TH + 6 even).  64 x 58 tiles make 58 + 6 = 64 source rows = 32 row pairs x 16 dword groups = exactly two
-// full passes of the workgroup in the horizontal stage (a 32-row tile runs 304 tasks on 2 x 256 threads) with a 10 % halo instead of
-// 19 %: 0.69 -> 0.54 ms per 512 frames with nothing else on the GPU (0.49 with 90 rows).  In the two-lane pipeline the same build is
-// 3 % SLOWER (189 against 195 Mkeypoints/s, three alternating runs each): the blur then ends before the quad-tree chain it hides and the
-// lane's descriptor kernel starts no earlier, while fewer, longer blur workgroups leave the other lane's kernels less room.  32 it stays.
-constexpr int kBlurTW = 64, kBlurTH = BLUR_TH;
+// 64 x 32 output tiles (taller tiles make the blur alone faster but the two-lane pipeline slower: DESIGN.md section 6)
+constexpr int kBlurTW = 64, kBlurTH = 32;
 struct CellDev {            // FAST sub-image [x0,x1) x [y0,y1) in level coordinates (orbExtractor.cpp:562-581)
   short level, x0, y0, x1, y1, pad0;
   int srcOff;               // byte offset of the sub-image's first pixel inside a frame's pyramid block (host-computed)
@@ -1442,14 +1435,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
 // keypoint + level counts, the orientation patch, the rotated test points) with little arithmetic between them, and a CU holds at
 // most 32 waves, so one keypoint per wave leaves the vector ALUs idle half of the time.  With KPW keypoints the loads of all of
 // them are in flight together.  Arithmetic per keypoint is unchanged (same operations in the same order).
-// STAGE: the 37 x 37 neighbourhood of the blurred level that the 512 rotated test points fall into is copied to LDS first - 7 aligned
-// dword loads per lane, issued together with the orientation loads (they need the keypoint position only, not its angle) - and the test
-// points are LDS byte reads.  The 8 byte gathers per lane of the direct form each touch ~30 cache lines (a wave's 64 test points spread
-// over 37 rows) and keep the texture-address path 77 % busy; the row loads touch ~9.  Measured per 512 frames, nothing else on the GPU:
-// 0.477 ms direct (KPW 4) -> 0.441 staged KPW 4 -> 0.410 staged KPW 2; extraction alone gains 2 %, but the two-lane extract + match pipeline
-// does not (191 against 194 Mkeypoints/s, two alternating runs each): YDORB_DESC_STAGE=1 turns it on, the default stays the direct form.
-constexpr int kDescPatchR = 18, kDescPatchRows = 2 * kDescPatchR + 1, kDescPatchDw = 11, kDescPatchPitch = 4 * kDescPatchDw;
-template <int KPW, bool STAGE>
+template <int KPW>
 __global__ __launch_bounds__(256) void k_orient_describe_n(const uint8_t* __restrict__ pyr, size_t pyrFrameStride,
                                                            const uint8_t* __restrict__ blur, size_t blurFrameStride, PlanDev P,
                                                            const uint32_t* __restrict__ lvlKp, const int* __restrict__ lvlCount,
@@ -1517,24 +1503,6 @@ __global__ __launch_bounds__(256) void k_orient_describe_n(const uint8_t* __rest
     const uint8_t* roi = pyr + (size_t)f * pyrFrameStride + L.padOff + (size_t)kPad * L.pitch + kPad;
     org[j] = roi + (ptrdiff_t)(ky[j] - 15) * L.pitch + (kx[j] - 32);
   }
-  __shared__ __align__(16) uint8_t patchLds[STAGE ? 4 * KPW * kDescPatchRows * kDescPatchPitch : 16];
-  constexpr int kStageIters = (kDescPatchRows * kDescPatchDw + 63) / 64;
-  uint32_t pdw[STAGE ? KPW : 1][STAGE ? kStageIters : 1];
-  int dxo[KPW];   // column of the keypoint inside its staged rows
-  if (STAGE) {
-#pragma unroll
-    for (int j = 0; j < KPW; j++) {
-      const LevelDev& L = P.lv[level[j]];
-      const int x0 = (kx[j] - kDescPatchR) & ~3;
-      dxo[j] = kx[j] - x0;
-      const uint8_t* src = blur + (size_t)f * blurFrameStride + L.blurOff + (ptrdiff_t)(ky[j] - kDescPatchR) * L.blurPitch + x0;
-#pragma unroll
-      for (int it = 0; it < kStageIters; it++) {
-        const int i = it * 64 + lane, row = (i * 745) >> 13, dw = i - row * kDescPatchDw;   // i / 11 for i < 448
-        pdw[j][it] = i < kDescPatchRows * kDescPatchDw ? *reinterpret_cast<const uint32_t*>(src + (ptrdiff_t)row * L.blurPitch + 4 * dw) : 0u;
-      }
-    }
-  }
   const int u = lane - 32;
   unsigned narrow = 0;
 #pragma unroll
@@ -1580,15 +1548,6 @@ __global__ __launch_bounds__(256) void k_orient_describe_n(const uint8_t* __rest
     float sinB, cosA;
     sincos_det(rad, &sinB, &cosA);
     const uint8_t* bl = blur + (size_t)f * blurFrameStride + L.blurOff + (ptrdiff_t)(ky[j] - kBias) * L.blurPitch + (kx[j] - kBias);
-    uint8_t* myPatch = patchLds + (STAGE ? ((threadIdx.x >> 6) * KPW + j) * kDescPatchRows * kDescPatchPitch : 0);
-    if (STAGE) {   // this wave's copy of the neighbourhood (a wave reads only what it wrote: program order, no barrier)
-#pragma unroll
-      for (int it = 0; it < kStageIters; it++) {
-        const int i = it * 64 + lane;
-        if (i < kDescPatchRows * kDescPatchDw) reinterpret_cast<uint32_t*>(myPatch)[i] = pdw[j][it];
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       const float4 pt = pat[t];
@@ -1596,13 +1555,8 @@ __global__ __launch_bounds__(256) void k_orient_describe_n(const uint8_t* __rest
       const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(pt.x, cosA), __fmul_rn(pt.y, sinB)));
       const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(pt.z, sinB), __fmul_rn(pt.w, cosA)));
       const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(pt.z, cosA), __fmul_rn(pt.w, sinB)));
-      if (STAGE) {
-        tA[j][t] = myPatch[(r0 + kDescPatchR) * kDescPatchPitch + c0 + dxo[j]];
-        tB[j][t] = myPatch[(r1 + kDescPatchR) * kDescPatchPitch + c1 + dxo[j]];
-      } else {
-        tA[j][t] = bl[(unsigned)((r0 + kBias) * L.blurPitch + c0 + kBias)];
-        tB[j][t] = bl[(unsigned)((r1 + kBias) * L.blurPitch + c1 + kBias)];
-      }
+      tA[j][t] = bl[(unsigned)((r0 + kBias) * L.blurPitch + c0 + kBias)];
+      tB[j][t] = bl[(unsigned)((r1 + kBias) * L.blurPitch + c1 + kBias)];
     }
   }
 #pragma unroll

@@ -61,11 +61,8 @@ struct ydorb_extractor {
   int sumQuota = 0;
   hipStream_t stream = nullptr;
   hipStream_t qtStream[kMaxLevels]{};   // side streams of the per-level quad-tree launches
-  bool userSide = false;                // qtStream[] are the caller's (ydorb_extractor_set_side_streams): not destroyed here
-  std::vector<hipStream_t> ownedSide;   // the handle's own side streams after they were replaced
   hipEvent_t evFork = nullptr, evJoin[kMaxLevels]{};
   hipEvent_t evFast[kMaxLevels]{};      // end of the FAST launch that covers level l (levels are launched in groups)
-  bool descStage = false;               // YDORB_DESC_STAGE=1: descriptor test points from an LDS copy of the blurred neighbourhood
   int descKpw = 2;                      // keypoints per wave of k_orient_describe_n
   bool qtGrouped = false;               // batched handles: one quad-tree launch per FAST level group instead of one per level
   bool qtInline = false;                // YDORB_QT_STREAMS=0: the quad-tree launches go on the caller's stream, behind the blur
@@ -617,13 +614,13 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   {
     const int kpw = e->descKpw;   // keypoints per wave (YDORB_DESC_KPW: 1, 2 or 4)
     const dim3 gd(((D.sumQuota + 4 * kpw - 1) / (4 * kpw) + 7) / 8 * 8, nFrames);
-#define YD_DESC(K, ST) hipLaunchKernelGGL((k_orient_describe_n<K, ST>), gd, dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur, P.blurFrameStride, D, \
+#define YD_DESC(K) hipLaunchKernelGGL((k_orient_describe_n<K>), gd, dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur, P.blurFrameStride, D, \
                                          e->d_lvlKp, e->d_lvlCount, d_kps, d_desc, cap, d_nOut, e->d_lvlAngle)
     if (kpw == 1)
       hipLaunchKernelGGL(k_orient_describe, gd, dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
                          P.blurFrameStride, D, e->d_lvlKp, e->d_lvlCount, d_kps, d_desc, cap, d_nOut, e->d_lvlAngle);
-    else if (kpw == 2) { if (e->descStage) YD_DESC(2, true); else YD_DESC(2, false); }
-    else { if (e->descStage) YD_DESC(4, true); else YD_DESC(4, false); }
+    else if (kpw == 2) YD_DESC(2);
+    else YD_DESC(4);
 #undef YD_DESC
   }
   if (prof) { HIPCHK(hipEventRecord(e->ev[5], s)); e->profPending = true; }
@@ -685,7 +682,6 @@ int ydorb_extractor_create(const YdExtractorConfig* cfg, ydorb_extractor_t** out
   // keypoints per wave of the orientation + descriptor kernel: 4 for batches (their loads overlap: 0.56 -> 0.47 ms per 512 frames); a
   // single-frame handle keeps one keypoint per wave (1000 short waves spread over the chip finish sooner than 250 long ones)
   e->descKpw = cfg->max_batch <= 8 ? 1 : 4;
-  if (const char* v = getenv("YDORB_DESC_STAGE")) e->descStage = atoi(v) != 0;
   if (const char* v = getenv("YDORB_DESC_KPW")) e->descKpw = atoi(v) == 1 ? 1 : atoi(v) == 4 ? 4 : 2;
   e->cfg.min_fast_thr = cfg->ini_fast_thr;  // reference quirk, orbExtractor.cpp:318
   // constructor tables, orbExtractor.cpp:319-353
@@ -761,7 +757,7 @@ void ydorb_extractor_destroy(ydorb_extractor_t* e) {
   freeBuffers(e);
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   for (int l = 0; l < kMaxLevels; l++) {
-    if (e->qtStream[l] && !e->userSide) {
+    if (e->qtStream[l]) {
       bool shared = false;
       for (int k = 0; k < l; k++) shared = shared || e->qtStream[k] == e->qtStream[l];
       if (!shared) { (void)hipStreamSynchronize(e->qtStream[l]); (void)hipStreamDestroy(e->qtStream[l]); }
@@ -769,28 +765,9 @@ void ydorb_extractor_destroy(ydorb_extractor_t* e) {
     if (e->evJoin[l]) (void)hipEventDestroy(e->evJoin[l]);
     if (e->evFast[l]) (void)hipEventDestroy(e->evFast[l]);
   }
-  {
-    std::vector<hipStream_t> seen;
-    for (hipStream_t st : e->ownedSide) {
-      bool dup = false;
-      for (hipStream_t t : seen) dup = dup || t == st;
-      if (!dup) { seen.push_back(st); (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-    }
-  }
   if (e->evFork) (void)hipEventDestroy(e->evFork);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
-}
-
-int ydorb_extractor_set_side_streams(ydorb_extractor_t* e, void* const* streams, int32_t n) {
-  if (!e || n < 0 || n > kMaxLevels || (n > 0 && !streams)) { set_error("invalid argument"); return YDORB_ERR_INVALID_ARG; }
-  HIPCHK(hipSetDevice(e->cfg.device));
-  // the handle's own side streams stay alive (they may still carry work) and are destroyed with the handle
-  for (int l = 0; l < kMaxLevels; l++) if (e->qtStream[l] && !e->userSide) e->ownedSide.push_back(e->qtStream[l]);
-  e->userSide = true;
-  e->qtInline = n == 0;
-  for (int l = 0; l < kMaxLevels; l++) e->qtStream[l] = n ? (hipStream_t)streams[l % n] : nullptr;
-  return YDORB_OK;
 }
 
 int ydorb_extractor_tables(const ydorb_extractor_t* e, float* scale, float* inv_scale, float* scale_sq, float* inv_scale_sq,

@@ -71,8 +71,6 @@ const char* kMatchStageNames[MS_COUNT] = {"grid_build", "gather_distances", "res
 struct ydorb_matcher {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t resolveStream = nullptr;   // ydorb_matcher_set_resolve_stream
-  hipEvent_t evGathered = nullptr;
   Buf kps, desc, rightX, queries, qdesc, taken, assigned, matchQ, qInfo, qPre, cellStart, cellIdx, pool, frames, calls, misc, kps2,
       desc2, feat, valid, qFeat, qRange, qAngle, sf, heads, sortedKp, sortedDesc, kps1, good1, good2, stereoPar, stereoCnt, stereoOut;
   size_t poolRecords = 1u << 20;
@@ -173,8 +171,6 @@ void ydorb_matcher_destroy(ydorb_matcher_t* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   (void)hipStreamSynchronize(m->stream);
-  if (m->resolveStream) (void)hipStreamSynchronize(m->resolveStream);
-  if (m->evGathered) (void)hipEventDestroy(m->evGathered);
   for (Buf* b : {&m->kps, &m->desc, &m->rightX, &m->queries, &m->qdesc, &m->taken, &m->assigned, &m->matchQ, &m->qInfo, &m->qPre, &m->cellStart,
                  &m->cellIdx, &m->pool, &m->frames, &m->calls, &m->misc, &m->kps2, &m->desc2, &m->feat, &m->valid, &m->qFeat, &m->qRange,
                  &m->qAngle, &m->sf, &m->heads, &m->sortedKp, &m->sortedDesc, &m->kps1, &m->good1, &m->good2, &m->stereoPar, &m->stereoCnt,
@@ -724,16 +720,9 @@ int ydorb_match_pairs_device(ydorb_matcher_t* m, const YdFrameSetDev* Q, const Y
                      m->pool.as<uint32_t>(), m->heads.as<unsigned>(), (unsigned)poolPerCall, m->misc.as<int>() + 1);
   if (prof) HIPCHK(hipEventRecord(m->ev[2], s));
   const int takenWords = (cap + 31) / 32;
-  hipStream_t rs = s;
-  if (m->resolveStream && m->resolveStream != s) {
-    if (!m->evGathered) HIPCHK(hipEventCreateWithFlags(&m->evGathered, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(m->evGathered, s));
-    HIPCHK(hipStreamWaitEvent(m->resolveStream, m->evGathered, 0));
-    rs = m->resolveStream;
-  }
-  hipLaunchKernelGGL(k_resolve, dim3(nCalls), dim3(64), sizeof(unsigned) * takenWords, rs, m->calls.as<CallDev>(), m->frames.as<FrameDev>(),
+  hipLaunchKernelGGL(k_resolve, dim3(nCalls), dim3(64), sizeof(unsigned) * takenWords, s, m->calls.as<CallDev>(), m->frames.as<FrameDev>(),
                      m->pool.as<uint32_t>(), takenWords);
-  if (prof) { HIPCHK(hipEventRecord(m->ev[3], rs)); m->evPending = true; }
+  if (prof) { HIPCHK(hipEventRecord(m->ev[3], s)); m->evPending = true; }
   HIPCHK(hipGetLastError());
   return YDORB_OK;
 }
@@ -818,12 +807,6 @@ int ydorb_matcher_synchronize(ydorb_matcher_t* m) {
       return YDORB_ERR_CAPACITY;
     }
   }
-  return YDORB_OK;
-}
-
-int ydorb_matcher_set_resolve_stream(ydorb_matcher_t* m, void* stream) {
-  if (!m) { set_error("null handle"); return YDORB_ERR_INVALID_ARG; }
-  m->resolveStream = (hipStream_t)stream;
   return YDORB_OK;
 }
 

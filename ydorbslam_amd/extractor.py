@@ -23,11 +23,6 @@ class OrbExtractor:
         self.n_levels = n_levels
         self.max_keypoints = self._L.ydorb_extractor_max_keypoints(self._h)
 
-    def set_side_streams(self, streams):
-        """Raw hipStream_t handles for the per-level quad-tree launches (level l -> streams[l % n]); [] = everything on the call's stream."""
-        arr = (C.c_void_p * max(len(streams), 1))(*streams)
-        check(self._L.ydorb_extractor_set_side_streams(self._h, arr, len(streams)))
-
     def close(self):
         if getattr(self, "_h", None):
             self._L.ydorb_extractor_destroy(self._h)

@@ -226,10 +226,6 @@ class OrbMatcher:
     def set_profiling(self, on=True):
         check(self._L.ydorb_matcher_set_profiling(self._h, int(on)))
 
-    def set_resolve_stream(self, stream):
-        """The ordered resolve of the device-resident searches goes on `stream` (a raw hipStream_t) behind an event; None = the call's stream."""
-        check(self._L.ydorb_matcher_set_resolve_stream(self._h, stream))
-
     def stage_times(self):
         names = (C.c_char_p * 8)()
         ms = (C.c_float * 8)()
