@@ -652,7 +652,15 @@ int ydorb_match_pairs_device(ydorb_matcher_t* m, const YdFrameSetDev* Q, const Y
     }
   HIPCHK(hipSetDevice(m->device));
   hipStream_t s = stream ? (hipStream_t)stream : m->stream;
-  const int cap = Q->cap, nFrames = T->n_frames;
+  // grids are built only for the frames that appear as a pair's TARGET: on the multi-GPU path T is the all-gathered set (world x F
+  // frames) of which this rank searches its own F
+  std::vector<int> tmap(T->n_frames, -1);
+  std::vector<int> tused;
+  for (int c = 0; c < nCalls; c++) {
+    const int tf = pairs[2 * c + 1];
+    if (tmap[tf] < 0) { tmap[tf] = (int)tused.size(); tused.push_back(tf); }
+  }
+  const int cap = Q->cap, nFrames = (int)tused.size();
   const size_t poolPerCall = (size_t)cap * kSlot + (size_t)cap * m->ovfPerKeypoint;  // fixed slots + overflow region (records of queries with > kSlot candidates)
   int rc;
   if ((rc = m->queries.ensure(sizeof(QueryDev) * (size_t)cap * nCalls)) || (rc = m->taken.ensure((size_t)cap * nCalls)) ||
@@ -668,16 +676,17 @@ int ydorb_match_pairs_device(ydorb_matcher_t* m, const YdFrameSetDev* Q, const Y
   std::vector<CallDev> hc(nCalls);
   const float minX = 0.f, minY = 0.f, maxX = (float)width, maxY = (float)height;  // Frame::computeImageBounds without distortion
   for (int f = 0; f < nFrames; f++) {
+    const int tf = tused[f];
     FrameDev F{};
-    F.kps = reinterpret_cast<const KeyPointDev*>(T->d_kps) + (size_t)f * cap; F.desc = T->d_desc + (size_t)f * cap * 32; F.rightX = nullptr;
-    F.nPtr = T->d_n + f; F.n = 0; F.minX = minX; F.minY = minY;
+    F.kps = reinterpret_cast<const KeyPointDev*>(T->d_kps) + (size_t)tf * cap; F.desc = T->d_desc + (size_t)tf * cap * 32; F.rightX = nullptr;
+    F.nPtr = T->d_n + tf; F.n = 0; F.minX = minX; F.minY = minY;
     F.gridWInv = static_cast<float>(kGridCols) / (maxX - minX); F.gridHInv = static_cast<float>(kGridRows) / (maxY - minY);
     F.cellStart = m->cellStart.as<int>() + (size_t)f * (kGridCells + 1); F.cellIdx = m->cellIdx.as<int>() + (size_t)f * cap;
     F.sortedKp = m->sortedKp.as<float4>() + (size_t)f * cap; F.sortedDesc = m->sortedDesc.as<uint8_t>() + (size_t)f * cap * 32;
     hf[f] = F;
   }
   for (int c = 0; c < nCalls; c++) {
-    const int qf = pairs[2 * c], tf = pairs[2 * c + 1];
+    const int qf = pairs[2 * c], tf = tmap[pairs[2 * c + 1]];
     CallDev C{};
     C.frame = tf; C.tkps = hf[tf].kps; C.qAngle = nullptr; C.queries = m->queries.as<QueryDev>() + (size_t)c * cap;
     C.qkps = reinterpret_cast<const KeyPointDev*>(Q->d_kps) + (size_t)qf * cap;
