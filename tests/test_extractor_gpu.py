@@ -106,9 +106,9 @@ def test_strided_input(oracle_lib):
 
 
 def test_quadtree_flat_and_pass_kernels_agree(oracle_lib, monkeypatch):
-    """The thinning has two device forms: the flat one (histogram pyramid / all-pairs prefixes + one stable sort,
-    quadtree_flat.h) and the pass one (quadtree_core.h, taken for units the flat form hands over).  Both must give the
-    oracle's keypoints on dense frames, sparse frames (deep trees: few candidates, nearly all kept) and the real image."""
+    """The thinning has two device forms: the rank one (k_qt_fast: histogram pyramid, list positions from one scan, per-node maxima,
+    quadtree_flat.h) and the pass one (quadtree_core.h, taken for units the rank form hands over).  Both must give the
+    oracle's keypoints on dense frames, sparse frames (few candidates, nearly all kept) and the real image."""
     import os
     import ydorbslam_amd as y
     from oracle.orb_oracle import OrbExtractorOracle
@@ -128,7 +128,7 @@ def test_quadtree_flat_and_pass_kernels_agree(oracle_lib, monkeypatch):
             _same_kps(k, ck)
             assert np.array_equal(d, cd)
         for l in range(8):
-            assert flat.debug_read(3, l, f) == 0      # the flat kernel itself finished every one of these units
+            assert flat.debug_read(3, l, f) == 0      # k_qt_fast itself finished every one of these units
             assert passk.debug_read(3, l, f) == 1
 
 
@@ -266,13 +266,11 @@ def test_read_pyramid_single_transfer_equals_level_reads():
             assert np.array_equal(lv[l], ex.read_level(l, f)), "frame %d level %d" % (f, l)
 
 
-@pytest.mark.parametrize("w,h,nf,grouped,single", [(640, 480, 1000, "0", False), (752, 480, 1000, "0", False), (640, 480, 1000, "1", False),
-                                                   (640, 480, 1000, "0", True)])
-def test_batched_handle_paths_match_the_oracle(oracle_lib, monkeypatch, w, h, nf, grouped, single):
+@pytest.mark.parametrize("w,h,nf,single", [(640, 480, 1000, False), (752, 480, 1000, False), (640, 480, 1000, True), (1241, 376, 2000, True)])
+def test_batched_handle_paths_match_the_oracle(oracle_lib, w, h, nf, single):
     """A handle for more than 8 frames per call takes the throughput paths the headline bench runs: FAST cells launched in two level
-    groups, four keypoints per wave in the descriptor kernel and - with YDORB_QT_GROUPED=1 - one quad-tree launch per
-    level group (k_quadtree_flat_levels) instead of one per level; `single` = a YDORB_EXTRACTOR_SINGLE_STREAM handle (every launch on the
-    call's stream: what bench.py's stereo lanes use).  Twelve frames of
+    groups, one quad-tree launch (k_qt_fast) per group, four keypoints per wave in the descriptor kernel; `single` = a
+    YDORB_EXTRACTOR_SINGLE_STREAM handle (every launch on the call's stream: what bench.py's lanes use).  Twelve frames of
     mixed content (textured, half empty, nearly empty) - twice, so that the second call runs with the retuned quad-tree footprints -
     against the oracle, frame by frame."""
     import ydorbslam_amd as y
@@ -281,9 +279,7 @@ def test_batched_handle_paths_match_the_oracle(oracle_lib, monkeypatch, w, h, nf
     frames[3] = frames[3].copy(); frames[3][: h // 2] = 128
     frames[7] = np.full((h, w), 90, np.uint8); frames[7][100:150, 100:160] = synth_frame(w, h, 63)[100:150, 100:160]
     imgs = np.stack(frames)
-    monkeypatch.setenv("YDORB_QT_GROUPED", grouped)
     gpu = y.OrbExtractor(nf, 1.2, 8, 20, 7, max_batch=12, single_stream=single)
-    monkeypatch.delenv("YDORB_QT_GROUPED")
     gpu.extract_batch(imgs)
     res = gpu.extract_batch(imgs)
     for f, img in enumerate(frames):

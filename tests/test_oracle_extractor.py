@@ -160,6 +160,45 @@ def test_flat_quadtree_formulation_matches_pass_algorithm(qt_harness):
     assert 0 < deep < 200
 
 
+def test_rank_quadtree_formulation_matches_pass_algorithm(qt_harness):
+    """The form k_qt_fast runs (quadtree_flat.h "rank form", restated sequentially in the harness): path keys from the two axis tables
+    (checked against qt_path_key for every candidate: -9 otherwise), depth-6 pyramid, list positions from one pass over the permuted
+    quads, per-node maxima, introsort replay only for tied nodes of more than 16 members.  Against the pass algorithm on random,
+    clustered, shuffled and heavily tied (few distinct responses) candidate sets; -2 = a unit the kernel hands to the pass kernel."""
+    rng = np.random.default_rng(6)
+    handed, tied_runs = 0, 0
+    for t in range(500):
+        W, H = int(rng.integers(2, 1300)), int(rng.integers(2, 500))
+        mode = int(rng.integers(0, 4))
+        n = min(int(rng.integers(1, 6000)) if mode else int(rng.integers(1, 40)), W * H)
+        if mode == 2:
+            cx, cy, k = rng.integers(0, W, 6), rng.integers(0, H, 6), rng.integers(0, 6, n)
+            x = np.clip(cx[k] + rng.normal(0, 9, n), 0, W - 1).astype(np.int64)
+            y = np.clip(cy[k] + rng.normal(0, 9, n), 0, H - 1).astype(np.int64)
+            pix = np.unique(y * W + x)
+        else:
+            pix = np.sort(rng.choice(W * H, n, replace=False))
+        if mode == 3:
+            pix = rng.permutation(pix)
+        n = len(pix)
+        hi_r = int(rng.choice([9, 12, 30, 255]))
+        tied_runs += hi_r <= 12
+        r = rng.integers(7, hi_r, n).astype(np.uint32)
+        packed = ((pix % W).astype(np.uint32) | ((pix // W).astype(np.uint32) << 12) | (r << 24)).astype(np.uint32)
+        quota = int(rng.choice([1, 2, 5, 30, 60, 120, 217, 434, 1000]))
+        ref, a = (np.zeros(4 * quota + 8, np.uint32) for _ in range(2))
+        P = C.c_int(0)
+        pp = packed.ctypes.data_as(C.c_void_p)
+        n0 = qt_harness.qt_cpu_distribute(pp, n, W, H, quota, ref.ctypes.data_as(C.c_void_p))
+        n1 = qt_harness.qt_rank_distribute(pp, n, W, H, quota, a.ctypes.data_as(C.c_void_p), C.byref(P))
+        if n1 == -2:
+            handed += 1
+        else:
+            assert n1 == n0, (t, n1, n0)
+            assert np.array_equal(a[:n0], ref[:n0]), t
+    assert handed < 250 and tied_runs > 50
+
+
 def test_sort_front_emulation_matches_libstdcxx(qt_harness):
     """Best-per-node uses std::sort(...).front() (orbExtractor.cpp:536-539); ties depend on libstdc++'s introsort."""
     rng = np.random.default_rng(0)

@@ -10,7 +10,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <rocprim/block/block_radix_sort.hpp>
 #include "quadtree_core.h"
 #include "quadtree_flat.h"
 
@@ -797,26 +796,41 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(PlanDev P, const uint32
 }
 
 // ------------------------------------------------------------------------------------------------
-// Quad-tree thinning without passes (quadtree_flat.h): path keys -> histogram pyramid (all-pairs prefixes when a unit with
-// <= 1024 candidates has a tree deeper than the pyramid) -> number of passes P the reference would run -> final list rank R per candidate -> ONE stable sort by R ->
-// best keypoint of the first `quota` nodes.  One 512-thread workgroup per (frame, level); units the flat form cannot take
-// (more candidates than 512*ITEMS, or a tree deeper than the pyramid) raise needPass and k_quadtree (the pass algorithm)
-// processes exactly those afterwards.
-// LDS: cand u32[CAP] | union{hist pyramid u16[21845], sort storage + 512 hand-off keys, keys of the std::sort replay u32[CAP],
-//      all-pairs key/R arrays, cellBase} | head flags u8[CAP] | nodeStart u16[quota+2] | per-node max keys u32[2][quota+1]
+// Quad-tree thinning without passes and without a sort (closed form: quadtree_flat.h).  One 256-thread workgroup per (frame, level)
+// unit, ONE launch for a range of levels, ~20 KB of LDS, one register of state per candidate (ITEMS per thread, flat index
+// i = j*256 + tid):
+//   1. scan of the level's cell counts -> cell bases (u16); a thread finds candidate i by a 10-step binary search over them and
+//      loads it straight from the FAST kernel's cell slots (no staging copy);
+//   2. path key to depth 6 from two LDS tables: the x digits of the reference's split sequence depend on x only, the y digits on
+//      y only until the first child 3 (divideNode's line-27 slip gives node 4 the parent's TOP edge as its bottom: from there on
+//      every y test fails), so key = xs[x] | ys[y], then every y bit below the first digit 3 is set (checked against qt_path_key for
+//      every pixel of several level sizes).  Keys feed a histogram pyramid H_d (4^6 bins at the bottom, u16, packed LDS atomics),
+//      parents from children; per-depth node / leaf tallies give the number of passes P and the list length K the reference's
+//      loop ends with (qt_flat_passes);
+//   3. the final list is [depth-P nodes, ascending in prefix ^ mask_P] ++ [leaves of depth P-1, ascending in prefix ^ mask_{P-1}] ++ ...
+//      (quadtree_flat.h, observation 3), so a node's list position is its rank in that order: ONE block scan over the flags of the
+//      concatenated (permuted) bin spaces; the pyramid is overwritten IN PLACE with the positions (bit 15: more than 16 members);
+//   4. every candidate looks its node's position up (first depth where it is alone, then the position) and joins two LDS atomic
+//      maxima per node: (response, smallest original index) and (response, largest original index);
+//   5. a node whose two maxima name the same candidate, or with <= 16 members (insertion sort: first maximum), is done.  Only a
+//      tied maximum in a node of more than 16 members needs libstdc++'s introsort replayed (qt_sort_front): its members are
+//      collected (LDS append, then ranked by original index) into the dead pyramid and one thread per such node runs the replay.
+// A tree deeper than the pyramid - sparse scenes, where nearly every candidate ends up alone: the usual case on real images - with at
+// most 1024 candidates takes the all-pairs form instead of steps 2-3: 30-bit keys (15 levels), a candidate's "alone" depth and its
+// group's first depth from pairwise common prefixes, the same tallies -> P, K, then its node's list position = number of distinct
+// smaller ranks R (quadtree_flat.h), again by comparing all pairs; steps 4-5 are shared.
+// Units the kernel does not take - more than 256*ITEMS candidates, more than 1024 cells, a deep tree with more than 1024 candidates,
+// quota <= 1, tie buffers too small - raise needPass and k_quadtree (the pass algorithm) processes exactly those afterwards.
 // ------------------------------------------------------------------------------------------------
-#ifdef QT_FLAT_TIMING
-__device__ long long g_qtClk[kMaxLevels][16];
-#define QT_CLK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_qtClk[level][i] = wall_clock64(); } while (0)
-#else
-#define QT_CLK(i) do { } while (0)
-#endif
-constexpr int kQtFlatThreads = 512;
-constexpr int kQtFlatUnion = 43696;   // kQtFlatBins u16 rounded up to 16 B; >= sort storage (<= 32 KB) + 2 KB, >= 4*CAP for CAP <= 8192
-constexpr int kQtSmall = 1024;        // all-pairs variant up to this many candidates
-inline size_t qt_flat_lds_bytes(int items, int quota) {
-  const size_t cap = (size_t)kQtFlatThreads * items;
-  return 4 * cap + kQtFlatUnion + cap + 2 * ((size_t)quota + 2) + 8 * ((size_t)quota + 2) + 16;
+constexpr int kQfThreads = 256;
+constexpr int kQfMaxCells = 1024;
+constexpr int kQfTieCap = kQfPyrU16 * 2 / 8;           // (key, value) pairs the dead pyramid holds: 1366
+constexpr int kQfMaxTied = 32;
+constexpr int kQfSmall = 1024;                         // all-pairs form (trees deeper than the pyramid) up to this many candidates
+constexpr int kQfRegionA = kQfSmall * (4 + 8 + 1) > kQfPyrU16 * 2 ? kQfSmall * (4 + 8 + 1) : kQfPyrU16 * 2;   // pyramid | all-pairs arrays | tie buffers
+// tabLen = (w - 32 + 1) + (h - 32 + 1) of the launch's largest level
+inline size_t qt_fast_lds_bytes(int quotaMax, int tabLen) {
+  return (size_t)kQfRegionA + (size_t)(kQfMaxCells + 8) * 2 + (size_t)((tabLen + 7) & ~7) * 2 + (size_t)(quotaMax + 2) * 8 + (size_t)((quotaMax + 2 + 15) & ~15) + 64;
 }
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
@@ -829,339 +843,437 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 }
 
 template <int ITEMS>
-__device__ __forceinline__ void qt_flat_unit(const PlanDev& P, const uint32_t* __restrict__ cellCount,
-                                             const uint32_t* __restrict__ cellCand, int level, int frame,
-                                             uint32_t* __restrict__ lvlKp, int* __restrict__ lvlCount,
-                                             uint8_t* __restrict__ needPass, int* __restrict__ lvlMaxN) {
-  constexpr int NT = kQtFlatThreads, CAP = NT * ITEMS;
-  using Sort = rocprim::block_radix_sort<uint32_t, NT, ITEMS, uint32_t>;
-  static_assert(sizeof(typename Sort::storage_type) + 4 * NT <= kQtFlatUnion && 4 * CAP <= kQtFlatUnion, "union region too small");
+__global__ __launch_bounds__(kQfThreads) void k_qt_fast(PlanDev P, const uint32_t* __restrict__ cellCount, const uint32_t* __restrict__ cellCand,
+                                                        int levelFirst, int quotaMax, int tabLen, uint32_t* __restrict__ lvlKp,
+                                                        int* __restrict__ lvlCount, uint8_t* __restrict__ needPass, int* __restrict__ lvlMaxN) {
+  constexpr int NT = kQfThreads, CAP = NT * ITEMS, D = kQfDepth;
   extern __shared__ __align__(16) uint8_t smem[];
-  __shared__ unsigned w32[16];
-  __shared__ unsigned long long w64[16];
+  __shared__ unsigned w32[4];
   __shared__ unsigned long long sRed[4];
-  __shared__ int sDiff[kQtPairDepth + 3], sLeaf[kQtPairDepth + 2];
-  const int f = frame, tid = threadIdx.x;
+  __shared__ int sTieN, sFlag, sTieCnt[kQfMaxTied], sTieNode[kQfMaxTied];
+  const int f = blockIdx.x, level = levelFirst + blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const LevelDev L = P.lv[level];
-  QT_LDS uint32_t* cand = (QT_LDS uint32_t*)smem;
-  uint8_t* un = smem + 4 * CAP;
-  QT_LDS uint16_t* hist = (QT_LDS uint16_t*)un;
-  QT_LDS uint32_t* hist32 = (QT_LDS uint32_t*)un;
-  QT_LDS uint32_t* cellBase = (QT_LDS uint32_t*)un;
-  QT_LDS uint32_t* keysAll = (QT_LDS uint32_t*)un;
-  QT_LDS uint32_t* lastKey = (QT_LDS uint32_t*)(un + kQtFlatUnion - 4 * NT);
-  QT_LDS uint32_t* key30 = (QT_LDS uint32_t*)un;                                   // all-pairs arrays: keys, then ranks
-  QT_LDS unsigned long long* R64 = (QT_LDS unsigned long long*)(un + 4 * kQtSmall);
-  QT_LDS uint8_t* head = (QT_LDS uint8_t*)(un + kQtFlatUnion);
-  QT_LDS uint16_t* nodeStart = (QT_LDS uint16_t*)(un + kQtFlatUnion + CAP);
-  QtBlockCtx cx{w32, w64};
-  const int unit = f * kMaxLevels + level;
-  const int quota = L.quota;
-  QT_LDS uint32_t* nodeMaxLo = (QT_LDS uint32_t*)(un + kQtFlatUnion + CAP + ((2 * (quota + 2) + 3) & ~3));   // [quota+1] each
-  QT_LDS uint32_t* nodeMaxHi = nodeMaxLo + quota + 1;
+  const int unit = f * kMaxLevels + level, quota = L.quota;
+  QT_LDS uint16_t* hist = (QT_LDS uint16_t*)smem;
+  QT_LDS uint32_t* hist32 = (QT_LDS uint32_t*)smem;
+  QT_LDS uint16_t* cellBase = (QT_LDS uint16_t*)(smem + kQfRegionA);                          // [kQfMaxCells + 1]
+  QT_LDS uint16_t* xs = cellBase + kQfMaxCells + 8;                                           // [w - 32 + 1], then ys [h - 32 + 1]
+  QT_LDS uint32_t* nodeLo = (QT_LDS uint32_t*)(xs + ((tabLen + 7) & ~7));                     // [quotaMax + 2] each
+  QT_LDS uint32_t* nodeHi = nodeLo + quotaMax + 2;
+  QT_LDS uint8_t* nodeBig = (QT_LDS uint8_t*)(nodeHi + quotaMax + 2);
 
-  QT_CLK(0);
-  // concatenate the level's cells in (row, col) order == keyPointsToDistr (orbExtractor.cpp:584-590)
+  auto block_scan_excl = [&](unsigned v, unsigned* total) -> unsigned {   // exclusive prefix over the 256 threads (two barriers)
+    unsigned x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) w32[wv] = x;
+    __syncthreads();
+    const unsigned s0 = w32[0], s1 = w32[1], s2 = w32[2], s3 = w32[3];
+    __syncthreads();
+    *total = s0 + s1 + s2 + s3;
+    return x - v + (wv > 0 ? s0 : 0u) + (wv > 1 ? s1 : 0u) + (wv > 2 ? s2 : 0u);
+  };
+  auto give_up = [&]() { if (tid == 0) needPass[unit] = 1; };
+
+  // ---- 1. cell bases: the level's cells in (row, col) order == keyPointsToDistr (orbExtractor.cpp:584-590) ----------------------
+  const int rootX1 = L.w - 2 * kBorder, rootY1 = L.h - 2 * kBorder;
+  if (L.nCells > kQfMaxCells || rootX1 < 0 || rootY1 < 0 || rootX1 + rootY1 + 2 > tabLen) { give_up(); return; }
   const uint32_t* cnts = cellCount + (size_t)f * P.nCellsTotal + L.cellBegin;
-  unsigned nU = 0;
-  for (int c0 = 0; c0 < L.nCells; c0 += NT) {
-    const int c = c0 + tid;
-    const unsigned v = c < L.nCells ? cnts[c] : 0u;
-    unsigned tot;
-    const unsigned incl = cx.scan_incl_u32(v, &tot);
-    if (c < L.nCells) cellBase[c] = nU + incl - v;
-    nU += tot;
-  }
-  if (tid < kQtPairDepth + 3) sDiff[tid] = 0;
-  if (tid < kQtPairDepth + 2) sLeaf[tid] = 0;
+  unsigned cc4[4], mine = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { cc4[k] = 4 * tid + k < L.nCells ? cnts[4 * tid + k] : 0u; mine += cc4[k]; }
   if (tid < 4) sRed[tid] = 0;
-  cx.sync();
+  if (tid == 0) { sTieN = 0; sFlag = 0; }
+  if (tid < kQfMaxTied) sTieCnt[tid] = 0;
+  unsigned nU;
+  unsigned run = block_scan_excl(mine, &nU);
   const int n = (int)nU;
   if (tid == 0 && n > lvlMaxN[level]) atomicMax(&lvlMaxN[level], n);   // the host sizes the next launch from this
-  if (n > CAP) {                       // too many candidates for this launch's LDS: the pass kernel takes the unit
-    if (tid == 0) needPass[unit] = 1;
-    return;
-  }
+  if (n > CAP) { give_up(); return; }
   if (n == 0 || quota <= 0) {
     if (tid == 0) { needPass[unit] = 0; lvlCount[unit] = 0; }
     return;
   }
-  for (int c = tid; c < L.nCells; c += NT) {
-    const unsigned m = cnts[c], b = cellBase[c];
-    const uint32_t* src = cellCand + ((size_t)f * P.nCellsTotal + L.cellBegin + c) * P.cellCap;
-    unsigned i = 0;
-    for (; i + 4 <= m; i += 4) {       // independent loads in flight
-      const uint32_t v0 = src[i], v1 = src[i + 1], v2 = src[i + 2], v3 = src[i + 3];
-      cand[b + i] = v0; cand[b + i + 1] = v1; cand[b + i + 2] = v2; cand[b + i + 3] = v3;
-    }
-    for (; i < m; i++) cand[b + i] = src[i];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { cellBase[4 * tid + k] = (uint16_t)run; run += cc4[k]; }   // cells beyond nCells: base = n
+  if (tid == 0) cellBase[kQfMaxCells] = (uint16_t)n;
+  for (int i = tid; i < kQfPyrU16 / 2; i += NT) hist32[i] = 0;
+  for (int k = tid; k < quotaMax + 2; k += NT) { nodeLo[k] = 0; nodeHi[k] = 0; nodeBig[k] = 0; }
+  // split digits of the reference's geometry (qt_center = ceil of the midpoint), most significant first, already spread to the key's
+  // even (x) and odd (y) bit positions and complemented: bit set = "not left" / "not top"
+  QT_LDS uint16_t* ys = xs + rootX1 + 1;
+  for (int v = tid; v <= rootX1 + rootY1 + 1; v += NT) {
+    const bool isY = v > rootX1;
+    const uint32_t bits = qf_axis_digits(isY ? v - rootX1 - 1 : v, isY ? rootY1 : rootX1);
+    xs[v] = (uint16_t)(isY ? bits << 1 : bits);
   }
-  cx.sync();
-  QT_CLK(1);
-  const int rootX1 = L.w - 2 * kBorder, rootY1 = L.h - 2 * kBorder;
-  int Pn = 0, K = 0;
-  bool pairs = false;
+  __syncthreads();
+  const uint32_t* slots = cellCand + ((size_t)f * P.nCellsTotal + L.cellBegin) * P.cellCap;
+  uint32_t* outKp = lvlKp + (size_t)f * P.sumQuota + L.kpOff;
+  auto fetch = [&](int i) -> uint32_t {     // candidate i of the level's concatenated list
+    int c = 0;
+#pragma unroll
+    for (int st = kQfMaxCells / 2; st >= 1; st >>= 1)
+      if ((int)cellBase[c + st] <= i) c += st;
+    return slots[(size_t)c * P.cellCap + (i - (int)cellBase[c])];
+  };
+  if (n == 1) {          // a single candidate: the root is the only node (list [root], P = 1, K = 1)
+    if (tid == 0) { outKp[0] = fetch(0); needPass[unit] = 0; lvlCount[unit] = 1; }
+    return;
+  }
+  if (quota <= 1) { give_up(); return; }   // P = 0: the whole level is one node (never with the reference's quotas)
 
-  {
-    // ---- histogram pyramid over 7 levels of path digits ------------------------------------------------------------------
-    constexpr int D = kQtFlatDepth;
-    uint32_t c[ITEMS], ky[ITEMS];
+  // ---- 2. candidates -> one register each (key | response << 16), histogram pyramid ------------------------------------------------
+  // Groups of four candidates, straight-line inside a group (an index beyond n is clamped and contributes nothing), so that the four
+  // binary searches / loads / table look-ups of a group are in flight together; a group beyond n is skipped (wave-uniform).
+  static_assert(ITEMS % 4 == 0, "groups of four");
+  uint32_t st[ITEMS];
 #pragma unroll
-    for (int j = 0; j < ITEMS; j++) {
-      const int i = tid * ITEMS + j;
-      c[j] = i < n ? cand[i] : 0u;
-      ky[j] = qt_path_key<kQtFlatDepth>(c[j], rootX1, rootY1);
-    }
-    for (int i = tid; i < (kQtFlatBins + 1) / 2; i += NT) hist32[i] = 0;   // cellBase (same bytes) was last read before the barrier above
-    cx.sync();
-    {
-      const int off = qt_flat_level_off(D);
+  for (int g = 0; g < ITEMS / 4; g++) {
 #pragma unroll
-      for (int j = 0; j < ITEMS; j++)
-        if (tid * ITEMS + j < n) {
-          const int idx = off + (int)ky[j];
-          __hip_atomic_fetch_add(hist32 + (idx >> 1), 1u << (16 * (idx & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    }
-    cx.sync();
-    QT_CLK(2);
-    // parents from children, level by level; a parent with >= 2 candidates makes its occupied children list nodes of the
-    // next pass and its single-candidate children leaves.  Packed 16-bit tallies: [nodes d=1..4][nodes 5..7][leaves 1..4][leaves 5..7]
-    unsigned long long tn0 = 0, tn1 = 0, tl0 = 0, tl1 = 0;
+    for (int jj = 0; jj < 4; jj++) st[4 * g + jj] = 0;
+    if (4 * g * NT < n) {
+      int ii[4], cc[4];
 #pragma unroll
-    for (int d = D - 1; d >= 0; d--) {
-      const int offC = qt_flat_level_off(d + 1), offP = qt_flat_level_off(d);
-      for (int b = tid; b < (1 << (2 * d)); b += NT) {
-        const unsigned c0 = hist[offC + 4 * b], c1 = hist[offC + 4 * b + 1], c2 = hist[offC + 4 * b + 2], c3 = hist[offC + 4 * b + 3];
-        const unsigned sum = c0 + c1 + c2 + c3;
-        hist[offP + b] = (uint16_t)sum;
-        if (sum >= 2) {
-          const unsigned long long nn = (c0 != 0) + (c1 != 0) + (c2 != 0) + (c3 != 0), ll = (c0 == 1) + (c1 == 1) + (c2 == 1) + (c3 == 1);
-          const int dd = d + 1;   // depth of the children
-          if (dd <= 4) { tn0 += nn << (16 * (dd - 1)); tl0 += ll << (16 * (dd - 1)); }
-          else { tn1 += nn << (16 * (dd - 5)); tl1 += ll << (16 * (dd - 5)); }
-        }
-      }
-      cx.sync();
-    }
-    QT_CLK(3);
-    tn0 = wave_sum_u64(tn0); tn1 = wave_sum_u64(tn1); tl0 = wave_sum_u64(tl0); tl1 = wave_sum_u64(tl1);
-    if ((tid & 63) == 0) {
-      __hip_atomic_fetch_add(&sRed[0], tn0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(&sRed[1], tn1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(&sRed[2], tl0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(&sRed[3], tl1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    cx.sync();
-    {
-      int nodes[D + 1], leaves[D + 1];
-      nodes[0] = 1; leaves[0] = n == 1;
-      const unsigned long long a0 = sRed[0], a1 = sRed[1], b0 = sRed[2], b1 = sRed[3];
+      for (int jj = 0; jj < 4; jj++) { ii[jj] = min((4 * g + jj) * NT + tid, n - 1); cc[jj] = 0; }
 #pragma unroll
-      for (int d = 1; d <= D; d++) {
-        nodes[d] = (int)(((d <= 4 ? a0 : a1) >> (16 * ((d - 1) & 3))) & 0xFFFF);
-        leaves[d] = (int)(((d <= 4 ? b0 : b1) >> (16 * ((d - 1) & 3))) & 0xFFFF);
-      }
-      Pn = qt_flat_passes(nodes, leaves, quota, &K, D);
-    }
-    QT_CLK(4);
-    if (Pn < 0) {
-      if (n > kQtSmall) {                // deep tree with many candidates: pass kernel
-        if (tid == 0) needPass[unit] = 1;
-        return;
-      }
-      pairs = true;                      // deep tree, few candidates (sparse scene): all-pairs form below, any depth up to 15
-    } else {
-      const int endBit = 2 * Pn + 4;
-      // depth at which each candidate's node stops splitting: the first depth where it is alone (count 1 stays 1 below), else P
-      int dd[ITEMS];
+      for (int sp = kQfMaxCells / 2; sp >= 1; sp >>= 1)
 #pragma unroll
-      for (int j = 0; j < ITEMS; j++) dd[j] = Pn;
-      for (int d = Pn - 1; d >= 0; d--) {
-        const int off = qt_flat_level_off(d), sh = 2 * (D - d);
+        for (int jj = 0; jj < 4; jj++)
+          cc[jj] += (int)cellBase[cc[jj] + sp] <= ii[jj] ? sp : 0;
+      uint32_t c[4];
 #pragma unroll
-        for (int j = 0; j < ITEMS; j++)
-          if (hist[off + (int)(ky[j] >> sh)] == 1) dd[j] = d;
-      }
-      uint32_t R[ITEMS];
+      for (int jj = 0; jj < 4; jj++) c[jj] = slots[(size_t)cc[jj] * P.cellCap + (ii[jj] - (int)cellBase[cc[jj]])];
 #pragma unroll
-      for (int j = 0; j < ITEMS; j++) {
-        const int d = dd[j];
-        R[j] = ((uint32_t)(Pn - d) << (2 * Pn)) | ((ky[j] >> (2 * (D - d))) ^ qt_flat_mask(d));
-        if (tid * ITEMS + j >= n) R[j] = (1u << endBit) - 1u;   // padding sorts behind every real entry (group 15)
-      }
-      cx.sync();   // the pyramid is dead: its bytes become the sort's exchange buffer
-      QT_CLK(5);
-      Sort().sort(R, c, *reinterpret_cast<typename Sort::storage_type*>(un), 0, endBit);
-      QT_CLK(6);
-      lastKey[tid] = R[ITEMS - 1];
-      cx.sync();
-      uint32_t prev = tid ? lastKey[tid - 1] : 0xFFFFFFFFu;
-#pragma unroll
-      for (int j = 0; j < ITEMS; j++) {
-        const int i = tid * ITEMS + j;
-        if (i < n) { cand[i] = c[j]; head[i] = R[j] != prev; }
-        prev = R[j];
+      for (int jj = 0; jj < 4; jj++) {
+        const uint32_t key = qf_key(xs[qt_x(c[jj])], ys[qt_y(c[jj])]);
+        st[4 * g + jj] = key | ((uint32_t)qt_r(c[jj]) << 16);
+        const int idx = qf_off(D) + (int)key;
+        const bool real = (4 * g + jj) * NT + tid < n;
+        __hip_atomic_fetch_add(hist32 + (idx >> 1), real ? 1u << (16 * (idx & 1)) : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   }
+  __syncthreads();
+  // parents from children; a parent with >= 2 candidates makes its occupied children list nodes of the next pass and its
+  // single-candidate children leaves.  Packed 16-bit tallies: [nodes d=1..4][nodes 5..6][leaves 1..4][leaves 5..6]
+  unsigned long long tn0 = 0, tn1 = 0, tl0 = 0, tl1 = 0;
+  auto reduce_level = [&](int d, int b) {   // parent b of depth d from its four children of depth d + 1
+    const uint2 q = *reinterpret_cast<const QT_LDS uint2*>(hist + qf_off(d + 1) + 4 * b);
+    const unsigned c0 = q.x & 0xFFFFu, c1 = q.x >> 16, c2 = q.y & 0xFFFFu, c3 = q.y >> 16;
+    const unsigned sum = c0 + c1 + c2 + c3;
+    hist[qf_off(d) + b] = (uint16_t)sum;
+    if (sum >= 2) {
+      const unsigned long long nn = (c0 != 0) + (c1 != 0) + (c2 != 0) + (c3 != 0), ll = (c0 == 1) + (c1 == 1) + (c2 == 1) + (c3 == 1);
+      const int dd = d + 1;   // depth of the children
+      if (dd <= 4) { tn0 += nn << (16 * (dd - 1)); tl0 += ll << (16 * (dd - 1)); }
+      else { tn1 += nn << (16 * (dd - 5)); tl1 += ll << (16 * (dd - 5)); }
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < 4; q++) reduce_level(5, tid + NT * q);
+  __syncthreads();
+  reduce_level(4, tid);
+  __syncthreads();
+  if (wv == 0) {                            // depths 3 .. 0 on one wave (LDS accesses of a wave are in program order)
+    reduce_level(3, lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    if (lane < 16) reduce_level(2, lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    if (lane < 4) reduce_level(1, lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    if (lane == 0) reduce_level(0, 0);
+  }
+  tn0 = wave_sum_u64(tn0); tn1 = wave_sum_u64(tn1); tl0 = wave_sum_u64(tl0); tl1 = wave_sum_u64(tl1);
+  if (lane == 0) {
+    __hip_atomic_fetch_add(&sRed[0], tn0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(&sRed[1], tn1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(&sRed[2], tl0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(&sRed[3], tl1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();
+  int Pn, K = 0;
+  {
+    int nodes[D + 1], leaves[D + 1];
+    nodes[0] = 1; leaves[0] = 0;
+    const unsigned long long a0 = sRed[0], a1 = sRed[1], b0 = sRed[2], b1 = sRed[3];
+#pragma unroll
+    for (int d = 1; d <= D; d++) {
+      nodes[d] = (int)(((d <= 4 ? a0 : a1) >> (16 * ((d - 1) & 3))) & 0xFFFF);
+      leaves[d] = (int)(((d <= 4 ? b0 : b1) >> (16 * ((d - 1) & 3))) & 0xFFFF);
+    }
+    Pn = qt_flat_passes(nodes, leaves, quota, &K, D);
+  }
+  const bool pairs = Pn < 1;               // the reference's loop would still be splitting below depth 6
+  if (pairs && n > kQfSmall) { give_up(); return; }
+  int nOut = K < quota ? K : quota;
   if (pairs) {
-    // ---- few candidates, deep tree: pairwise common prefixes of 30-bit keys ------------------------------------------------
-    constexpr int D = kQtPairDepth, PER = kQtSmall / NT;
-    static_assert(PER == 2, "two candidates per thread");
-    const int i0 = tid, i1 = tid + NT, n4 = (n + 3) & ~3;
-    const uint32_t c0 = i0 < n ? cand[i0] : 0u, c1 = i1 < n ? cand[i1] : 0u;
-    const uint32_t k0 = qt_path_key<kQtPairDepth>(c0, rootX1, rootY1), k1 = qt_path_key<kQtPairDepth>(c1, rootX1, rootY1);
-    cx.sync();   // pyramid reads are done
-    if (i0 < n4) key30[i0] = i0 < n ? k0 : 0xFFFFFFFFu;   // padding: clz(x) = 0 -> depth 0, neutral
-    if (i1 < n4) key30[i1] = i1 < n ? k1 : 0xFFFFFFFFu;
-    cx.sync();
-    int s0 = 0, e0 = 0, s1 = 0, e1 = 0;
+    // ---- 2b / 3b. few candidates, deep tree: pairwise common prefixes of 30-bit keys --------------------------------------------
+    constexpr int DP = kQtPairDepth, PER = kQfSmall / NT;
+    QT_LDS uint32_t* key30 = (QT_LDS uint32_t*)smem;                                  // [kQfSmall]
+    QT_LDS unsigned long long* R64 = (QT_LDS unsigned long long*)(smem + 4 * kQfSmall);   // [kQfSmall]
+    QT_LDS uint8_t* firstOf = (QT_LDS uint8_t*)(smem + 12 * kQfSmall);                // [kQfSmall]: 1 = no earlier candidate in the same node
+    __shared__ int sDiff[kQtPairDepth + 3], sLeaf[kQtPairDepth + 2];
+    const int n4 = (n + 3) & ~3;
+    uint32_t kk[PER];
+    __syncthreads();                        // every read of the pyramid is done
+    if (tid < DP + 3) sDiff[tid] = 0;
+    if (tid < DP + 2) sLeaf[tid] = 0;
+#pragma unroll
+    for (int t = 0; t < PER; t++) {
+      const int i = t * NT + tid;
+      kk[t] = i < n ? qt_path_key<kQtPairDepth>(fetch(i), rootX1, rootY1) : 0xFFFFFFFFu;   // padding: clz(x) = 0 -> depth 0, neutral
+      if (i < n4) key30[i] = kk[t];
+    }
+    __syncthreads();
+    int sA[PER], eA[PER];
+#pragma unroll
+    for (int t = 0; t < PER; t++) { sA[t] = 0; eA[t] = 0; }
     for (int q = 0; q < n4; q += 4) {
       const uint4 kq = *reinterpret_cast<const QT_LDS uint4*>(key30 + q);
-      const uint32_t kk[4] = {kq.x, kq.y, kq.z, kq.w};
+      const uint32_t ko[4] = {kq.x, kq.y, kq.z, kq.w};
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const uint32_t x0 = k0 ^ kk[t], x1 = k1 ^ kk[t];
-        const int d0 = q + t == i0 ? 0 : (x0 ? ((__clz(x0) - 2) >> 1) + 1 : D + 1);
-        const int d1 = q + t == i1 ? 0 : (x1 ? ((__clz(x1) - 2) >> 1) + 1 : D + 1);
-        s0 = max(s0, d0); s1 = max(s1, d1);
-        if (q + t < i0) e0 = max(e0, d0);
-        if (q + t < i1) e1 = max(e1, d1);
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int t = 0; t < PER; t++) {
+          const int i = t * NT + tid;
+          const uint32_t x = kk[t] ^ ko[u];
+          const int dpt = q + u == i ? 0 : (x ? ((__clz((int)x) - 2) >> 1) + 1 : DP + 1);
+          sA[t] = max(sA[t], dpt);
+          if (q + u < i) eA[t] = max(eA[t], dpt);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < PER; t++)
+      if (t * NT + tid < n) {
+        if (eA[t] <= DP) { atomicAdd(&sDiff[eA[t]], 1); atomicAdd(&sDiff[min(sA[t], DP) + 1], -1); }
+        if (sA[t] <= DP) atomicAdd(&sLeaf[sA[t]], 1);
       }
-    }
-    if (i0 < n) {
-      if (e0 <= D) { atomicAdd(&sDiff[e0], 1); atomicAdd(&sDiff[min(s0, D) + 1], -1); }
-      if (s0 <= D) atomicAdd(&sLeaf[s0], 1);
-    }
-    if (i1 < n) {
-      if (e1 <= D) { atomicAdd(&sDiff[e1], 1); atomicAdd(&sDiff[min(s1, D) + 1], -1); }
-      if (s1 <= D) atomicAdd(&sLeaf[s1], 1);
-    }
-    cx.sync();
+    __syncthreads();
     {
-      int nodes[D + 1], leaves[D + 1], run = 0;
+      int nodes[DP + 1], leaves[DP + 1], run2 = 0;
 #pragma unroll
-      for (int d = 0; d <= D; d++) { run += sDiff[d]; nodes[d] = run; leaves[d] = sLeaf[d]; }
-      Pn = qt_flat_passes(nodes, leaves, quota, &K, D);
+      for (int d = 0; d <= DP; d++) { run2 += sDiff[d]; nodes[d] = run2; leaves[d] = sLeaf[d]; }
+      Pn = qt_flat_passes(nodes, leaves, quota, &K, DP);
     }
-    if (Pn < 0) {                        // cannot happen for 12-bit coordinates; the pass kernel would cope
-      if (tid == 0) needPass[unit] = 1;
-      return;
+    if (Pn < 1) { give_up(); return; }      // cannot happen for 12-bit coordinates; the pass kernel would cope
+    nOut = K < quota ? K : quota;
+    unsigned long long RR[PER];
+#pragma unroll
+    for (int t = 0; t < PER; t++) {
+      const int i = t * NT + tid, dA = min(Pn, sA[t]);
+      RR[t] = ((unsigned long long)(Pn - dA) << (2 * Pn)) | (unsigned long long)((kk[t] >> (2 * (DP - dA))) ^ qt_flat_mask(dA));
+      if (i < n4) R64[i] = i < n ? RR[t] : ~0ull;
     }
-    const int dA = min(Pn, s0), dB = min(Pn, s1);
-    const unsigned long long R0 = ((unsigned long long)(Pn - dA) << (2 * Pn)) | (unsigned long long)((k0 >> (2 * (D - dA))) ^ qt_flat_mask(dA));
-    const unsigned long long R1 = ((unsigned long long)(Pn - dB) << (2 * Pn)) | (unsigned long long)((k1 >> (2 * (D - dB))) ^ qt_flat_mask(dB));
-    if (i0 < n4) R64[i0] = i0 < n ? R0 : ~0ull;
-    if (i1 < n4) R64[i1] = i1 < n ? R1 : ~0ull;
-    cx.sync();
-    int r0 = 0, r1 = 0;
-    bool f0 = true, f1 = true;
+    __syncthreads();
+    // sweep A: is the candidate the first of its node (no earlier candidate with the same rank)?
+    bool fst[PER];
+#pragma unroll
+    for (int t = 0; t < PER; t++) fst[t] = true;
     for (int q = 0; q < n4; q += 2) {
       const ulonglong2 o = *reinterpret_cast<const QT_LDS ulonglong2*>(R64 + q);
       const unsigned long long oo[2] = {o.x, o.y};
 #pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const bool eq0 = oo[t] == R0 && q + t < i0, eq1 = oo[t] == R1 && q + t < i1;
-        r0 += (oo[t] < R0) || eq0; r1 += (oo[t] < R1) || eq1;
-        f0 = f0 && !eq0; f1 = f1 && !eq1;
-      }
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int t = 0; t < PER; t++) fst[t] = fst[t] && !(oo[u] == RR[t] && q + u < t * NT + tid);
     }
-    cx.sync();   // every key/cand read is done: the sorted order can overwrite cand[]
-    if (i0 < n) { cand[r0] = c0; head[r0] = f0; }
-    if (i1 < n) { cand[r1] = c1; head[r1] = f1; }
+#pragma unroll
+    for (int t = 0; t < PER; t++) { const int i = t * NT + tid; if (i < n4) firstOf[i] = i < n && fst[t]; }
+    __syncthreads();
+    // sweep B: list position of the node = number of distinct smaller ranks; members of the node
+    int kp[PER], mm[PER];
+#pragma unroll
+    for (int t = 0; t < PER; t++) { kp[t] = 0; mm[t] = 0; }
+    for (int q = 0; q < n4; q += 2) {
+      const ulonglong2 o = *reinterpret_cast<const QT_LDS ulonglong2*>(R64 + q);
+      const unsigned long long oo[2] = {o.x, o.y};
+      const unsigned f2 = *reinterpret_cast<const QT_LDS uint16_t*>(firstOf + q);
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int t = 0; t < PER; t++) {
+          kp[t] += (oo[u] < RR[t]) & ((f2 >> (8 * u)) & 1u);
+          mm[t] += oo[u] == RR[t];
+        }
+    }
+    // hand-over to the shared tail: the low half of the state = the node's list position (0xFFFF = beyond the quota)
+#pragma unroll
+    for (int t = 0; t < PER; t++) {
+      const int i = t * NT + tid;
+      if (i < n && kp[t] < nOut && mm[t] > 16) nodeBig[kp[t]] = 1;
+    }
+    static_assert(PER <= ITEMS, "the all-pairs candidates live in the first PER state registers");
+#pragma unroll
+    for (int t = 0; t < PER; t++) st[t] = (st[t] & 0xFFFF0000u) | (uint32_t)(kp[t] < nOut ? kp[t] : 0x7FFF);
+    __syncthreads();                        // the key / rank arrays are dead: the region becomes the position table of step 4 (identity)
   }
-  cx.sync();
-  QT_CLK(7);
 
-  // ---- common tail: node boundaries, then best keypoint per node in list order, truncated to the quota (:534-543) ---------
-  const int nOut = K < quota ? K : quota;
-  const int per = (n + NT - 1) / NT;
-  int firstNode;
-  {
-    int mine = 0;
-    for (int j = 0; j < per; j++) {
-      const int p = tid * per + j;
-      if (p < n) mine += head[p];
-    }
-    unsigned total;
-    const unsigned incl = cx.scan_incl_u32((unsigned)mine, &total);
-    firstNode = (int)incl - mine;   // nodes started before this thread's range
-    int k = firstNode;
-    for (int j = 0; j < per; j++) {
-      const int p = tid * per + j;
-      if (p < n && head[p]) {
-        if (k <= nOut) nodeStart[k] = (uint16_t)p;
-        k++;
+  // ---- 3. depth at which each candidate's node stops splitting: the first depth where it is alone, else P -------------------------
+#pragma unroll
+  for (int g = 0; g < ITEMS / 4; g++) {
+    if (!pairs && 4 * g * NT < n) {
+      int key[4], slot[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) { key[jj] = (int)(st[4 * g + jj] & 0xFFFu); slot[jj] = qf_off(Pn) + (key[jj] >> (2 * (D - Pn))); }
+      for (int d = Pn - 1; d >= 1; d--) {
+        const int off = qf_off(d), sh = 2 * (D - d);
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+          const int sl = off + (key[jj] >> sh);
+          if (hist[sl] == 1) slot[jj] = sl;
+        }
       }
-    }
-    if (tid == 0 && K <= nOut) nodeStart[K] = (uint16_t)n;
-    for (int k2 = tid; k2 < nOut; k2 += NT) { nodeMaxLo[k2] = 0; nodeMaxHi[k2] = 0; }
-    if ((int)total != K) {           // cannot happen: the pyramid/pair count and the sorted runs describe the same list
-      if (tid == 0) needPass[unit] = 1;
-      return;
+      // from here on the low half is the pyramid slot of the candidate's final node
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) st[4 * g + jj] = (st[4 * g + jj] & 0xFFFF0000u) | (uint32_t)slot[jj];
     }
   }
-  cx.sync();   // also retires the union's previous tenant (sort hand-off / R64) before keysAll is written
-  {
-    // Per node: the maximum response with the smallest and with the largest member index.  When both name the same member the
-    // maximum is unique and std::sort's front() is that member whatever the sort did internally; only tied nodes with more
-    // than 16 members need the introsort replay (<= 16 members: insertion sort, first maximum).
-    int k = firstNode - 1;           // node of the position just before this thread's range
-    for (int j = 0; j < per; j++) {
-      const int p = tid * per + j;
-      if (p < n) {
-        k += head[p];
-        if (k < nOut) {
-          const uint32_t mi = (uint32_t)(p - nodeStart[k]), rs = (uint32_t)qt_r(cand[p]) << 16;
-          keysAll[p] = rs | mi;
-          __hip_atomic_fetch_max(nodeMaxLo + k, rs | (0xFFFFu - mi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_max(nodeMaxHi + k, rs | mi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // list positions: quads (four siblings) of the groups d = P, P-1, .., 1 in list order, a contiguous run of quads per thread
+  if (!pairs) {
+    const int TQ = ((1 << (2 * Pn)) - 1) / 3;            // 4^(P-1) + .. + 1
+    const int per = (TQ + NT - 1) / NT;                  // <= 6
+    constexpr int MAXQ = ((1 << (2 * D)) - 1) / 3 / NT + 1;
+    uint2 qv[MAXQ];
+    int qslot[MAXQ];                                     // pyramid index of the quad's first child; -1: none
+    unsigned flags = 0, cntF = 0;                        // 4 flag bits per quad, in LIST order (child 3 first)
+#pragma unroll
+    for (int t = 0; t < MAXQ; t++) {
+      qslot[t] = -1; qv[t] = make_uint2(0, 0);
+      const int q = tid * per + t;
+      if (t < per && q < TQ) {
+        int d = Pn, start = 0;                           // group of quad q: depth d holds 4^(d-1) quads
+        while (q >= start + (1 << (2 * (d - 1)))) { start += 1 << (2 * (d - 1)); d--; }
+        const int pq = q - start;                        // permuted parent index inside the group
+        const int bq = pq ^ (int)(qt_flat_mask(d) >> 2); // natural parent index (depth d - 1)
+        qslot[t] = qf_off(d) + 4 * bq;
+        qv[t] = *reinterpret_cast<const QT_LDS uint2*>(hist + qslot[t]);
+        const unsigned c[4] = {qv[t].x & 0xFFFFu, qv[t].x >> 16, qv[t].y & 0xFFFFu, qv[t].y >> 16};
+        const unsigned sum = c[0] + c[1] + c[2] + c[3];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {                    // list order inside a quad: child 3, 2, 1, 0 (the last digit is always complemented)
+          const unsigned cn = c[3 - e];
+          const bool fl = sum >= 2 && (d == Pn ? cn >= 1 : cn == 1);
+          flags |= (unsigned)fl << (4 * t + e);
+          cntF += fl;
         }
       }
     }
-  }
-  cx.sync();
-  QT_CLK(8);
-  uint32_t* outKp = lvlKp + (size_t)f * P.sumQuota + L.kpOff;
-  for (int k = tid; k < nOut; k += NT) {
-    const int b = nodeStart[k], m = nodeStart[k + 1] - b;
-    const int lo = (int)(0xFFFFu - (nodeMaxLo[k] & 0xFFFFu)), hi = (int)(nodeMaxHi[k] & 0xFFFFu);
-    int best = lo;
-    if (m > 16 && lo != hi) best = qt_sort_front(keysAll + b, m);
-    outKp[k] = cand[b + best];
-  }
-  QT_CLK(9);
-  if (tid == 0) { needPass[unit] = 0; lvlCount[unit] = nOut; }
-}
-
-// one launch per level (single-frame handles: each level on its own stream) ...
-template <int ITEMS>
-__global__ __launch_bounds__(kQtFlatThreads) void k_quadtree_flat(PlanDev P, const uint32_t* __restrict__ cellCount,
-                                                                  const uint32_t* __restrict__ cellCand, int level,
-                                                                  uint32_t* __restrict__ lvlKp, int* __restrict__ lvlCount,
-                                                                  uint8_t* __restrict__ needPass, int* __restrict__ lvlMaxN) {
-  qt_flat_unit<ITEMS>(P, cellCount, cellCand, level, blockIdx.x, lvlKp, lvlCount, needPass, lvlMaxN);
-}
-// ... or ONE launch for a range of levels (YDORB_QT_GROUPED=1): grid (frames, levels), the big levels first.  Each level runs the
-// instantiation its candidate counts ask for, but the launch's LDS is the largest of them, which costs more occupancy than the shorter
-// launch chain gains (measured: 178 against 190 Mkeypoints/s in the two-lane pipeline) - kept as an option, off by default.
-struct QtItems { int items[kMaxLevels]; };
-__global__ __launch_bounds__(kQtFlatThreads) void k_quadtree_flat_levels(PlanDev P, const uint32_t* __restrict__ cellCount,
-                                                                         const uint32_t* __restrict__ cellCand, int levelFirst, QtItems it,
-                                                                         uint32_t* __restrict__ lvlKp, int* __restrict__ lvlCount,
-                                                                         uint8_t* __restrict__ needPass, int* __restrict__ lvlMaxN) {
-  const int level = levelFirst + blockIdx.y, frame = blockIdx.x;
-  int items = 0;
+    unsigned total;
+    unsigned pos = block_scan_excl(cntF, &total);        // (its barriers also end every read of the counts: step 3 above included)
+    if ((int)total != K) { give_up(); return; }          // cannot happen: tallies and flags describe the same list
 #pragma unroll
-  for (int l = 0; l < kMaxLevels; l++) if (l == level) items = it.items[l];
-  switch (items) {
-    case 2: qt_flat_unit<2>(P, cellCount, cellCand, level, frame, lvlKp, lvlCount, needPass, lvlMaxN); break;
-    case 4: qt_flat_unit<4>(P, cellCount, cellCand, level, frame, lvlKp, lvlCount, needPass, lvlMaxN); break;
-    case 8: qt_flat_unit<8>(P, cellCount, cellCand, level, frame, lvlKp, lvlCount, needPass, lvlMaxN); break;
-    case 12: qt_flat_unit<12>(P, cellCount, cellCand, level, frame, lvlKp, lvlCount, needPass, lvlMaxN); break;
-    default: qt_flat_unit<16>(P, cellCount, cellCand, level, frame, lvlKp, lvlCount, needPass, lvlMaxN); break;
+    for (int t = 0; t < MAXQ; t++) {
+      if (qslot[t] >= 0) {
+        const unsigned c[4] = {qv[t].x & 0xFFFFu, qv[t].x >> 16, qv[t].y & 0xFFFFu, qv[t].y >> 16};
+        unsigned o[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const unsigned cn = c[3 - e];
+          unsigned v = 0x7FFFu;
+          if ((flags >> (4 * t + e)) & 1u) {
+            if ((int)pos < nOut) {
+              v = pos | (cn > 16 ? 0x8000u : 0u);
+              if (cn > 16) nodeBig[pos] = 1;
+            }
+            pos++;
+          }
+          o[3 - e] = v;
+        }
+        *reinterpret_cast<QT_LDS uint2*>(hist + qslot[t]) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+      }
+    }
   }
+  __syncthreads();
+
+  // ---- 4. per node: maximum response with the smallest and with the largest original index -------------------------------------
+  // (a candidate beyond n or beyond the quota joins the maxima of a spare slot with the value 0: no branch)
+#pragma unroll
+  for (int g = 0; g < ITEMS / 4; g++) {
+    if (4 * g * NT < n) {
+      unsigned pv[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) pv[jj] = pairs ? st[4 * g + jj] & 0x7FFFu : hist[st[4 * g + jj] & 0xFFFFu] & 0x7FFFu;
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) {
+        const int i = (4 * g + jj) * NT + tid;
+        const bool ok = i < n && (int)pv[jj] < nOut;
+        const unsigned k = ok ? pv[jj] : (unsigned)(quotaMax + 1);
+        const uint32_t rs = st[4 * g + jj] & 0xFFFF0000u;
+        __hip_atomic_fetch_max(nodeLo + k, ok ? rs | (0xFFFFu - (uint32_t)i) : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(nodeHi + k, ok ? rs | (uint32_t)i : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        st[4 * g + jj] = rs | (ok ? k : 0xFFFFu);   // from here on the low half is the candidate's node (list position), 0xFFFF = none
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 5. output; nodes with a tied maximum and more than 16 members are set aside for the introsort replay --------------------
+  for (int k = tid; k < nOut; k += NT) {
+    const unsigned iLo = 0xFFFFu - (nodeLo[k] & 0xFFFFu), iHi = nodeHi[k] & 0xFFFFu;
+    if (iLo == iHi || !nodeBig[k]) {
+      outKp[k] = fetch((int)iLo);
+    } else {
+      const int s = atomicAdd(&sTieN, 1);
+      if (s < kQfMaxTied) { sTieNode[s] = k; nodeBig[k] = (uint8_t)(2 + s); }
+    }
+  }
+  __syncthreads();
+  const int nTied = sTieN;
+  if (nTied > kQfMaxTied) { give_up(); return; }
+  if (nTied > 0) {
+    // the pyramid is dead (every position was read before the barrier above): it becomes [keys u32 | original indices u32] of the tied nodes
+    const int slotCap = kQfTieCap / nTied;
+    QT_LDS uint32_t* tKey = (QT_LDS uint32_t*)smem;
+    QT_LDS uint32_t* tVal = tKey + kQfTieCap;
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) {
+      if (j * NT < n) {
+        const unsigned k = st[j] & 0xFFFFu;
+        if (k != 0xFFFFu) {
+          const unsigned tb = nodeBig[k];
+          if (tb >= 2) {
+            const int s = (int)tb - 2, idx = atomicAdd(&sTieCnt[s], 1);
+            if (idx < slotCap) { tKey[s * slotCap + idx] = (uint32_t)(j * NT + tid); tVal[s * slotCap + idx] = st[j] >> 16; }
+            else sFlag = 1;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (sFlag) { give_up(); return; }       // a tied node larger than its share of the buffer: pass kernel
+    for (int s = 0; s < nTied; s++) {       // members in original order: rank = number of members with a smaller original index
+      const int m = sTieCnt[s];
+      constexpr int MAXM = (kQfTieCap + NT - 1) / NT;
+      int rk[MAXM];
+      uint32_t oi[MAXM], rr[MAXM];
+#pragma unroll
+      for (int t = 0; t < MAXM; t++) {
+        rk[t] = -1; oi[t] = 0; rr[t] = 0;
+        const int e = tid + NT * t;
+        if (e < m) {
+          oi[t] = tKey[s * slotCap + e];
+          rr[t] = tVal[s * slotCap + e];
+          int r = 0;
+          for (int u = 0; u < m; u++) r += tKey[s * slotCap + u] < oi[t];
+          rk[t] = r;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < MAXM; t++)
+        if (rk[t] >= 0) { tKey[s * slotCap + rk[t]] = (rr[t] << 16) | (uint32_t)rk[t]; tVal[s * slotCap + rk[t]] = oi[t]; }
+      __syncthreads();
+    }
+    if (tid < nTied) {
+      const int m = sTieCnt[tid];
+      const int best = qt_sort_front(tKey + tid * slotCap, m);
+      outKp[sTieNode[tid]] = fetch((int)tVal[tid * slotCap + best]);
+    }
+  }
+  if (tid == 0) { needPass[unit] = 0; lvlCount[unit] = nOut; }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -34,7 +34,7 @@ struct HostPlan {
   int maxCellDim = 0;   // largest FAST cell (without its 6-px halo): sizes the per-wave LDS of k_fast_cells
   int levelCellDim[kMaxLevels]{};   // ... per level: a launch group takes the tile pitch and LDS of ITS largest cell
   // quad-tree launch geometry per level: node table for 4*quota nodes, LDS-resident candidates up to candCap (HBM beyond)
-  struct QtLevel { int nodeCap, candCap; size_t lds; int flatItems; size_t flatLds; bool passOk; } qt[kMaxLevels]{};
+  struct QtLevel { int nodeCap, candCap; size_t lds; int items; bool passOk; } qt[kMaxLevels]{};   // items: candidates per thread k_qt_fast needs for this level
   size_t qtLdsMax = 0;
   size_t qtPassLds = 0;   // the all-levels hand-over launch: largest node table + cell bases, candidates in HBM
   int qtPassNodes = 0;    // ... and how many nodes that table holds (a level that needs more cannot be handed over)
@@ -64,7 +64,6 @@ struct ydorb_extractor {
   hipEvent_t evFork = nullptr, evJoin[kMaxLevels]{};
   hipEvent_t evFast[kMaxLevels]{};      // end of the FAST launch that covers level l (levels are launched in groups)
   int descKpw = 2;                      // keypoints per wave of k_orient_describe_n
-  bool qtGrouped = false;               // batched handles: one quad-tree launch per FAST level group instead of one per level
   bool qtInline = false;                // YDORB_QT_STREAMS=0: the quad-tree launches go on the caller's stream, behind the blur
   int fastGroups = 1;                   // FAST launches per call: 1 = all levels together
   HostPlan plan;
@@ -132,13 +131,8 @@ void freeBuffers(ydorb_extractor* e) {
 
 // Level sizes, cell grid, scratch layout, resize tables for a w x h input.
 
-// smallest supported items-per-thread of k_quadtree_flat whose 512*items slots hold `want` candidates (16 = the largest)
-static int flatItemsFor(long want) {
-  const int steps[5] = {2, 4, 8, 12, 16};
-  for (int i = 0; i < 5; i++)
-    if ((long)kQtFlatThreads * steps[i] >= want) return steps[i];
-  return 16;
-}
+// smallest instantiated items-per-thread of k_qt_fast whose 256*items registers hold `want` candidates (32 = the largest)
+static int qfItemsFor(long want) { return want <= 8L * kQfThreads ? 8 : want <= 16L * kQfThreads ? 16 : 32; }
 
 // Tables of a level whose kernel writes its own pad (extract_kernels.hip.h, k_pyr_level0_f / k_pyr_resize_f).  Leaves fused[l].on
 // false when the scheme does not apply: a side below 20 px (a pad byte would need two reflections), horizontal scale factor > 2
@@ -360,11 +354,9 @@ int buildPlan(ydorb_extractor* e, int w, int h, HostPlan& P) {
       P.qtLdsMax = std::max(P.qtLdsMax, Q.lds);
       P.qtPassLds = std::max(P.qtPassLds, Q.lds);
     }
-    // flat kernel: 512*items candidate slots.  First guess from the densities above (L0 1/45 .. L7 1/20 of the band); enqueue()
-    // re-sizes it from the candidate counts the device actually saw.  A unit with more candidates goes to the pass kernel.
-    Q.flatItems = flatItemsFor((long)((double)band / (45.0 - 3.5 * l)) + 64);
-    Q.flatLds = qt_flat_lds_bytes(Q.flatItems, L.quota);
-    if (Q.flatLds > 150 * 1024) { Q.flatItems = 0; Q.flatLds = 0; }   // huge quotas: pass kernel only
+    // k_qt_fast keeps 256*items candidates in registers.  First guess from the densities above (L0 1/45 .. L7 1/20 of the band);
+    // enqueue() re-sizes it from the candidate counts the device actually saw.  A unit with more candidates goes to the pass kernel.
+    Q.items = qfItemsFor((long)((double)band / (45.0 - 3.5 * l)) + 64);
   }
   P.qtPassLds = std::max<size_t>(P.qtPassLds, 1024);
   return YDORB_OK;
@@ -427,16 +419,13 @@ int ensurePlan(ydorb_extractor* e, int w, int h, int nFrames) {
   if (std::max(P.qtLdsMax, P.qtPassLds) > 48 * 1024)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(P.qtLdsMax, P.qtPassLds)));
   {
-    size_t ldsFlat = 0;   // any level may later be re-sized up to 16 items (retuneQuadtree)
-    for (int l = 0; l < D.nLevels; l++)
-      if (P.qt[l].flatItems) ldsFlat = std::max(ldsFlat, std::min<size_t>(qt_flat_lds_bytes(16, D.lv[l].quota), 150 * 1024));
-    if (ldsFlat > 48 * 1024) {
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_flat<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFlat));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_flat<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFlat));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_flat<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFlat));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_flat<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFlat));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_flat<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFlat));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_flat_levels), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFlat));
+    int qmax = 1, tabLen = 2;
+    for (int l = 0; l < D.nLevels; l++) { qmax = std::max(qmax, D.lv[l].quota); tabLen = std::max(tabLen, std::max(D.lv[l].w - 2 * kBorder, 0) + std::max(D.lv[l].h - 2 * kBorder, 0) + 2); }
+    const size_t ldsFast = std::min<size_t>(qt_fast_lds_bytes(qmax, tabLen), 150 * 1024);
+    if (ldsFast > 48 * 1024) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qt_fast<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFast));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qt_fast<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFast));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qt_fast<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFast));
     }
   }
   e->planValid = true;
@@ -445,19 +434,13 @@ int ensurePlan(ydorb_extractor* e, int w, int h, int nFrames) {
 
 void collectProfile(ydorb_extractor* e);
 
-// Adapt the flat quad-tree kernel's LDS footprint to the scene: the device keeps the largest candidate count per level, the
-// copy-back at the end of every call brings it here (a call behind, which is fine — both kernels give the same keypoints).
+// Adapt k_qt_fast's candidates-per-thread to the scene: the device keeps the largest candidate count per level, the copy-back at the
+// end of every call brings it here (a call behind, which is fine - a unit that does not fit goes to the pass kernel, same keypoints).
 static void retuneQuadtree(ydorb_extractor* e) {
   HostPlan& P = e->plan;
   for (int l = 0; l < P.dev.nLevels; l++) {
-    HostPlan::QtLevel& Q = P.qt[l];
     const int seen = e->h_lvlMaxN[l];
-    if (!Q.flatItems || seen <= 0) continue;
-    const int items = flatItemsFor((long)seen + seen / 8 + 32);
-    if (items != Q.flatItems && qt_flat_lds_bytes(items, P.dev.lv[l].quota) <= 150 * 1024) {
-      Q.flatItems = items;
-      Q.flatLds = qt_flat_lds_bytes(items, P.dev.lv[l].quota);
-    }
+    if (seen > 0) P.qt[l].items = qfItemsFor((long)seen + seen / 8 + 32);
   }
 }
 
@@ -505,8 +488,8 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   }
   if (prof) HIPCHK(hipEventRecord(e->ev[1], s));
   hipEvent_t fastEv[kMaxLevels]{};
-  int grpFirst[kMaxLevels]{}, grpEnd[kMaxLevels]{}, nGroups = 0;   // level ranges of the FAST launches
-  if (D.nCellsTotal > 0) {
+  int grpFirst[kMaxLevels]{}, grpEnd[kMaxLevels]{}, nGroups = 0;   // level ranges of the FAST launches (and of the quad-tree launches)
+  {
     // one wave per cell, 4 cells per workgroup; the per-wave LDS (tile, score map, candidate list) is sized for the plan's largest cell
     const int thr = std::min(std::max(e->cfg.ini_fast_thr, 0), 255);
     // LDS of a launch: sized for the largest cell of the levels it covers (one level with 40-px cells - 1241 x 376: level 5 - would
@@ -536,7 +519,7 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
     for (int g = 0; g < e->fastGroups && l0 < D.nLevels; g++) {
       const int l1 = g == e->fastGroups - 1 ? D.nLevels : l0 + 1;
       const int c0 = D.lv[l0].cellBegin, c1 = D.lv[l1 - 1].cellBegin + D.lv[l1 - 1].nCells;
-      if (c1 > c0) {
+      if (c1 > c0 && D.nCellsTotal > 0) {
         FastLds fl; bool narrow;
         const size_t dyn = fastGeom(l0, l1, fl, narrow);
         const dim3 grid(((c1 - c0 + 3) / 4 + 7) / 8 * 8, nFrames);
@@ -556,58 +539,41 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   HIPCHK(hipEventRecord(e->evFork, s));
   hipLaunchKernelGGL(k_blur, dim3((D.blurTileBegin[D.nLevels] + 7) / 8 * 8, nFrames), dim3(256), 0, s, e->d_pyr, P.pyrFrameStride, e->d_blur,
                      P.blurFrameStride, D);
-  bool anyFlat = false;
-  bool grouped = e->qtGrouped && !e->forcePassQuadtree && nGroups > 0;
-  for (int l = 0; l < D.nLevels && grouped; l++) grouped = P.qt[l].flatItems > 0;
-  if (grouped) {
-    // one quad-tree launch per FAST level group (k_quadtree_flat_levels), on the side streams in turn
-    for (int g = 0; g < nGroups; g++) {
-      const int l0 = grpFirst[g], l1 = grpEnd[g];
-      const hipStream_t qs = e->qtInline ? s : e->qtStream[g % kMaxLevels];
-      if (!e->qtInline) HIPCHK(hipStreamWaitEvent(qs, fastEv[l0], 0));
-      QtItems it{};
-      size_t lds = 0;
-      for (int l = l0; l < l1; l++) { it.items[l] = P.qt[l].flatItems; lds = std::max(lds, P.qt[l].flatLds); }
-      hipLaunchKernelGGL(k_quadtree_flat_levels, dim3(nFrames, l1 - l0), dim3(kQtFlatThreads), lds, qs, D, e->d_cellCount, e->d_cellCand, l0, it,
-                         e->d_lvlKp, e->d_lvlCount, e->d_needPass, e->d_lvlMaxN);
-      if (!e->qtInline) HIPCHK(hipEventRecord(e->evJoin[g], qs));
-    }
-    if (prof) HIPCHK(hipEventRecord(e->ev[3], s));
-    if (!e->qtInline) for (int g = 0; g < nGroups; g++) HIPCHK(hipStreamWaitEvent(s, e->evJoin[g], 0));
-    anyFlat = true;
-  } else {
-  for (int l = 0; l < D.nLevels; l++) {
-    const hipStream_t qs = e->qtInline ? s : e->qtStream[l];
-    if (!e->qtInline) HIPCHK(hipStreamWaitEvent(qs, fastEv[l] ? fastEv[l] : e->evFork, 0));
-    const HostPlan::QtLevel& Q = P.qt[l];
-    const uint8_t* needPass = nullptr;
-    if (Q.flatItems && !e->forcePassQuadtree) {
-      needPass = e->d_needPass;
-#define YD_QT_FLAT(IT)                                                                                                              \
-  hipLaunchKernelGGL(k_quadtree_flat<IT>, dim3(nFrames), dim3(kQtFlatThreads), Q.flatLds, qs, D, e->d_cellCount,        \
-                     e->d_cellCand, l, e->d_lvlKp, e->d_lvlCount, e->d_needPass, e->d_lvlMaxN)
-      switch (Q.flatItems) {
-        case 2: YD_QT_FLAT(2); break;
-        case 4: YD_QT_FLAT(4); break;
-        case 8: YD_QT_FLAT(8); break;
-        case 12: YD_QT_FLAT(12); break;
-        default: YD_QT_FLAT(16); break;
-      }
-#undef YD_QT_FLAT
-    }
-    // pass algorithm on this level's stream only when the flat kernel is off for the level; otherwise the units the flat kernel
-    // hands over (rare) are picked up by ONE launch over all levels after the join (below)
-    if (!needPass)
-      hipLaunchKernelGGL(k_quadtree, dim3(1, nFrames), dim3(kQtThreads), Q.lds, qs, D, e->d_cellCount, e->d_cellCand,
-                         e->d_qtCand, e->d_qtNode, P.qtFrameStride, Q.nodeCap, Q.candCap, l, e->d_lvlKp, e->d_lvlCount, e->d_status, needPass, e->d_nodeScratch);
-    else
-      anyFlat = true;
-    if (!e->qtInline) HIPCHK(hipEventRecord(e->evJoin[l], qs));
-  }
   if (prof) HIPCHK(hipEventRecord(e->ev[3], s));   // end of the blur; the quad-tree stage is the interval up to the join below
-  if (!e->qtInline) for (int l = 0; l < D.nLevels; l++) HIPCHK(hipStreamWaitEvent(s, e->evJoin[l], 0));
+  // Quad-tree thinning: ONE launch of k_qt_fast per FAST level group (grid = frames x the group's levels), on the group's side stream or
+  // - single-stream handles - on `s` behind the blur.  A group whose quotas need more LDS than a workgroup may have (thousands of
+  // features on few levels) runs the pass kernel level by level instead.
+  bool anyFast = false;
+  for (int g = 0; g < nGroups; g++) {
+    const int l0 = grpFirst[g], l1 = grpEnd[g];
+    const hipStream_t qs = e->qtInline ? s : e->qtStream[g % kMaxLevels];
+    if (!e->qtInline) HIPCHK(hipStreamWaitEvent(qs, fastEv[l0] ? fastEv[l0] : e->evFork, 0));
+    int items = 8, qmax = 1, tabLen = 2;
+    for (int l = l0; l < l1; l++) {
+      items = std::max(items, P.qt[l].items); qmax = std::max(qmax, D.lv[l].quota);
+      tabLen = std::max(tabLen, std::max(D.lv[l].w - 2 * kBorder, 0) + std::max(D.lv[l].h - 2 * kBorder, 0) + 2);
+    }
+    const size_t lds = qt_fast_lds_bytes(qmax, tabLen);
+    if (!e->forcePassQuadtree && lds <= 150 * 1024) {
+      const dim3 grid(nFrames, l1 - l0);
+#define YD_QT_FAST(IT) hipLaunchKernelGGL(k_qt_fast<IT>, grid, dim3(kQfThreads), lds, qs, D, e->d_cellCount, e->d_cellCand, l0, qmax, tabLen, e->d_lvlKp, \
+                                          e->d_lvlCount, e->d_needPass, e->d_lvlMaxN)
+      if (items <= 8) YD_QT_FAST(8);
+      else if (items <= 16) YD_QT_FAST(16);
+      else YD_QT_FAST(32);
+#undef YD_QT_FAST
+      anyFast = true;
+    } else {
+      for (int l = l0; l < l1; l++) {
+        const HostPlan::QtLevel& Q = P.qt[l];
+        hipLaunchKernelGGL(k_quadtree, dim3(1, nFrames), dim3(kQtThreads), Q.lds, qs, D, e->d_cellCount, e->d_cellCand, e->d_qtCand, e->d_qtNode,
+                           P.qtFrameStride, Q.nodeCap, Q.candCap, l, e->d_lvlKp, e->d_lvlCount, e->d_status, nullptr, e->d_nodeScratch);
+      }
+    }
+    if (!e->qtInline) HIPCHK(hipEventRecord(e->evJoin[g], qs));
   }
-  if (anyFlat)   // hand-over units of every level: node table in LDS, candidates in HBM scratch (candCap 0); others exit at once
+  if (!e->qtInline) for (int g = 0; g < nGroups; g++) HIPCHK(hipStreamWaitEvent(s, e->evJoin[g], 0));
+  if (anyFast)   // units k_qt_fast handed over (rare): node table in LDS, candidates in HBM scratch (candCap 0); all others exit at once
     hipLaunchKernelGGL(k_quadtree, dim3(D.nLevels, nFrames), dim3(kQtThreads), P.qtPassLds, s, D, e->d_cellCount, e->d_cellCand, e->d_qtCand,
                        e->d_qtNode, P.qtFrameStride, -std::max(P.qtPassNodes, 1), 0, 0, e->d_lvlKp, e->d_lvlCount, e->d_status, e->d_needPass, e->d_nodeScratch);
   if (prof) HIPCHK(hipEventRecord(e->ev[4], s));
@@ -739,8 +705,6 @@ int ydorb_extractor_create(const YdExtractorConfig* cfg, ydorb_extractor_t** out
     (void)hipEventCreateWithFlags(&e->evFast[l], hipEventDisableTiming);
   }
   {
-    const char* qg = getenv("YDORB_QT_GROUPED");
-    e->qtGrouped = qg && atoi(qg) != 0;   // off: measured slower (every unit then reserves the largest level's LDS: 178 vs 190 Mkeypoints/s)
     const char* g = getenv("YDORB_FAST_GROUPS");
     // batches: level 0 on its own, then the rest - the quad-tree of level 0 (the longest of the eight) starts ~0.5 ms earlier and the
     // chain no longer outlasts the blur when a second handle's kernels share the GPU (alternate-step pipelining: 188 -> 195 Mkeypoints/s)
@@ -970,21 +934,14 @@ int ydorb_extractor_debug_read(ydorb_extractor_t* e, int32_t what, int32_t frame
   if (what == 3) {   // which quad-tree kernel produced the unit: 0 = flat, 1 = pass
     if (dst_bytes < 1) { set_error("need 1 byte"); return YDORB_ERR_CAPACITY; }
     uint8_t v = 1;
-    if (!e->forcePassQuadtree && P.qt[level].flatItems)
+    int qmaxAll = 1, tabAll = 2;
+    for (int l = 0; l < D.nLevels; l++) { qmaxAll = std::max(qmaxAll, D.lv[l].quota); tabAll = std::max(tabAll, std::max(D.lv[l].w - 2 * kBorder, 0) + std::max(D.lv[l].h - 2 * kBorder, 0) + 2); }
+    if (!e->forcePassQuadtree && qt_fast_lds_bytes(qmaxAll, tabAll) <= 150 * 1024)   // (conservative: a group's own largest quota decides at launch)
       HIPCHK(hipMemcpy(&v, e->d_needPass + (size_t)frame * kMaxLevels + level, 1, hipMemcpyDeviceToHost));
     *(uint8_t*)dst = v;
     *written = 1;
     return YDORB_OK;
   }
-#ifdef QT_FLAT_TIMING
-  if (what == 4) {
-    long long clk[kMaxLevels][16];
-    HIPCHK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_qtClk), sizeof(clk)));
-    memcpy(dst, clk[level], sizeof(clk[level]));
-    *written = sizeof(clk[level]);
-    return YDORB_OK;
-  }
-#endif
   set_error("unknown debug stage %d", what);
   return YDORB_ERR_INVALID_ARG;
 }

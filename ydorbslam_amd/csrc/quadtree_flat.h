@@ -60,4 +60,33 @@ YD_HD inline int qt_flat_passes(const int* nodes, const int* leaves, int quota, 
   return p;
 }
 
+// ---- rank form (k_qt_fast, extract_kernels.hip.h): no sort, list positions from one scan over the permuted bin spaces --------------
+constexpr int kQfDepth = 6;                                    // histogram pyramid depth of the rank form: 4^6 = 4096 bins at the bottom
+YD_HD constexpr int qf_off(int d) { return d == 0 ? 0 : 4 + ((1 << (2 * d)) - 4) / 3; }   // 8-byte aligned levels: 0, 4, 8, 24, 88, 344, 1368
+constexpr int kQfPyrU16 = 1368 + 4096;
+// The split digits of one axis: the reference's x tests depend on x only, its y tests on y only until the first child 3 (the
+// line-27 slip hands node 4 the parent's TOP edge as its bottom: from there on every y test fails).  Digits most significant first,
+// complemented (bit set = "not left" / "not top"), spread to every second bit: x digits on the even bits of the key, y digits << 1.
+YD_HD inline uint32_t qf_axis_digits(int c, int hi, int depth = kQfDepth) {
+  int a = 0, b = hi;
+  uint32_t bits = 0;
+  for (int d = 0; d < depth; d++) {
+    const int m = qt_center(a, b);
+    const bool lt = c < m;
+    bits = (bits << 2) | (lt ? 0u : 1u);
+    if (lt) b = m; else a = m;
+  }
+  return bits;
+}
+YD_HD inline uint32_t qf_key(uint32_t xDigits, uint32_t yDigitsShifted) {   // == qt_path_key<kQfDepth> (the harness checks every pixel)
+  uint32_t key = xDigits | yDigitsShifted;
+  const uint32_t both = key & (key >> 1) & 0x555u;
+#if defined(__HIP_DEVICE_COMPILE__)
+  key |= both ? ((1u << (31 - __clz((int)both))) - 1u) & 0xAAAu : 0u;
+#else
+  key |= both ? ((1u << (31 - __builtin_clz(both))) - 1u) & 0xAAAu : 0u;
+#endif
+  return key;
+}
+
 }  // namespace ydorb
