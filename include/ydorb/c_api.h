@@ -425,6 +425,12 @@ int ydorb_ba_solve(const YdBaProblem* prob, const YdBaOptions* opt, YdBaResult* 
  * (may be NULL) per problem; returns the first non-zero status.  Every result is bit-identical to its own ydorb_ba_solve call. */
 int ydorb_ba_solve_batch(const YdBaProblem* probs, int32_t n, const YdBaOptions* opt, YdBaResult* res, int32_t threads, int32_t* rc_each);
 
+/* The solver keeps its device scratch between calls: 8 contexts per device for ydorb_ba_solve / ydorb_pose_optimize and up to 64
+ * problem contexts (~40 MB each at 100 keyframes x 10 000 points) for ydorb_ba_solve_batch.  ydorb_ba_release frees all of it on `device`
+ * (waiting for solves in flight); the next call allocates again.  The reference has no counterpart: g2o's optimizer dies with
+ * localBundleAdjust's stack frame (optimizer.cpp:175-181). */
+int ydorb_ba_release(int32_t device);
+
 /* ------------------------------------------------------------------------------------------
  * Pose-only optimisation.  Replaces YDORBSLAM::Optimizer::optimizePose (src/optimizer.cpp:358-501) — the
  * Tracking thread calls it 1-3x per frame right after a match (tracking.cpp:386,466,611).  A batch of frames is solved in one

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Golden vectors of the extractor oracle on a REAL 640x480 gray frame and on seeded synthetic frames.
 
-Input: thirdParty/DBow3/utils/images/image0.png of the reference (a data file its DBoW3 tests use; read with Pillow).
+Input: thirdParty/DBow3/utils/images/image{0..3}.png of the reference (data files its DBoW3 tests use; read with Pillow).
 No reference binary exists for the extractor (OpenCV is absent), so these vectors pin the ORACLE against
 regressions — "OpenCV-version parity unpinned" — and give the GPU parity tests a fixed real-image case.
 """
@@ -13,10 +13,12 @@ sys.path.insert(0, str(ROOT))
 from oracle.orb_oracle import OrbExtractorOracle
 from ydorbslam_amd.synth import synth_frame
 
-img = np.array(Image.open("/root/reference/thirdParty/DBow3/utils/images/image0.png").convert("L"))
-assert img.shape == (480, 640)
-k, d = OrbExtractorOracle(1000, 1.2, 8, 20, 7).extract(img)
-np.savez_compressed(pathlib.Path(__file__).with_name("dbow3_image0_orb.npz"), image=img, keypoints=k, descriptors=d)
+for i in range(4):
+    img = np.array(Image.open("/root/reference/thirdParty/DBow3/utils/images/image%d.png" % i).convert("L"))
+    assert img.shape == (480, 640)
+    k, d = OrbExtractorOracle(1000, 1.2, 8, 20, 7).extract(img)
+    np.savez_compressed(pathlib.Path(__file__).with_name("dbow3_image%d_orb.npz" % i), image=img, keypoints=k, descriptors=d)
+    print("image%d: %d keypoints" % (i, len(k)))
 h = {}
 for (w, hh, nf, idx) in [(640, 480, 1000, 0), (752, 480, 1000, 1), (1241, 376, 2000, 2), (321, 243, 500, 3)]:
     kk, dd = OrbExtractorOracle(nf, 1.2, 8, 20, 7).extract(synth_frame(w, hh, idx))

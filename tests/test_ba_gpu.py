@@ -298,3 +298,149 @@ def test_batch_with_mixed_sizes_empty_stopped_and_invalid_members(oracle_lib):
     rc = L.ydorb_ba_solve_batch(P, 2, C.byref(o), R, 0, rc_each)
     assert rc != 0 and rc_each[0] != 0 and rc_each[1] == 0
     assert keep[1][0].tobytes() == single[1]["poses"].tobytes() and R[1].n_trials == single[1]["trials"]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_landmark_sharded_solve_through_the_allreduce_callback(world):
+    """SURVEY 8(e), local BA on N GPUs: landmarks (and their edges) shard over ranks, every rank holds all poses, and the solver's five
+    reduction points ([Hpp|bp], max diagonal, [S|bs], the step's scale terms, chi2) go through YdBaOptions.allreduce.  Here the ranks are
+    host threads of ONE process on one GPU (each solve takes its own pooled context / stream) and the callback is a thread-barrier
+    sum / max over the ranks' device comm buffers - what torch.distributed.all_reduce does over RCCL in bench.py.  The sharded solve
+    must follow the unsharded one: same LM trial counts, chi2 / lambda trajectory to 1e-9 (the sums differ only in their association),
+    identical outlier lists, poses equal on every rank, points equal shard by shard."""
+    import threading
+    import torch
+    import ydorbslam_amd as y
+    from ydorbslam_amd.parallel import shard_ba_problem
+    prob = synth_ba_problem(12, 600, 6, seed=11, outlier_frac=0.04, mono_frac=0.3)
+    ref = y.Optimizer.local_bundle_adjust(prob)
+    dev = torch.device("cuda:0")
+    ncomm = 128 * 129 + 4096
+    comm = [torch.zeros(ncomm, dtype=torch.float64, device=dev) for _ in range(world)]
+    bar = threading.Barrier(world)
+    calls = [0] * world
+    res, err = [None] * world, [None] * world
+
+    def make_cb(r):
+        def cb(user, d_buf, count, op):
+            try:
+                calls[r] += 1
+                bar.wait(timeout=60)                 # every rank has copied its partial term into comm[r][:count]
+                if r == 0:
+                    parts = torch.stack([c[:count] for c in comm])
+                    red = parts.max(dim=0).values if op == 1 else parts.sum(dim=0)
+                    for c in comm:
+                        c[:count].copy_(red)
+                    torch.cuda.synchronize()
+                bar.wait(timeout=60)
+                return 0
+            except Exception:  # noqa: BLE001
+                return 1
+        return cb
+
+    def run(r):
+        try:
+            sub, _, _ = shard_ba_problem(prob, r, world)
+            res[r] = y.Optimizer.local_bundle_adjust(sub, y.Optimizer.default_options(), allreduce=make_cb(r), comm_tensor_ptr=comm[r].data_ptr(),
+                                                     comm_doubles=ncomm, rank=r, world=world)
+        except Exception as e:  # noqa: BLE001
+            err[r] = e
+            bar.abort()
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=120)
+    assert err == [None] * world, err
+    assert len(set(calls)) == 1 and calls[0] > 5 * ref["trials"] // 2      # the reduction points were really exercised, equally on every rank
+    for r in range(world):
+        _, keep, ke = shard_ba_problem(prob, r, world)
+        got = res[r]
+        assert got["trials"] == ref["trials"] and np.array_equal(got["log"][:, 2:], ref["log"][:, 2:])
+        assert np.allclose(got["log"][:, :2], ref["log"][:, :2], rtol=1e-9, atol=0)
+        assert np.array_equal(got["outlier"], ref["outlier"][ke])
+        assert np.allclose(got["poses"], ref["poses"], rtol=1e-9, atol=1e-12)
+        assert np.array_equal(got["poses"], res[0]["poses"])              # every rank factorises the same reduced system
+        assert np.allclose(got["points"], ref["points"][keep], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("trip_at", [3, 8, 19])
+def test_stop_flag_raised_at_a_fixed_reduction_is_deterministic(trip_at):
+    """The asynchronous stop (tracking.cpp:786 -> localMapping.hpp:62) without a timer: the flag is raised inside the trip_at-th
+    all-reduce callback of a 2-rank landmark-sharded solve, i.e. at the same point of the LM schedule on both ranks and in every run.
+    The solve must end early with stopped = 1, both ranks must hold the same poses, and a second run must reproduce it bit for bit."""
+    import threading
+    import torch
+    import ydorbslam_amd as y
+    from ydorbslam_amd.parallel import shard_ba_problem
+    prob = synth_ba_problem(12, 600, 6, seed=11, outlier_frac=0.04, mono_frac=0.3)
+    full = y.Optimizer.local_bundle_adjust(prob)
+    dev = torch.device("cuda:0")
+    ncomm = 128 * 129 + 4096
+
+    def sharded_run():
+        comm = [torch.zeros(ncomm, dtype=torch.float64, device=dev) for _ in range(2)]
+        bar = threading.Barrier(2)
+        stop = np.zeros(1, np.uint8)
+        calls = [0]
+        res, err = [None, None], [None, None]
+
+        def make_cb(r):
+            def cb(user, d_buf, count, op):
+                try:
+                    bar.wait(timeout=60)
+                    if r == 0:
+                        calls[0] += 1
+                        parts = torch.stack([c[:count] for c in comm])
+                        red = parts.max(dim=0).values if op == 1 else parts.sum(dim=0)
+                        for c in comm:
+                            c[:count].copy_(red)
+                        torch.cuda.synchronize()
+                        if calls[0] == trip_at:
+                            stop[0] = 1
+                    bar.wait(timeout=60)
+                    return 0
+                except Exception:  # noqa: BLE001
+                    return 1
+            return cb
+
+        def run(r):
+            try:
+                sub, _, _ = shard_ba_problem(prob, r, 2)
+                res[r] = y.Optimizer.local_bundle_adjust(sub, y.Optimizer.default_options(), stop=stop, allreduce=make_cb(r),
+                                                         comm_tensor_ptr=comm[r].data_ptr(), comm_doubles=ncomm, rank=r, world=2)
+            except Exception as e:  # noqa: BLE001
+                err[r] = e
+                bar.abort()
+        ths = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=120)
+        assert err == [None, None], err
+        return res
+    a, b = sharded_run(), sharded_run()
+    for r in range(2):
+        assert a[r]["stopped"] and a[r]["trials"] < full["trials"] and a[r]["iterations"] < full["iterations"]
+        assert a[r]["poses"].tobytes() == b[r]["poses"].tobytes() and a[r]["points"].tobytes() == b[r]["points"].tobytes()
+        assert a[r]["trials"] == b[r]["trials"]
+    assert a[0]["poses"].tobytes() == a[1]["poses"].tobytes()
+
+
+def test_release_gives_the_pooled_scratch_back():
+    """ydorb_ba_release: the solver's pooled contexts (single solves, pose batches, lock-step batch jobs) free their device buffers and
+    pinned staging; the next solve allocates again and gives the same result."""
+    import torch
+    import ydorbslam_amd as y
+    prob = synth_ba_problem(20, 2000, 6, seed=2)
+    a = y.Optimizer.local_bundle_adjust(prob)
+    ba = y.Optimizer.local_bundle_adjust_batch([prob] * 3)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    y.Optimizer.release(0)
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free1 > free0
+    b = y.Optimizer.local_bundle_adjust(prob)
+    bb = y.Optimizer.local_bundle_adjust_batch([prob] * 3)
+    assert a["poses"].tobytes() == b["poses"].tobytes() and a["points"].tobytes() == b["points"].tobytes()
+    assert all(x["poses"].tobytes() == a["poses"].tobytes() for x in ba + bb)

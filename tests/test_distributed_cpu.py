@@ -103,6 +103,46 @@ def _worker(rank, world, port, q):
         allf, _ = stream_render(plan, range(G))
         recs = [oex.extract(f) for f in allf]
         res["match_single"] = {g: match(*recs[g], *recs[g + 1], plan["predicted"][g]) for g in range(G - 1)}
+    # 5. the ordering bench.py runs: the exchange of launch k is in flight (communication stream there, async collectives here) while
+    #    launch k + 1 is being extracted into ANOTHER output set; launch 1 shows the stream's frames in reverse order of ownership
+    #    (a different set of records), so a gather that landed in the wrong set or was matched too early gives different matches.
+    sets = [(g_kps, g_desc, g_n), (torch.zeros_like(g_kps), torch.zeros_like(g_desc), torch.zeros_like(g_n))]
+    works = []
+    def issue(b):
+        return [dist.all_gather_into_tensor(full, full[rank * Fr:(rank + 1) * Fr].clone(), async_op=True) for full in sets[b]]
+    for full in sets[0]:
+        full[:rank * Fr] = 0; full[(rank + 1) * Fr:] = 0          # forget what step 4 gathered: only the own slice is known
+    works.append(issue(0))                                        # launch 0's exchange starts ...
+    frames1, _ = stream_render(plan, [G - 1 - g for g in own])    # ... while launch 1 is "extracted" (the stream mirrored in time)
+    for t in range(Fr):
+        k, d = oex.extract(frames1[t])
+        sets[1][0][rank * Fr + t, :len(k)] = torch.from_numpy(k.view(np.uint8).reshape(-1, 28).copy())
+        sets[1][1][rank * Fr + t, :len(k)] = torch.from_numpy(d.copy())
+        sets[1][2][rank * Fr + t] = len(k)
+    for w_ in works[0]:
+        w_.wait()
+    works.append(issue(1))
+    res["match_overlapped"] = {int(p): match(*rec(qi), *rec(ti), plan["predicted"][p]) for (qi, ti), p in zip(pairs, pred)}   # set 0 again
+    for w_ in works[1]:
+        w_.wait()
+    res["set1_counts"] = sets[1][2].tolist()
+    # 6. neighbour exchange (bench.py --exchange neighbour): contiguous shards, only each rank's LAST frame record travels; the set a
+    #    rank matches on is [own Fr frames | every rank's boundary frame]
+    lo_g, hi_g = par.frame_shard(G, rank, world)
+    framesc, _ = stream_render(plan, range(lo_g, hi_g))
+    n_kps = torch.zeros((Fr + world, cap2, 28), dtype=torch.uint8); n_desc = torch.zeros((Fr + world, cap2, 32), dtype=torch.uint8)
+    n_n = torch.zeros(Fr + world, dtype=torch.int32)
+    for t in range(Fr):
+        k, d = oex.extract(framesc[t])
+        n_kps[t, :len(k)] = torch.from_numpy(k.view(np.uint8).reshape(-1, 28).copy()); n_desc[t, :len(k)] = torch.from_numpy(d.copy()); n_n[t] = len(k)
+    for full in (n_kps, n_desc, n_n):
+        dist.all_gather_into_tensor(full[Fr:], full[Fr - 1:Fr].clone())
+
+    def recn(i):
+        n_ = int(n_n[i])
+        return n_kps[i, :n_].numpy().reshape(-1).view(KP).copy(), n_desc[i, :n_].numpy().copy()
+    npairs = [(t - 1, t, lo_g + t - 1) for t in range(1, Fr)] + ([(Fr + rank - 1, 0, lo_g - 1)] if rank > 0 else [])
+    res["match_neighbour"] = {int(p): match(*recn(qi), *recn(ti), plan["predicted"][p]) for qi, ti, p in npairs}
     mx = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     res["max"] = mx.item()
@@ -138,6 +178,19 @@ def test_two_rank_gloo():
             merged[g] = v
     single = out[0]["match_single"]
     assert sorted(merged) == sorted(single) == list(range(world * 3 - 1))
+    # the overlapped ordering gives the same matches, and launch 1's gathered set is complete on every rank
+    for r in range(world):
+        assert out[r]["match_overlapped"] == out[r]["match"]
+        assert out[r]["set1_counts"] == out[0]["set1_counts"] and min(out[r]["set1_counts"]) > 0
+    # neighbour exchange: every consecutive pair exactly once, with the single-process answer
+    nb = {}
+    for r in range(world):
+        for g, v in out[r]["match_neighbour"].items():
+            assert g not in nb
+            nb[g] = v
+    assert sorted(nb) == sorted(single)
+    for g in single:
+        assert nb[g] == single[g], g
     for g in single:
         assert merged[g][0] == single[g][0] and merged[g][1] == single[g][1], "pair %d" % g
     assert sum(v[0] for v in single.values()) > 0

@@ -105,6 +105,26 @@ def test_strided_input(oracle_lib):
     assert np.array_equal(desc[:n.value], cd)
 
 
+@pytest.mark.parametrize("batched", [False, True])
+def test_real_images_match_the_committed_goldens(batched):
+    """The reference's four real 640x480 frames (thirdParty/DBow3/utils/images/image{0..3}.png): the HIP path against the committed oracle
+    outputs (tests/golden/dbow3_image*_orb.npz, made by make_extractor_golden.py) - no oracle call here.  Real frames are sparse
+    (~1.5 candidates per kept keypoint on level 0): the quad-tree's deep-tree form."""
+    import os
+    import ydorbslam_amd as y
+    gold = [np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dbow3_image%d_orb.npz" % i)) for i in range(4)]
+    if batched:
+        ex = y.OrbExtractor(1000, 1.2, 8, 20, 7, max_batch=12, single_stream=True)
+        res = ex.extract_batch(np.stack([g["image"] for g in gold] * 3))
+    else:
+        ex = y.OrbExtractor(1000, 1.2, 8, 20, 7)
+        res = [ex.extract(g["image"]) for g in gold]
+    for i, (k, d) in enumerate(res):
+        g = gold[i % 4]
+        _same_kps(k, g["keypoints"])
+        assert np.array_equal(d, g["descriptors"]), i
+
+
 def test_quadtree_flat_and_pass_kernels_agree(oracle_lib, monkeypatch):
     """The thinning has two device forms: the rank one (k_qt_fast: histogram pyramid, list positions from one scan, per-node maxima,
     quadtree_flat.h) and the pass one (quadtree_core.h, taken for units the rank form hands over).  Both must give the

@@ -375,3 +375,54 @@ def test_back_to_back_calls_on_one_handle_without_synchronize():
     assert int(ref_c.sum()) > 100
     for a, c in outs:
         assert torch.equal(a, ref_a) and torch.equal(c, ref_c)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_match_pairs_on_the_gathered_layouts_of_every_rank(world):
+    """The multi-GPU match step on one GPU: the records of a stream of world * F frames laid out as the all-gathered set (rank-major,
+    global frame g = t * world + rank at slot rank * F + t), every rank's pair list from parallel.round_robin_pairs, distinct query /
+    target slots per pair and only F of the world * F frames searched (the matcher builds grids for those alone).  The union over
+    ranks must equal the consecutive matching of the stream in its natural order."""
+    import torch
+    import ydorbslam_amd as y
+    from ydorbslam_amd.parallel import round_robin_pairs
+    from ydorbslam_amd.synth import stream_plan, stream_render
+    W, H, F = 640, 480, 3
+    G = world * F
+    plan = stream_plan(W, H, G, seed=3, segment=G)
+    imgs, _ = stream_render(plan, range(G))
+    ex = y.OrbExtractor(1000, max_batch=G)
+    cap = ex.max_keypoints
+    dev = torch.device("cuda:0")
+    d_img = torch.from_numpy(imgs).to(dev)
+    kps = torch.zeros((G, cap, 7), dtype=torch.float32, device=dev)
+    desc = torch.zeros((G, cap, 32), dtype=torch.uint8, device=dev)
+    n = torch.zeros(G, dtype=torch.int32, device=dev)
+    ex.extract_batch_device(d_img.data_ptr(), W, H, W, W * H, G, kps.data_ptr(), desc.data_ptr(), cap, n.data_ptr())
+    ex.synchronize()
+    sf = ex.tables()["scale"]
+    aff = torch.from_numpy(np.ascontiguousarray(plan["predicted"], np.float32)).to(dev)
+    m = y.OrbMatcher(0.9, True)
+    ref_a = torch.zeros((G - 1, cap), dtype=torch.int32, device=dev)
+    ref_c = torch.zeros(G - 1, dtype=torch.int32, device=dev)
+    m.match_consecutive_device(kps.data_ptr(), desc.data_ptr(), n.data_ptr(), cap, G, W, H, 15.0, sf, ref_a.data_ptr(), ref_c.data_ptr(), d_affine=aff.data_ptr())
+    m.synchronize()
+    assert int(ref_c.sum()) > 50
+    slot_of = torch.tensor([(g % world) * F + g // world for g in range(G)], device=dev)       # natural index -> gathered slot
+    g_kps, g_desc, g_n = torch.zeros_like(kps), torch.zeros_like(desc), torch.zeros_like(n)
+    g_kps[slot_of], g_desc[slot_of], g_n[slot_of] = kps, desc, n
+    gs = (g_kps.data_ptr(), g_desc.data_ptr(), g_n.data_ptr(), G, cap)
+    seen = set()
+    for rank in range(world):
+        pairs, pred = round_robin_pairs(rank, world, F)
+        a = torch.zeros((len(pairs), cap), dtype=torch.int32, device=dev)
+        c = torch.zeros(len(pairs), dtype=torch.int32, device=dev)
+        d_aff = aff[torch.from_numpy(pred).to(dev)].contiguous()
+        mr = y.OrbMatcher(0.9, True)
+        mr.match_pairs_device(gs, gs, pairs, W, H, 15.0, sf, a.data_ptr(), c.data_ptr(), d_aff.data_ptr())
+        mr.synchronize()
+        for i, g in enumerate(pred.tolist()):
+            assert g not in seen
+            seen.add(g)
+            assert int(c[i]) == int(ref_c[g]) and torch.equal(a[i], ref_a[g]), (rank, g)
+    assert seen == set(range(G - 1))

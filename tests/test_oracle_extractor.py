@@ -13,10 +13,12 @@ from ydorbslam_amd.synth import synth_frame
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def test_golden_real_image(oracle_lib):
-    g = np.load(os.path.join(HERE, "golden", "dbow3_image0_orb.npz"))
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_golden_real_image(oracle_lib, idx):
+    """The reference's four real 640x480 frames (thirdParty/DBow3/utils/images/image{0..3}.png): committed oracle outputs."""
+    g = np.load(os.path.join(HERE, "golden", "dbow3_image%d_orb.npz" % idx))
     k, d = oracle_lib.OrbExtractorOracle(1000, 1.2, 8, 20, 7).extract(g["image"])
-    assert len(k) == len(g["keypoints"]) == 1000
+    assert len(k) == len(g["keypoints"]) and 900 < len(k) <= 1000
     assert k.tobytes() == g["keypoints"].tobytes()
     assert np.array_equal(d, g["descriptors"])
 

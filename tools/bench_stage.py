@@ -6,7 +6,7 @@ import ydorbslam_amd as y
 from ydorbslam_amd.synth import synth_frame
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 imgs = np.stack([synth_frame(640, 480, i % 32) for i in range(F)])
-ex = y.OrbExtractor(1000, max_batch=F)
+ex = y.OrbExtractor(1000, max_batch=F, single_stream=bool(int(os.environ.get("YDORB_STAGE_SINGLE", "1"))))   # single-stream handle: what bench.py's lanes use
 ex.extract_batch(imgs)
 ex.set_profiling(True)
 for _ in range(5):

@@ -76,6 +76,7 @@ SYMBOLS = {
     "ydorb_matcher_set_profiling": (C.c_int, [_VP, _I]),
     "ydorb_matcher_stage_times": (C.c_int, [_VP, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_I)]),
     "ydorb_ba_default_options": (None, [_VP]),
+    "ydorb_ba_release": (C.c_int, [_I]),
     "ydorb_ba_solve": (C.c_int, [_VP, _VP, _VP]),
     "ydorb_ba_solve_batch": (C.c_int, [_VP, _I, _VP, _VP, _I, _VP]),
     "ydorb_ba_dense_solve": (C.c_int, [_I, _VP, _I, _VP, _VP, C.POINTER(_I)]),

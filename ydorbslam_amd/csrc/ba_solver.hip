@@ -50,6 +50,7 @@ struct DBuf {
     return YDORB_OK;
   }
   template <class T> T* as() { return reinterpret_cast<T*>(p); }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
 enum { PH_ERR = 0, PH_BUILD, PH_SCHUR, PH_SOLVE, PH_UPDATE, PH_COUNT };
@@ -74,6 +75,14 @@ struct Ctx {  // per-device scratch, reused across calls (localBundleAdjust runs
     return YDORB_OK;
   }
   DBuf pStart, pPoses, pX, pMeas, pInfo, pErr, pFlags, pOutlier, pInl, pChi, pTrials;   // pose-only batches
+  void releaseBuffers() {   // ydorb_ba_release: device scratch and pinned staging back to the system (stream and events stay)
+    for (DBuf* b : {&poses[0], &poses[1], &pts[0], &pts[1], &ePose, &ePidx, &ePt, &eMeas, &eInfo, &eInfo0, &eRobust, &eOutlier, &eLm, &ptStart,
+                    &poseStart, &poseEdges, &poseOf, &ptOf, &err, &partial, &Hll, &bl, &Hpl, &BD, &Hpp, &bp, &S, &diagL, &diagInv, &bs, &Dinv, &db,
+                    &xp, &xl, &yv, &scal, &status, &pairCnt, &pairStart, &pairCursor, &pairA, &pairB, &pStart, &pPoses, &pX, &pMeas, &pInfo, &pErr,
+                    &pFlags, &pOutlier, &pInl, &pChi, &pTrials})
+      b->release();
+    if (hStage) { (void)hipHostFree(hStage); hStage = nullptr; hStageCap = 0; }
+  }
 };
 // A small pool of contexts per device: one localBundleAdjust at a time is the reference's use (LocalMapping thread), but the solve
 // is a latency chain that leaves most of the GPU idle, so several host threads (several maps / sessions) may solve concurrently,
@@ -677,6 +686,7 @@ int solveGroup(BatchPool& B, const YdBaProblem* probs, const YdBaOptions& Oin, Y
   trace("batch: set-up done");
 
   auto maxOver = [&](auto fn) { int m = 0; for (int j = 0; j < n; j++) if (!J[j]->done) m = std::max(m, fn(J[j]->run->sys)); return m; };
+  auto rounds = [&]() -> int {
   while (true) {
     bool any = false;
     for (int j = 0; j < n; j++) any = any || !J[j]->done;
@@ -788,8 +798,22 @@ int solveGroup(BatchPool& B, const YdBaProblem* probs, const YdBaOptions& Oin, Y
       if (lambdaBroke || !(X.rho < 0 && X.qmax < X.O.max_trials && !X.run->stopped())) endIteration(j);
     }
   }
+  return YDORB_OK;
+  };
+  {
+    // a HIP error inside the rounds ends the group: every member that has not been read back reports it (its poses / points / outlier
+    // list were not written), members that failed earlier keep their own status
+    int rr = rounds();
+    if (rr == YDORB_OK && hipStreamSynchronize(s) != hipSuccess) { set_error("hipStreamSynchronize failed after the lock-step rounds"); rr = YDORB_ERR_HIP; }
+    if (rr != YDORB_OK) {
+      const std::string text = ydorb_last_error();
+      for (int j = 0; j < n; j++)
+        if (J[j]->rc == YDORB_OK && J[j]->run && (!J[j]->done || J[j]->pendingEnd)) { J[j]->pendingEnd = false; J[j]->errText = text; fail(j, rr); }
+      set_error("%s", text.c_str());
+      return rr;
+    }
+  }
   {  // endSolve of every finished problem, spread over the set-up threads and streams (the lock-step stream has drained)
-    HIPCHK(hipStreamSynchronize(s));
     const int nt = std::max(1, std::min(n, (int)B.setupStreams.size()));
     std::atomic<int> next{0};
     auto worker = [&](int t) {
@@ -975,6 +999,29 @@ int ydorb_ba_solve_batch(const YdBaProblem* probs, int32_t n, const YdBaOptions*
   }
   if (first != YDORB_OK) set_error("%s", firstText.c_str());
   return first;
+}
+
+int ydorb_ba_release(int32_t device) {
+  if (device < 0 || device >= 16) { set_error("invalid device"); return YDORB_ERR_INVALID_ARG; }
+  int rc = require_device(device);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(device));
+  for (int i = 0; i < kCtxPool; i++) {          // waits for a solve that holds the context
+    std::lock_guard<std::mutex> lock(g_mu[device][i]);
+    Ctx& c = g_ctx[device][i];
+    if (c.stream) (void)hipStreamSynchronize(c.stream);
+    c.releaseBuffers();
+  }
+  BatchPool& B = g_batch[device];
+  std::lock_guard<std::mutex> lock(B.mu);
+  if (B.stream) (void)hipStreamSynchronize(B.stream);
+  for (Job* j : B.jobs) { j->ctx.releaseBuffers(); delete j; }
+  B.jobs.clear();
+  B.dDev.release(); B.dScal.release();
+  if (B.hDev) (void)hipHostFree(B.hDev);
+  if (B.hScal) (void)hipHostFree(B.hScal);
+  B.hDev = nullptr; B.hScal = nullptr; B.cap = 0;
+  return YDORB_OK;
 }
 
 int ydorb_ba_dense_solve(int32_t device, const double* A, int32_t n0, const double* b, double* x, int32_t* ok) {

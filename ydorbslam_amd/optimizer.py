@@ -71,6 +71,11 @@ class Optimizer:
                             update=res.ms_update))
 
     @staticmethod
+    def release(device=0):
+        """ydorb_ba_release: give the solver's pooled device scratch on `device` back (the next solve allocates again)."""
+        check(lib().ydorb_ba_release(device))
+
+    @staticmethod
     def local_bundle_adjust_batch(probs, options=None, threads=0):
         """n independent problems in one ydorb_ba_solve_batch call (host threads inside the library, one pooled context each).
         Returns a list of the dicts local_bundle_adjust returns."""
