@@ -568,16 +568,29 @@ def mono_section(ctx, y, link):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # Configs 3 and 4: stereo streams (extract L + R, computeStereoMatches, consecutive left-frame search), inclusive and resident
 # ---------------------------------------------------------------------------------------------------------------------------------
-def stereo_config(ctx, y, link, w, h, nf, n_pairs, label, repeats):
+def stereo_config(ctx, y, link, w, h, nf, n_pairs, label, repeats, tile_default=1):
     import numpy as np
     from ydorbslam_amd.synth import stream_plan, stream_render
     torch, dev, args = ctx.torch, ctx.dev, ctx.args
-    pl = stream_plan(w, h, n_pairs, seed=7, segment=32)
-    L_, R_ = stream_render(pl, range(n_pairs), stereo=True)
+    # `tile` launches' worth of the stream per launch: the two serial chains of a launch (stereo replay, ordered resolve) take the same time
+    # for 128 pairs as for 512 (one wave per pair), so larger launches hide them better behind the other lanes' extractions
+    # (measured, inclusive / resident Mkeypoints/s with 4 lanes - tools/bench_stereo_sweep.sh: config 3 at 128 / 256 pairs per launch 133 / 193 ->
+    # 186 / 205; config 4 at 64 / 128 / 256 pairs per launch 79 / 138 -> 93 / 171 -> 124 / 190)
+    tile = max(1, int(os.environ.get("YDORB_BENCH_STEREO_TILE", str(tile_default))))
+    distinct = n_pairs
+    pl = stream_plan(w, h, distinct, seed=7, segment=32)
+    L_, R_ = stream_render(pl, range(distinct), stereo=True)
+    if tile > 1:
+        L_, R_ = np.concatenate([L_] * tile), np.concatenate([R_] * tile)
+        n_pairs = distinct * tile
     hL, hR = torch.from_numpy(L_).pin_memory(), torch.from_numpy(R_).pin_memory()
     mk = lambda *shape, dt=torch.float32: torch.zeros(shape, dtype=dt, device=dev)
     prs = np.array([(i, i + 1) for i in range(n_pairs - 1)], np.int32)
-    daf = torch.from_numpy(np.ascontiguousarray(pl["predicted"], np.float32)).to(dev)
+    pred_ = np.ascontiguousarray(pl["predicted"], np.float32)
+    if tile > 1:   # the pair that joins two copies of the stream is a scene cut (identity prediction)
+        ident = np.array([[1, 0, 0, 0, 1, 0]], np.float32)
+        pred_ = np.concatenate([pred_] + [np.concatenate([ident, pred_])] * (tile - 1))
+    daf = torch.from_numpy(pred_).to(dev)
     # NSETS lanes, each a complete set (extractor pair, outputs, matchers) with ONE stream: a launch's two extractions, its association (the
     # serial replay of frame.cpp:391-462) and its left-frame search (ordered resolve) run back to back on the lane's stream, consecutive
     # launches go to consecutive lanes, no events between lanes: the two latency chains of a launch hide behind the extractions of the other
@@ -690,7 +703,7 @@ def stereo_config(ctx, y, link, w, h, nf, n_pairs, label, repeats):
     t_inc = res["inclusive"]["ms_per_launch"] * 1e-3
     t_res = res["kernel_pipeline"]["ms_per_launch"] * 1e-3
     out = {"workload": label, "value": res["inclusive"]["value"], "unit": "Mkeypoints/s", "inclusive": res["inclusive"], "kernel_pipeline": res["kernel_pipeline"],
-           "extract_only": res["extract_only"], "stereo_pairs_per_launch": n_pairs, "keypoints_per_image": kp_img,
+           "extract_only": res["extract_only"], "stereo_pairs_per_launch": n_pairs, "distinct_stereo_pairs": distinct, "keypoints_per_image": kp_img,
            "stereo_measurements_per_pair": float(sets[0]["kept"].float().mean().item()), "matches_per_left_pair": float(sets[0]["cnt"].float().mean().item()),
            "pipelining": "%d lanes (handle pair + matchers + one stream each) take consecutive launches; a launch's extractions, association and search run back "
                          "to back on its lane; uploads into a ring of %d device image pairs on a copy-in stream, read-backs on a copy-out stream" % (NSETS, RING),
@@ -883,11 +896,11 @@ def main():
     if want("config3"):
         out["config3"] = stereo_config(ctx, y, link, 1241, 376, 2000, 128, "KITTI-00-size 1241x376 stereo, 2000 feat/image: extract L+R, computeStereoMatches "
                                        "(as the reference writes it), consecutive left-frame search; pinned host frames in, results back in pinned host memory",
-                                       max(3, args.repeats // 2))
+                                       max(3, args.repeats // 2), tile_default=2)
     if want("config4"):
         out["config4"] = stereo_config(ctx, y, link, 752, 480, 1000, 64, "EuRoC-MH-size 752x480 stereo batch, 1000 feat/image, one GPU's share: extract L+R, "
                                        "computeStereoMatches, consecutive left-frame search; pinned host frames in, results back in pinned host memory",
-                                       max(3, args.repeats // 2))
+                                       max(3, args.repeats // 2), tile_default=4)
     state = None
     if extras:
         import bench_extras

@@ -47,8 +47,14 @@ struct PlanDev {
   int borderBegin[kMaxLevels + 1];     // first border thread of each level in k_pyr_borders' flat per-frame list (multiples of 256)
   LevelDev lv[kMaxLevels];
 };
-// 64 x 32 output tiles (taller tiles make the blur alone faster but the two-lane pipeline slower: DESIGN.md section 6)
-constexpr int kBlurTW = 64, kBlurTH = 32;
+#ifndef BLUR_TH
+#define BLUR_TH 58
+#endif
+// Output tile of k_blur: 64 x BLUR_TH (any height with BLUR_TH + 6 even).  58 + 6 = 64 source rows = 32 row pairs x 16 dword groups =
+// exactly two full passes of the workgroup in the horizontal stage, and a 10 % halo instead of 19 % with 32-row tiles: 0.516 -> 0.457 ms
+// per 512 frames alone, resident-frames pipeline 212.8 -> 216.2 Mkeypoints/s (26 rows: 0.577 ms, 210.6).  (Round 2 kept 32: the blur then
+// had to outlast the eight quad-tree launches it was hiding; k_qt_fast ended that.)
+constexpr int kBlurTW = 64, kBlurTH = BLUR_TH;
 struct CellDev {            // FAST sub-image [x0,x1) x [y0,y1) in level coordinates (orbExtractor.cpp:562-581)
   short level, x0, y0, x1, y1, pad0;
   int srcOff;               // byte offset of the sub-image's first pixel inside a frame's pyramid block (host-computed)
