@@ -14,7 +14,7 @@ and SURVEY.md 8(d) times "the batch incl. H2D/D2H".  So the headline `value` is 
 `kernel_pipeline` is the same work with the frames already resident in HBM and the results left there (what rounds 1-2 reported as
 `value`), `pcie` is the measured host link next to it, `roofline` the dominant kernel against the HBM roof.
 
-One "step" = --substeps launches of --frames frames each (default 16 x 512 = 8192 frames), alternating over two lanes; the timed
+One "step" = --substeps launches of --frames frames each (default 8 x 1024 = 8192 frames), dealt to four lanes in turn; the timed
 region is exactly --steps steps, bracketed by barrier + synchronize, and it is repeated --repeats times: `value` is the median,
 `repeats` holds min / max.
 
@@ -575,7 +575,7 @@ def stereo_config(ctx, y, link, w, h, nf, n_pairs, label, repeats, tile_default=
     # `tile` launches' worth of the stream per launch: the two serial chains of a launch (stereo replay, ordered resolve) take the same time
     # for 128 pairs as for 512 (one wave per pair), so larger launches hide them better behind the other lanes' extractions
     # (measured, inclusive / resident Mkeypoints/s with 4 lanes - tools/bench_stereo_sweep.sh: config 3 at 128 / 256 pairs per launch 133 / 193 ->
-    # 186 / 205; config 4 at 64 / 128 / 256 pairs per launch 79 / 138 -> 93 / 171 -> 124 / 190)
+    # 186 / 205; config 4 at 64 / 128 / 256 / 512 pairs per launch 79 / 138 -> 93 / 171 -> 124 / 190 -> 139 / 194)
     tile = max(1, int(os.environ.get("YDORB_BENCH_STEREO_TILE", str(tile_default))))
     distinct = n_pairs
     pl = stream_plan(w, h, distinct, seed=7, segment=32)
@@ -858,8 +858,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--repeats", type=int, default=10, help="timed regions of exactly --steps steps each; value = median")
-    ap.add_argument("--frames", type=int, default=512, help="frames per launch and per GPU")
-    ap.add_argument("--substeps", type=int, default=16, help="launches per step (a step = substeps x frames frames: 20 steps are then a timed region of > 1 s)")
+    ap.add_argument("--frames", type=int, default=1024, help="frames per launch and per GPU (measured, inclusive / resident Mkeypoints/s: 256 frames 142 / 214, "
+                                                            "512 frames 163 / 213, 1024 frames 174 / 209: longer uploads keep the link busier)")
+    ap.add_argument("--substeps", type=int, default=8, help="launches per step (a step = substeps x frames frames: 20 steps are then a timed region of > 1 s)")
     ap.add_argument("--region-s", type=float, default=1.0, help="target length of the timed regions of the config 3 / config 4 sections")
     ap.add_argument("--segment", type=int, default=64, help="frames per synthetic scene (a new scene is a cut)")
     ap.add_argument("--exchange", choices=("allgather", "neighbour"), default="allgather",
@@ -900,7 +901,7 @@ def main():
     if want("config4"):
         out["config4"] = stereo_config(ctx, y, link, 752, 480, 1000, 64, "EuRoC-MH-size 752x480 stereo batch, 1000 feat/image, one GPU's share: extract L+R, "
                                        "computeStereoMatches, consecutive left-frame search; pinned host frames in, results back in pinned host memory",
-                                       max(3, args.repeats // 2), tile_default=4)
+                                       max(3, args.repeats // 2), tile_default=8)
     state = None
     if extras:
         import bench_extras

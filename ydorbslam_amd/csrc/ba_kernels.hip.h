@@ -510,7 +510,10 @@ __global__ __launch_bounds__(256) void k_bs(EdgeSoA Ed, const int* __restrict__ 
 // share: it runs on the FP64 matrix core, v_mfma_f64_16x16x4_f64 (A[i = lane&15][k = lane>>4], B[k][j = lane&15],
 // D col = lane&15, row = (lane>>4) + 4*reg; rows/cols >= 6 are fed zeros), four k-columns per instruction.
 typedef double double4_t __attribute__((ext_vector_type(4)));
-constexpr int kSchurWaves = 4;   // waves per bucket
+#ifndef SCHUR_WAVES
+#define SCHUR_WAVES 4
+#endif
+constexpr int kSchurWaves = SCHUR_WAVES;   // waves per bucket
 __device__ __forceinline__ void b_schur_pairs(const int* __restrict__ start, const int2* __restrict__ items, int nP, int nBuckets,
                                                      const R* __restrict__ BD, const R* __restrict__ Hpl, const R* __restrict__ Hpp, R lambda,
                                                      R contrib, int n, R* __restrict__ S, R* __restrict__ bs) {

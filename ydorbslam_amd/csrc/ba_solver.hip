@@ -564,7 +564,7 @@ struct BatchPool {   // per device: contexts, stream and staging of the lock-ste
   int cap = 0;
 };
 BatchPool g_batch[16];
-constexpr int kSetupThreads = 8;   // host threads of a batch's set-up phase
+constexpr int kSetupThreads = 16;  // host threads of a batch's set-up phase
 constexpr int kBatchGroup = 64;    // problems per lock-step group (C5-sized problems take ~40 MB each)
 
 void fillDev(Job& J, BaDev& D, const BaDev* dDevBase, double* dScal, int* dStatus) {
