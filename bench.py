@@ -251,26 +251,30 @@ def pcie_link(ctx, mb=160, reps=5):
 class MonoStream:
     W, H, NFEAT = 640, 480, 1000
     LANES = int(os.environ.get("YDORB_BENCH_LANES", "4"))
-    # where the copies of the inclusive pipeline run: "lane" = on the lane's own stream (upload, kernels, read-back in stream order: no
-    # copy streams, no events; other lanes' kernels run beside a lane's copies), "streams" = a copy-in and a copy-out stream + events
-    COPY = os.environ.get("YDORB_BENCH_COPY", "lane")
     # single-stream handles (YDORB_EXTRACTOR_SINGLE_STREAM: quad-tree launches on the lane's stream): the device runs 4 hardware queues, so 4 lanes
-    # of one stream each keep every lane on its own queue; handles with side streams share queues with the copies and with each other
-    # (measured, inclusive / resident Mkeypoints/s: 4 lanes single-stream 151 / 199, 2 lanes with side streams 93 / 194, tools/bench_copy_sweep.sh)
+    # of one stream each keep every lane on its own queue; handles with side streams share queues with the copies and with each other.  The
+    # uploads and read-backs of the inclusive pipeline run on the lane's own stream (upload, kernels, read-back in stream order: no copy
+    # streams, no events - the other lanes' kernels run beside a lane's copies).  Measured, inclusive / resident Mkeypoints/s
+    # (tools/bench_copy_sweep.sh): 4 lanes single-stream 151 / 199, 2 lanes with side streams 93 / 194, copy-in / copy-out streams + 2 lanes 140 / 197.
     SINGLE = bool(int(os.environ.get("YDORB_BENCH_SINGLE_STREAM", "1")))
+    # N > 1: the exchange on a communication stream of the bench's own (1), or issued from the lane's stream (0: the collective itself still runs
+    # on RCCL's internal stream and the lane waits for it).  One more stream means the lanes share hardware queues again: with an RCCL
+    # process group at world size 1 on one GPU, 94 against 146 Mkeypoints/s inclusive (tools/rehearse_multigpu.sh) - off by default.
+    COMM_STREAM = bool(int(os.environ.get("YDORB_BENCH_COMM_STREAM", "0")))
 
-    def __init__(self, ctx, y):
+    def __init__(self, ctx, y, exchange=None):
         import numpy as np
         from ydorbslam_amd.synth import stream_plan, stream_render
-        from ydorbslam_amd.parallel import round_robin_pairs, frame_shard
+        from ydorbslam_amd.parallel import ring_pairs, frame_shard
         torch, args = ctx.torch, ctx.args
         self.ctx, self.y = ctx, y
         W, H, F, world, rank, dev = self.W, self.H, args.frames, ctx.world, ctx.rank, ctx.dev
         self.F, self.G = F, F * world
-        self.neighbour = args.exchange == "neighbour" and ctx.distributed
+        self.mode = (exchange or args.exchange) if ctx.distributed else "none"
+        neighbour = self.mode == "neighbour"
         # every frame distinct; frame g+1 = frame g after a small known motion (scene cut every --segment frames).
         self.plan = stream_plan(W, H, self.G, seed=0, segment=args.segment)
-        if self.neighbour:      # contiguous shards: global frame g = rank * F + t
+        if neighbour:           # contiguous shards: global frame g = rank * F + t
             lo_g, _ = frame_shard(self.G, rank, world)
             own = list(range(lo_g, lo_g + F))
         else:                   # round-robin: global frame g = t * world + rank
@@ -279,113 +283,122 @@ class MonoStream:
         # The lane streams are created FIRST, before any handle creates streams of its own: the device runs 4 hardware queues and HIP deals
         # streams onto them in creation order (profiles/r02d_queue_overlap.txt).
         self.lane_streams = [torch.cuda.Stream(device=dev) for _ in range(self.LANES)]
-        self.s_in, self.s_out, self.s_comm = (torch.cuda.Stream(device=dev) for _ in range(3))
-        self.RING = self.LANES if self.COPY == "lane" else self.LANES + 1
+        self.s_comm = torch.cuda.Stream(device=dev) if ctx.distributed and self.COMM_STREAM else None
         self.exs = [y.OrbExtractor(self.NFEAT, 1.2, 8, 20, 7, device=ctx.local_rank, max_batch=F, single_stream=self.SINGLE) for _ in range(self.LANES)]
         self.cap = cap = self.exs[0].max_keypoints
         self.sf = self.exs[0].tables()["scale"]
-        # output sets: one per lane, or two when the read-back of launch k runs on a copy-out stream under the lane's next launch k + LANES
-        self.NSET = NSET = self.LANES if self.COPY == "lane" else 2 * self.LANES
-        # an output set is laid out as the set the matcher reads: [world * F] frames (all-gather; this rank's extractor writes straight into its
-        # slice) or [F + world] (neighbour exchange: own frames, then every rank's boundary frame)
-        nset_frames = (F + world) if self.neighbour else self.G
-        self.lo = lo = 0 if self.neighbour else rank * F
-        self.g_kps = [torch.zeros((nset_frames, cap, 7), dtype=torch.float32, device=dev) for _ in range(NSET)]
-        self.g_desc = [torch.zeros((nset_frames, cap, 32), dtype=torch.uint8, device=dev) for _ in range(NSET)]
-        self.g_n = [torch.zeros(nset_frames, dtype=torch.int32, device=dev) for _ in range(NSET)]
-        self.d_kps = [t[lo:lo + F] for t in self.g_kps]
-        self.d_desc = [t[lo:lo + F] for t in self.g_desc]
-        self.d_n = [t[lo:lo + F] for t in self.g_n]
-        self.nset_frames = nset_frames
-        if self.neighbour:
+        self.NSET = NSET = self.LANES            # one output set (and one image buffer) per lane
+        # A rank's records of a launch are ONE slab [keypoints FS x cap x 28 B | descriptors FS x cap x 32 B | counts FS x 4 B]; an output set
+        # holds `world` slabs, rank r's at slab r, and this rank's extractor writes straight into its own (no packing copy).  With the
+        # frames dealt round-robin, every frame's predecessor lives on rank - 1 (mod world): the queries of a launch are rank - 1's slab,
+        # the targets the rank's own.  FS = F, or F + 1 with the neighbour exchange (slot F = the previous rank's boundary frame).
+        FS = F + 1 if neighbour else F
+        self.FS = FS
+        self.off_desc = FS * cap * 28
+        self.off_n = self.off_desc + FS * cap * 32
+        self.slab = (self.off_n + FS * 4 + 255) // 256 * 256
+        self.sets = [torch.zeros(world * self.slab, dtype=torch.uint8, device=dev) for _ in range(NSET)]
+        self.own = [t[rank * self.slab:(rank + 1) * self.slab] for t in self.sets]
+        self.prev_rank = (rank - 1) % world
+        if neighbour:
             prs = [(t - 1, t) for t in range(1, F)]
             pred = [lo_g + t - 1 for t in range(1, F)]
-            if rank > 0:      # the pair that straddles the shard boundary: query = rank - 1's last frame (slot F + rank - 1), target = own frame 0
-                prs.append((F + rank - 1, 0)); pred.append(lo_g - 1)
+            if rank > 0:      # the pair that straddles the shard boundary: query = rank - 1's last frame (slot F), target = own frame 0
+                prs.append((F, 0)); pred.append(lo_g - 1)
             self.pairs, pred_idx = np.array(prs, np.int32).reshape(-1, 2), np.array(pred, np.int64)
+            self.q_rank = rank
+            self.rec = cap * 60 + 4
+            self.recs = [torch.zeros((world, self.rec), dtype=torch.uint8, device=dev) for _ in range(NSET)]
+            self.myrec = [torch.zeros(self.rec, dtype=torch.uint8, device=dev) for _ in range(NSET)]
         else:
-            self.pairs, pred_idx = round_robin_pairs(rank, world, F)
+            self.pairs, pred_idx = ring_pairs(rank, world, F)
+            self.q_rank = self.prev_rank
         self.NPAIR = NPAIR = len(self.pairs)
         self.d_aff = torch.from_numpy(np.ascontiguousarray(self.plan["predicted"][pred_idx], np.float32)).to(dev)
         self.d_assigned = [torch.zeros((NPAIR, cap), dtype=torch.int32, device=dev) for _ in range(NSET)]
         self.d_counts = [torch.zeros(NPAIR, dtype=torch.int32, device=dev) for _ in range(NSET)]
         self.mts = [y.OrbMatcher(0.9, True, device=ctx.local_rank) for _ in range(NSET)]   # one matcher (own scratch) per output set
-        # host side of the inclusive pipeline: pinned frames, a ring of device image buffers, pinned result sets
+        # host side of the inclusive pipeline: pinned frames, one device image buffer per lane, pinned result sets
         self.h_img = torch.from_numpy(self.imgs).pin_memory()
-        self.d_img = [torch.empty_like(self.h_img, device=dev) for _ in range(self.RING)]
+        self.d_img = [torch.empty_like(self.h_img, device=dev) for _ in range(self.LANES)]
         self.d_img[0].copy_(self.h_img)
-        self.h_out = [[torch.zeros_like(t, device="cpu").pin_memory() for t in (self.d_kps[b], self.d_desc[b], self.d_n[b], self.d_assigned[b], self.d_counts[b])]
-                      for b in range(NSET)]
+        self.h_out = [[torch.zeros_like(t, device="cpu").pin_memory() for t in (self.own[b], self.d_assigned[b], self.d_counts[b])] for b in range(NSET)]
         ev = lambda n_: [torch.cuda.Event() for _ in range(n_)]
-        self.ev_in, self.ev_free = ev(self.RING), ev(self.RING)
-        self.ev_done, self.ev_out, self.ev_x, self.ev_g = ev(NSET), ev(NSET), ev(NSET), ev(NSET)
+        self.ev_x, self.ev_g = ev(NSET), ev(NSET)
         self.k = 0
         self.bytes_in = F * W * H
         self.bytes_out = sum(t.numel() * t.element_size() for t in self.h_out[0])
 
-    def gather(self, b, sA):
-        """N > 1: the exchange of launch k on the communication stream (the other lane extracts launch k + 1 meanwhile); the lane's
-        matcher waits for it."""
-        ctx, torch = self.ctx, self.ctx.torch
-        self.ev_x[b].record(sA)
-        self.s_comm.wait_event(self.ev_x[b])
-        with torch.cuda.stream(self.s_comm):
-            if self.neighbour:     # every rank's LAST frame record (60 KB + 4 B) into slots [F, F + world)
-                F = self.F
-                ctx.all_gather_into(self.g_kps[b][F:], self.g_kps[b][F - 1:F])
-                ctx.all_gather_into(self.g_desc[b][F:], self.g_desc[b][F - 1:F])
-                ctx.all_gather_into(self.g_n[b][F:], self.g_n[b][F - 1:F])
-            else:                  # SURVEY 8(e): all-gather of every rank's records of the launch, three large collectives, in place
-                ctx.all_gather_into(self.g_kps[b], self.d_kps[b])
-                ctx.all_gather_into(self.g_desc[b], self.d_desc[b])
-                ctx.all_gather_into(self.g_n[b], self.d_n[b])
-        self.ev_g[b].record(self.s_comm)
-        sA.wait_event(self.ev_g[b])
+    def ptrs(self, b, r):
+        """(d_kps, d_desc, d_n, n_frames, cap) of rank r's slab in output set b"""
+        base = self.sets[b].data_ptr() + r * self.slab
+        return (base, base + self.off_desc, base + self.off_n, self.FS, self.cap)
+
+    def counts(self, b, host=False):
+        """this rank's keypoint counts of output set b (device tensor, or the pinned host copy the inclusive pipeline delivered)"""
+        t = self.h_out[b][0] if host else self.own[b]
+        return t[self.off_n:self.off_n + 4 * self.F].view(self.ctx.torch.int32)
+
+    def exchange(self, b, sA):
+        """N > 1: the exchange of launch k; the lane's matcher waits for it, the other lanes extract launches k + 1 .. k + 3 meanwhile."""
+        ctx, torch, dist = self.ctx, self.ctx.torch, self.ctx.dist
+        sc = self.s_comm if self.s_comm is not None else sA
+        if sc is not sA:
+            self.ev_x[b].record(sA)
+            sc.wait_event(self.ev_x[b])
+        with torch.cuda.stream(sc):
+            if self.mode == "allgather":     # SURVEY 8(e): all-gather of every rank's records of the launch: ONE collective, in place
+                ctx.all_gather_into(self.sets[b].view(ctx.world, self.slab), self.own[b].view(1, self.slab))
+            elif self.mode == "ring":        # only what the matcher reads: the previous rank's slab (one send, one receive per rank)
+                if ctx.world > 1:
+                    prev = self.sets[b][self.prev_rank * self.slab:(self.prev_rank + 1) * self.slab]
+                    if ctx.staged:
+                        hs, hr = self.own[b].cpu(), torch.empty(self.slab, dtype=torch.uint8)
+                        for r_ in dist.batch_isend_irecv([dist.P2POp(dist.isend, hs, (ctx.rank + 1) % ctx.world), dist.P2POp(dist.irecv, hr, self.prev_rank)]):
+                            r_.wait()
+                        prev.copy_(hr)
+                    else:
+                        for r_ in dist.batch_isend_irecv([dist.P2POp(dist.isend, self.own[b], (ctx.rank + 1) % ctx.world), dist.P2POp(dist.irecv, prev, self.prev_rank)]):
+                            r_.wait()
+            else:                            # neighbour: every rank's LAST frame record (60 KB + 4 B); the previous rank's goes to slot F
+                F, cap, o = self.F, self.cap, self.own[b]
+                m = self.myrec[b]
+                m[:cap * 28].copy_(o[(F - 1) * cap * 28:F * cap * 28])
+                m[cap * 28:cap * 60].copy_(o[self.off_desc + (F - 1) * cap * 32:self.off_desc + F * cap * 32])
+                m[cap * 60:].copy_(o[self.off_n + 4 * (F - 1):self.off_n + 4 * F])
+                ctx.all_gather_into(self.recs[b], m.view(1, self.rec))
+                p = self.recs[b][self.prev_rank]
+                o[F * cap * 28:(F + 1) * cap * 28].copy_(p[:cap * 28])
+                o[self.off_desc + F * cap * 32:self.off_desc + (F + 1) * cap * 32].copy_(p[cap * 28:cap * 60])
+                o[self.off_n + 4 * F:self.off_n + 4 * F + 4].copy_(p[cap * 60:])
+        if sc is not sA:
+            self.ev_g[b].record(sc)
+            sA.wait_event(self.ev_g[b])
 
     def launch(self, inclusive, match=True):
-        """One launch of F frames: lane k % LANES, output set k % NSET, (inclusive) ring slot k % RING."""
+        """One launch of F frames on lane k % LANES (its stream, image buffer, output set and matcher): [upload] -> extraction ->
+        [exchange] -> matching -> [read-back], in stream order."""
         torch, W, H, F = self.ctx.torch, self.W, self.H, self.F
         k = self.k
         self.k += 1
-        lane, b = k % self.LANES, k % self.NSET
+        lane = b = k % self.LANES
         sA = self.lane_streams[lane]
-        img = self.d_img[0]
-        in_lane = self.COPY == "lane"
-        if inclusive and in_lane:
-            img = self.d_img[lane]
+        img = self.d_img[lane if inclusive else 0]
+        if inclusive:
             with torch.cuda.stream(sA):
                 img.copy_(self.h_img, non_blocking=True)
-        elif inclusive:
-            r = k % self.RING
-            img = self.d_img[r]
-            self.s_in.wait_event(self.ev_free[r])          # the extraction that last read this ring slot is done
-            with torch.cuda.stream(self.s_in):
-                img.copy_(self.h_img, non_blocking=True)
-            self.ev_in[r].record(self.s_in)
-            sA.wait_event(self.ev_in[r])
-            sA.wait_event(self.ev_out[b])                  # the read-back that last read this output set is done
-        self.exs[lane].extract_batch_device(img.data_ptr(), W, H, W, W * H, F, self.d_kps[b].data_ptr(), self.d_desc[b].data_ptr(), self.cap,
-                                            self.d_n[b].data_ptr(), sA.cuda_stream)
-        if inclusive and not in_lane:
-            self.ev_free[r].record(sA)
+        own = self.ptrs(b, self.ctx.rank)
+        self.exs[lane].extract_batch_device(img.data_ptr(), W, H, W, W * H, F, own[0], own[1], self.cap, own[2], sA.cuda_stream)
         if not match:
             return
         if self.ctx.distributed:
-            self.gather(b, sA)
-        gs = (self.g_kps[b].data_ptr(), self.g_desc[b].data_ptr(), self.g_n[b].data_ptr(), self.nset_frames, self.cap)
-        self.mts[b].match_pairs_device(gs, gs, self.pairs, W, H, 15.0, self.sf, self.d_assigned[b].data_ptr(), self.d_counts[b].data_ptr(),
-                                       self.d_aff.data_ptr(), sA.cuda_stream)
-        if inclusive and in_lane:
+            self.exchange(b, sA)
+        self.mts[b].match_pairs_device(self.ptrs(b, self.q_rank), own, self.pairs, W, H, 15.0, self.sf, self.d_assigned[b].data_ptr(),
+                                       self.d_counts[b].data_ptr(), self.d_aff.data_ptr(), sA.cuda_stream)
+        if inclusive:
             with torch.cuda.stream(sA):
-                for h_, d_ in zip(self.h_out[b], (self.d_kps[b], self.d_desc[b], self.d_n[b], self.d_assigned[b], self.d_counts[b])):
+                for h_, d_ in zip(self.h_out[b], (self.own[b], self.d_assigned[b], self.d_counts[b])):
                     h_.copy_(d_, non_blocking=True)
-        elif inclusive:
-            self.ev_done[b].record(sA)
-            self.s_out.wait_event(self.ev_done[b])
-            with torch.cuda.stream(self.s_out):
-                for h_, d_ in zip(self.h_out[b], (self.d_kps[b], self.d_desc[b], self.d_n[b], self.d_assigned[b], self.d_counts[b])):
-                    h_.copy_(d_, non_blocking=True)
-            self.ev_out[b].record(self.s_out)
 
     def step(self, inclusive, match=True):
         for _ in range(self.ctx.args.substeps):
@@ -490,9 +503,9 @@ def mono_section(ctx, y, link):
     # ---- the contract's number: H2D/D2H-inclusive, exactly --steps steps per timed region -----------------------------------------
     t_inc = ctx.timed(lambda: S.step(True), args.steps, args.warmup, args.repeats)
     S.synchronize()
-    kp_local = int(S.h_out[0][2].sum().item())            # from the pinned host copy the pipeline delivered
-    matched_local = int(S.h_out[0][4].sum().item())
-    if kp_local != int(S.d_n[0].sum().item()) or kp_local <= 0:
+    kp_local = int(S.counts(0, host=True).sum().item())   # from the pinned host copy the pipeline delivered
+    matched_local = int(S.h_out[0][2].sum().item())
+    if kp_local != int(S.counts(0).sum().item()) or kp_local <= 0:
         raise RuntimeError("the read-back of the inclusive pipeline does not match the device results")
     kp_total = ctx.sum_over_ranks(float(kp_local))
     rate = lambda dt: kp_total * launches / dt / 1e6
@@ -516,9 +529,8 @@ def mono_section(ctx, y, link):
     mt.set_profiling(True)
     for _ in range(5):
         ex2.extract_batch(S.imgs)
-    gs0 = (S.g_kps[0].data_ptr(), S.g_desc[0].data_ptr(), S.g_n[0].data_ptr(), S.nset_frames, S.cap)
     for _ in range(6):
-        mt.match_pairs_device(gs0, gs0, S.pairs, W, H, 15.0, S.sf, S.d_assigned[0].data_ptr(), S.d_counts[0].data_ptr(), S.d_aff.data_ptr())
+        mt.match_pairs_device(S.ptrs(0, S.q_rank), S.ptrs(0, ctx.rank), S.pairs, W, H, 15.0, S.sf, S.d_assigned[0].data_ptr(), S.d_counts[0].data_ptr(), S.d_aff.data_ptr())
         mt.synchronize()
     isolated = dict(ex2.stage_times())
     isolated.update(mt.stage_times())
@@ -537,8 +549,35 @@ def mono_section(ctx, y, link):
                               "roof - %.1f Mkeypoints/s at peak_GBps for this workload" % (kp_total / (S.bytes_in / (link["peak_GBps"] * 1e9)) / 1e6 / 1.0)})
     par = "1 GPU"
     if world > 1:
-        par = ("contiguous frame shards x%d, all-gather of each rank's boundary frame record per launch, local match" % world) if S.neighbour else \
-              ("frames dealt round-robin x%d, all-gather of [kp|desc|n] per launch on a communication stream, local match against the gathered set" % world)
+        par = {"neighbour": "contiguous frame shards x%d, all-gather of each rank's boundary frame record (60 KB) per launch, local match",
+               "ring": "frames dealt round-robin x%d, every rank sends its [kp|desc|n] slab of the launch to rank + 1 (the only rank that reads it), local match",
+               "allgather": "frames dealt round-robin x%d, ONE all-gather of every rank's [kp|desc|n] slab per launch, "
+                            "local match of the owned frames against rank - 1's slab"}[S.mode] % world
+    variants = None
+    if ctx.distributed and world > 1 or (ctx.force_dist and os.environ.get("YDORB_BENCH_VARIANTS")):
+        # the other two exchange forms, measured in the same run (3 repeats each): value stays the all-gather form north_star names
+        variants = {}
+        def quick(Sx):
+            ti = ctx.timed(lambda: Sx.step(True), args.steps, args.warmup, 3)
+            tr = ctx.timed(lambda: Sx.step(False), args.steps, args.warmup, 3)
+            Sx.synchronize()
+            kpx = ctx.sum_over_ranks(float(int(Sx.counts(0).sum().item())))
+            med = lambda ts: float(sorted(ts)[len(ts) // 2])
+            return {"value": kpx * launches / med(ti) / 1e6, "kernel_pipeline": kpx * launches / med(tr) / 1e6, "unit": "Mkeypoints/s",
+                    "exchanged_MB_per_rank_per_launch": (Sx.slab * (world - 1) if Sx.mode == "allgather" else Sx.slab if Sx.mode == "ring" else Sx.rec * world) / 1e6}
+        main_mode = S.mode
+        for mode in ("allgather", "ring"):
+            if mode != main_mode and main_mode != "neighbour":
+                S.mode = mode
+                variants[mode] = quick(S)
+        S.mode = main_mode
+        other = "neighbour" if main_mode != "neighbour" else "allgather"
+        S2 = MonoStream(ctx, y, exchange=other)
+        variants[other] = quick(S2)
+        if other == "allgather":
+            S2.mode = "ring"
+            variants["ring"] = quick(S2)
+        del S2
     out = {"metric": "ORB extract+match Mkeypoints/sec", "value": inc["median"], "unit": "Mkeypoints/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt_inc / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u8", "data": "synthetic", "parity": "partial", "parity_note": PARITY_NOTE,
@@ -551,9 +590,8 @@ def mono_section(ctx, y, link):
                                   "pinned host frames in, results back in pinned host memory",
                       "frames_per_step_per_gpu": F * args.substeps, "frames_per_launch": F, "launches_per_step": args.substeps,
                       "distinct_frames": F * world, "frames_per_scene": args.segment,
-                      "pipelining": "%d lanes (extractor handle + stream each) take consecutive launches, a launch's extraction and matching back to back on its "
-                                    "lane's stream; uploads on a copy-in stream into a ring of %d device image buffers, read-backs of the %d output sets on a "
-                                    "copy-out stream; every buffer reuse ordered by events" % (S.LANES, S.RING, S.NSET),
+                      "pipelining": "%d lanes (extractor handle + matcher + image buffer + output set + ONE stream each) take consecutive launches: upload, "
+                                    "extraction, matching and read-back of a launch in its lane's stream order, the lanes overlap each other" % S.LANES,
                       "motion": "per frame: roll within +-3 deg, shift within +-8 px (bounded walk); prediction = true motion + N(0,1.5^2) px on the translation",
                       "keypoints_per_frame": kp_local / F, "matches_per_pair": matched_local / max(S.NPAIR, 1), "parallelism": par},
            "kernel_pipeline": {"value": res["median"], "unit": "Mkeypoints/s", "ms_per_step": dt_res / args.steps * 1e3, "min": res["min"], "max": res["max"],
@@ -562,6 +600,11 @@ def mono_section(ctx, y, link):
            "extract_only": {"value": ext["median"], "unit": "Mkeypoints/s", "min": ext["min"], "max": ext["max"],
                             "note": "extraction launches only (frames resident), same handles and streams"},
            "pcie": pcie, "roofline": roofline}
+    if variants is not None:
+        out["exchange"] = {"mode": S.mode, "MB_per_rank_per_launch": (S.slab * (world - 1) if S.mode == "allgather" else S.slab if S.mode == "ring" else S.rec * world) / 1e6,
+                           "variants": variants,
+                           "note": "value / kernel_pipeline above use `mode`; variants = the other exchange forms in the same run (3 repeats): ring = round-robin "
+                                   "frames, each rank sends its slab to rank + 1 only; neighbour = contiguous frame shards, only the boundary frame travels"}
     return out, S
 
 
@@ -863,8 +906,9 @@ def main():
     ap.add_argument("--substeps", type=int, default=8, help="launches per step (a step = substeps x frames frames: 20 steps are then a timed region of > 1 s)")
     ap.add_argument("--region-s", type=float, default=1.0, help="target length of the timed regions of the config 3 / config 4 sections")
     ap.add_argument("--segment", type=int, default=64, help="frames per synthetic scene (a new scene is a cut)")
-    ap.add_argument("--exchange", choices=("allgather", "neighbour"), default="allgather",
-                    help="N > 1: round-robin frames + all-gather of every rank's records (SURVEY 8e), or contiguous shards + boundary frame only")
+    ap.add_argument("--exchange", choices=("allgather", "ring", "neighbour"), default="allgather",
+                    help="N > 1: round-robin frames + all-gather of every rank's records (SURVEY 8e); round-robin + only the previous rank's records "
+                         "(point-to-point); or contiguous shards + boundary frame only")
     ap.add_argument("--cpu-frames", type=int, default=96, help="frames of the 1-thread CPU-oracle sample")
     ap.add_argument("--ba-threads", type=int, default=64, help="problems of the lock-step batched local-BA figure (ydorb_ba_solve_batch)")
     ap.add_argument("--ba-reps", type=int, default=3, help="solves per timed repeat of the single local-BA figure")

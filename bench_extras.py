@@ -51,7 +51,8 @@ def run(ctx, y, S, out, want):
         single_call(ctx, y, S, out)
     if not want("rest"):
         return st
-    d_desc, d_n = S.d_desc[0], S.d_n[0]
+    d_desc = S.own[0][S.off_desc:S.off_desc + S.F * cap * 32].view(S.F, cap, 32)
+    d_n = S.counts(0)
     # ---- brute-force N x M Hamming top-2 (north_star; SURVEY 8d secondary figure, against the integer-VALU peak) -------------------
     NB_ = min(F - 1, 255)
     mb = y.OrbMatcher(device=ctx.local_rank)

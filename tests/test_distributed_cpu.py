@@ -195,3 +195,20 @@ def test_two_rank_gloo():
         assert merged[g][0] == single[g][0] and merged[g][1] == single[g][1], "pair %d" % g
     assert sum(v[0] for v in single.values()) > 0
     assert out[1]["pairs"][0] == [0, 3]        # rank 1's frame 0 (global 1) is searched for rank 0's frame 0 (global 0)
+
+
+def test_ring_pairs_are_the_round_robin_pairs_in_local_indices():
+    """parallel.ring_pairs: with the frames dealt round-robin every query of a rank lives on rank - 1 (mod world); the pairs must be
+    those of round_robin_pairs (indices into the rank-major gathered set), and over all ranks every consecutive pair exactly once."""
+    from ydorbslam_amd import parallel as par
+    for world in (1, 2, 3, 8):
+        F = 5
+        seen = []
+        for rank in range(world):
+            gp, gpred = par.round_robin_pairs(rank, world, F)
+            lp, lpred = par.ring_pairs(rank, world, F)
+            assert np.array_equal(gpred, lpred) and len(gp) == len(lp)
+            prev = (rank - 1) % world
+            assert np.array_equal(gp[:, 0], prev * F + lp[:, 0]) and np.array_equal(gp[:, 1], rank * F + lp[:, 1])
+            seen += lpred.tolist()
+        assert sorted(seen) == list(range(world * F - 1))

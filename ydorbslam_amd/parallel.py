@@ -36,6 +36,22 @@ def round_robin_pairs(rank, world, frames_per_rank):
     return np.array(pairs, np.int32).reshape(-1, 2), np.array(pred, np.int64)
 
 
+def ring_pairs(rank, world, frames_per_rank):
+    """The same pairs as round_robin_pairs, as (query, target) LOCAL frame indices: with the frames dealt round-robin every owned frame's
+    predecessor lives on rank - 1 (mod world), so the queries of a launch are that ONE rank's records - local index t for rank > 0
+    (g - 1 = t * world + rank - 1), t - 1 for rank 0 (g - 1 = (t - 1) * world + world - 1; global frame 0 has no predecessor).
+    Returns (pairs [n,2] int32, pred [n] = g - 1)."""
+    F = frames_per_rank
+    pairs, pred = [], []
+    for t in range(F):
+        g = t * world + rank
+        if g == 0:
+            continue
+        pairs.append((t if rank > 0 else t - 1, t))
+        pred.append(g - 1)
+    return np.array(pairs, np.int32).reshape(-1, 2), np.array(pred, np.int64)
+
+
 def boundary_record_bytes(cap):
     return cap * (28 + 32) + 4
 
