@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 #pragma unroll
       for (int k = 0; k < NR; k++) {
         const int ty = tyb + ty0 + ROWS * k;
-        r[k] = (colOk && ty < th) ? *reinterpret_cast<const u64_unaligned*>(sub + (size_t)ty * pitch + 8 * wd) : 0ull;
+        r[k] = (colOk && ty < th) ? *reinterpret_cast<const u64_unaligned*>(sub + (unsigned)(ty * pitch + 8 * wd)) : 0ull;   // scalar base + 32-bit lane offset
       }
 #pragma unroll
       for (int k = 0; k < NR; k++) {
@@ -498,14 +498,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     const uint8_t* p = tile + (byl + 3) * PITCH + bxl + 3;
     unsigned ent = (unsigned)(byl << 6) | (unsigned)bxl;
     const uint16_t t16 = (uint16_t)thr;
-    auto step = [&](bool valid) {
+    auto step = [&](uint16_t vmask) {      // vmask: 0xFFFF on lanes inside the band, 0x7FFF outside (their sign bit never survives)
       const uint16_t v = p[0], a = p[3 * PITCH], b = p[-3 * PITCH], cc = p[3], d = p[-3];
       const uint16_t lo1 = min(a, b), hi1 = max(a, b), lo2 = min(cc, d), hi2 = max(cc, d);
       const uint16_t mx = max(lo1, lo2), mn = min(hi1, hi2);
       const uint16_t second = max(mx, mn), third = min(mn, mx);
       const uint16_t s1 = (uint16_t)((uint16_t)(v + t16) - second);   // sign set: >= 2 brighter compass pixels
       const uint16_t s2 = (uint16_t)(third - (uint16_t)(v - t16));    // sign set: >= 2 darker compass pixels
-      const bool keep = ((int16_t)(s1 | s2) < 0) & valid;
+      const bool keep = (int16_t)((uint16_t)(s1 | s2) & vmask) < 0;
       const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
       if (keep) list[n1 + wave_rank(m)] = (uint16_t)(ent | (s1 & 0x8000u) | ((s2 & 0x8000u) >> 1));
       n1 += __popcll(m);
@@ -513,9 +513,13 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
       ent += rowsPerIt * 64;
     };
     const bool colOk = bxl < bw;
+    // (opaque to the optimiser: it otherwise turns the mask back into `compare AND lane-valid` and rebuilds the ballot from a 0 / 1 select)
+    unsigned vmA = colOk ? 0xFFFFu : 0x7FFFu, vmF = colOk && byl == 0 ? 0xFFFFu : 0x7FFFu;
+    asm volatile("" : "+v"(vmA), "+v"(vmF));
+    const uint16_t vmAll = (uint16_t)vmA, vmFirst = (uint16_t)vmF;
     int by0 = 0;
-    for (; by0 + rowsPerIt <= bh; by0 += rowsPerIt) step(colOk);
-    if (by0 < bh) step(colOk && byl == 0);   // odd band height: only the first row of the last step is inside
+    for (; by0 + rowsPerIt <= bh; by0 += rowsPerIt) step(vmAll);
+    if (by0 < bh) step(vmFirst);   // odd band height: only the first row of the last step is inside
   }
   __builtin_amdgcn_wave_barrier();
   // stage B: arc test and score in one network; corners stay in the list (compacted in place: writes never pass the reads)
