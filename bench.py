@@ -593,7 +593,12 @@ def mono_section(ctx, y, link):
                       "pipelining": "%d lanes (extractor handle + matcher + image buffer + output set + ONE stream each) take consecutive launches: upload, "
                                     "extraction, matching and read-back of a launch in its lane's stream order, the lanes overlap each other" % S.LANES,
                       "motion": "per frame: roll within +-3 deg, shift within +-8 px (bounded walk); prediction = true motion + N(0,1.5^2) px on the translation",
-                      "keypoints_per_frame": kp_local / F, "matches_per_pair": matched_local / max(S.NPAIR, 1), "parallelism": par},
+                      "keypoints_per_frame": kp_local / F, "matches_per_pair": matched_local / max(S.NPAIR, 1),
+                      "matches_note": "what the reference's rules accept: ~770 of 1000 keypoints of a frame re-appear within 2.5 px x scale in the next one "
+                                      "(median Hamming distance 35), but Frame::getKeyPointsInArea keeps only candidates with |dx| > r inside the "
+                                      "window's grid cells (frame.cpp:353, reproduced bit for bit) and the rotation histogram uses the factor 1/30 "
+                                      "(orbMatcher.cpp:78): ~120 pass the distance test, ~50 the rotation check",
+                      "parallelism": par},
            "kernel_pipeline": {"value": res["median"], "unit": "Mkeypoints/s", "ms_per_step": dt_res / args.steps * 1e3, "min": res["min"], "max": res["max"],
                                "n": res["n"], "timed_region_s": dt_res,
                                "note": "frames resident in HBM, results left in HBM; the same launches, lanes and streams without the copies"},

@@ -14,7 +14,7 @@ def last(name, counter):
     res = {}
     for k, v in d.items():
         ids = sorted(v)
-        # launches of the last batch: a stage may have several launches per batch (k_pyr_resize x7, k_quadtree_flat per level)
+        # launches of the last batch: a stage may have several launches per batch (k_pyr_resize x7, k_qt_fast per level group)
         n_per_batch = max(1, len(ids) // 6)
         res[k] = sum(v[i] for i in ids[-n_per_batch:])
     return res

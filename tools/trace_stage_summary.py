@@ -6,7 +6,7 @@ N = sys.argv[2] if len(sys.argv) > 2 else "512"
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     name = r["Kernel_Name"].replace("void ydorb::", "").replace("ydorb::", "").split("(")[0]
-    full = N in (r["Grid_Size_Y"], r["Grid_Size_Z"]) or (name.startswith("k_quadtree_flat") and r["Grid_Size_X"] == str(int(N) * 512)) \
+    full = N in (r["Grid_Size_Y"], r["Grid_Size_Z"]) or (name.startswith("k_qt_fast") and r["Grid_Size_X"] == str(int(N) * 256)) \
         or (name in ("k_resolve", "k_grid_build") and r["Grid_Size_X"] in (str((int(N) - 1) * 64), str(int(N) * 256))) \
         or (name in ("k_gather_projection", "k_queries_from_keypoints") and r["Grid_Size_Y"] == str(int(N) - 1))
     if full and name.startswith("k_"):
