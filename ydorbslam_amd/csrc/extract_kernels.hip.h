@@ -707,16 +707,15 @@ struct QtWaveCtx {
 
 // dynamic LDS layout: [cc|geom0|geom1|childIdx|cnt0|cnt1|base0|base1] for nodeCap nodes, keys/cand[ldsCandCap] u32 x2,
 // node ids [ldsCandCap] u16 x2, cellBase[maxCells+1]
-__global__ __launch_bounds__(kQtThreads) void k_quadtree(PlanDev P, const uint32_t* __restrict__ cellCount,
-                                                 const uint32_t* __restrict__ cellCand, uint32_t* __restrict__ qtCand,
-                                                 uint16_t* __restrict__ qtNode, size_t qtFrameStride, int nodeCap, int ldsCandCap, int levelBase,
-                                                 uint32_t* __restrict__ lvlKp, int* __restrict__ lvlCount, int* __restrict__ status,
-                                                 const uint8_t* __restrict__ needPass, uint8_t* __restrict__ nodeScratch) {
+__device__ __forceinline__ void qt_pass_unit(const PlanDev& P, const uint32_t* __restrict__ cellCount,
+                                             const uint32_t* __restrict__ cellCand, uint32_t* __restrict__ qtCand,
+                                             uint16_t* __restrict__ qtNode, size_t qtFrameStride, int nodeCap, int ldsCandCap, int level, int f,
+                                             uint32_t* __restrict__ lvlKp, int* __restrict__ lvlCount, int* __restrict__ status,
+                                             uint8_t* __restrict__ nodeScratch) {
   extern __shared__ __align__(16) uint8_t smem[];
   __shared__ unsigned w32[16];
   __shared__ unsigned long long w64[16];
-  const int level = levelBase + blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
-  if (needPass && !needPass[f * kMaxLevels + level]) return;   // k_quadtree_flat already produced this unit
+  const int lane = threadIdx.x;
   const LevelDev L = P.lv[level];
   bool nodesInHbm = false;
   if (nodeCap <= 0) {   // one launch over all levels (-nodeCap = nodes the launch's LDS holds): each level derives its own table size
@@ -804,6 +803,30 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(PlanDev P, const uint32
   }
   if (lane == 0) lvlCount[f * kMaxLevels + level] = nOut;
 }
+// every unit of a level: grid (1, frames) per level (YDORB_QT_PASS=1, or levels whose quota is too large for k_qt_fast's LDS)
+__global__ __launch_bounds__(kQtThreads) void k_quadtree(PlanDev P, const uint32_t* __restrict__ cellCount,
+                                                 const uint32_t* __restrict__ cellCand, uint32_t* __restrict__ qtCand,
+                                                 uint16_t* __restrict__ qtNode, size_t qtFrameStride, int nodeCap, int ldsCandCap, int levelBase,
+                                                 uint32_t* __restrict__ lvlKp, int* __restrict__ lvlCount, int* __restrict__ status,
+                                                 uint8_t* __restrict__ nodeScratch) {
+  qt_pass_unit(P, cellCount, cellCand, qtCand, qtNode, qtFrameStride, nodeCap, ldsCandCap, levelBase + blockIdx.x, blockIdx.y, lvlKp, lvlCount, status, nodeScratch);
+}
+// the units k_qt_fast handed over (rare): a FEW workgroups walk the hand-over list.  (One workgroup per (frame, level) unit that leaves at
+// once when its unit was not handed over looked free - 4.5 us alone - but 8192 workgroups of 512 threads and ~40 KB of LDS queue behind the
+// other lanes' kernels: 2.7 ms on average in the four-lane pipeline, in front of the lane's descriptor kernel.)
+constexpr int kQtPassWorkgroups = 32;
+__global__ __launch_bounds__(kQtThreads) void k_quadtree_list(PlanDev P, const uint32_t* __restrict__ cellCount,
+                                                 const uint32_t* __restrict__ cellCand, uint32_t* __restrict__ qtCand,
+                                                 uint16_t* __restrict__ qtNode, size_t qtFrameStride, int nodeCap, uint32_t* __restrict__ lvlKp,
+                                                 int* __restrict__ lvlCount, int* __restrict__ status, const int* __restrict__ passCount,
+                                                 const int* __restrict__ passList, uint8_t* __restrict__ nodeScratch) {
+  const int n = *passCount;
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int unit = passList[i];
+    qt_pass_unit(P, cellCount, cellCand, qtCand, qtNode, qtFrameStride, nodeCap, 0, unit % kMaxLevels, unit / kMaxLevels, lvlKp, lvlCount, status, nodeScratch);
+    __syncthreads();
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Quad-tree thinning without passes and without a sort (closed form: quadtree_flat.h).  One 256-thread workgroup per (frame, level)
@@ -855,7 +878,8 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 template <int ITEMS>
 __global__ __launch_bounds__(kQfThreads) void k_qt_fast(PlanDev P, const uint32_t* __restrict__ cellCount, const uint32_t* __restrict__ cellCand,
                                                         int levelFirst, int quotaMax, int tabLen, uint32_t* __restrict__ lvlKp,
-                                                        int* __restrict__ lvlCount, uint8_t* __restrict__ needPass, int* __restrict__ lvlMaxN) {
+                                                        int* __restrict__ lvlCount, uint8_t* __restrict__ needPass, int* __restrict__ lvlMaxN,
+                                                        int* __restrict__ passCount, int* __restrict__ passList) {
   constexpr int NT = kQfThreads, CAP = NT * ITEMS, D = kQfDepth;
   extern __shared__ __align__(16) uint8_t smem[];
   __shared__ unsigned w32[4];
@@ -886,7 +910,7 @@ __global__ __launch_bounds__(kQfThreads) void k_qt_fast(PlanDev P, const uint32_
     *total = s0 + s1 + s2 + s3;
     return x - v + (wv > 0 ? s0 : 0u) + (wv > 1 ? s1 : 0u) + (wv > 2 ? s2 : 0u);
   };
-  auto give_up = [&]() { if (tid == 0) needPass[unit] = 1; };
+  auto give_up = [&]() { if (tid == 0) { needPass[unit] = 1; passList[atomicAdd(passCount, 1)] = unit; } };   // k_quadtree_list takes the unit
 
   // ---- 1. cell bases: the level's cells in (row, col) order == keyPointsToDistr (orbExtractor.cpp:584-590) ----------------------
   const int rootX1 = L.w - 2 * kBorder, rootY1 = L.h - 2 * kBorder;

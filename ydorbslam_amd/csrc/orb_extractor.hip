@@ -74,7 +74,8 @@ struct ydorb_extractor {
   uint32_t *d_cellCount = nullptr, *d_cellCand = nullptr, *d_qtCand = nullptr, *d_qtKeys = nullptr, *d_lvlKp = nullptr;
   uint16_t* d_qtNode = nullptr;
   uint8_t* d_nodeScratch = nullptr;  // HBM node tables of the levels whose quota does not fit the LDS (usually none)
-  uint8_t* d_needPass = nullptr;   // [frame][level]: 1 = the flat quad-tree kernel left the unit to the pass kernel
+  uint8_t* d_needPass = nullptr;   // [frame][level]: 1 = k_qt_fast left the unit to the pass kernel
+  int* d_passList = nullptr;       // [1 + frames * levels]: count, then the units k_qt_fast handed over in this call
   int *d_lvlCount = nullptr, *d_status = nullptr, *d_nOut = nullptr;
   uint8_t* h_pyr = nullptr;           // pinned staging of one frame's pyramid block (ydorb_extractor_read_pyramid)
   size_t h_pyrBytes = 0;
@@ -121,7 +122,7 @@ namespace {
 void freeBuffers(ydorb_extractor* e) {
   auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
   F(e->d_img); F(e->d_pyr); F(e->d_blur); F(e->d_cellCount); F(e->d_cellCand); F(e->d_qtCand); F(e->d_qtKeys);
-  F(e->d_lvlKp); F(e->d_qtNode); F(e->d_needPass); F(e->d_nodeScratch); F(e->d_lvlCount); F(e->d_lvlMaxN); F(e->d_status); F(e->d_nOut); F(e->d_lvlAngle); F(e->d_cells);
+  F(e->d_lvlKp); F(e->d_qtNode); F(e->d_needPass); F(e->d_passList); F(e->d_nodeScratch); F(e->d_lvlCount); F(e->d_lvlMaxN); F(e->d_status); F(e->d_nOut); F(e->d_lvlAngle); F(e->d_cells);
   F(e->d_tabInt); F(e->d_tabShort); F(e->d_padTab); F(e->d_colTab); F(e->d_rowTab); F(e->d_kps); F(e->d_desc);
   auto H = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
   H(e->h_img); H(e->h_kps); H(e->h_desc); H(e->h_nOut); H(e->h_status); H(e->h_lvlMaxN); H(e->h_pyr);
@@ -385,6 +386,8 @@ int ensurePlan(ydorb_extractor* e, int w, int h, int nFrames) {
   if (D.nodeTabFrameStride) HIPCHK(hipMalloc(&e->d_nodeScratch, (size_t)D.nodeTabFrameStride * B));
   HIPCHK(hipMalloc(&e->d_needPass, (size_t)kMaxLevels * B));
   HIPCHK(hipMemsetAsync(e->d_needPass, 0, (size_t)kMaxLevels * B, e->stream));
+  HIPCHK(hipMalloc(&e->d_passList, sizeof(int) * ((size_t)kMaxLevels * B + 1)));
+  HIPCHK(hipMemsetAsync(e->d_passList, 0, sizeof(int), e->stream));
 
   HIPCHK(hipMalloc(&e->d_lvlKp, sizeof(uint32_t) * (size_t)D.sumQuota * B));
   HIPCHK(hipMalloc(&e->d_lvlAngle, sizeof(float) * (size_t)D.sumQuota * B));
@@ -417,7 +420,10 @@ int ensurePlan(ydorb_extractor* e, int w, int h, int nFrames) {
   HIPCHK(hipMemsetAsync(e->d_status, 0, sizeof(int), e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   if (std::max(P.qtLdsMax, P.qtPassLds) > 48 * 1024)
+  {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(P.qtLdsMax, P.qtPassLds)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_list), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(P.qtLdsMax, P.qtPassLds)));
+  }
   {
     int qmax = 1, tabLen = 2;
     for (int l = 0; l < D.nLevels; l++) { qmax = std::max(qmax, D.lv[l].quota); tabLen = std::max(tabLen, std::max(D.lv[l].w - 2 * kBorder, 0) + std::max(D.lv[l].h - 2 * kBorder, 0) + 2); }
@@ -557,7 +563,7 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
     if (!e->forcePassQuadtree && lds <= 150 * 1024) {
       const dim3 grid(nFrames, l1 - l0);
 #define YD_QT_FAST(IT) hipLaunchKernelGGL(k_qt_fast<IT>, grid, dim3(kQfThreads), lds, qs, D, e->d_cellCount, e->d_cellCand, l0, qmax, tabLen, e->d_lvlKp, \
-                                          e->d_lvlCount, e->d_needPass, e->d_lvlMaxN)
+                                          e->d_lvlCount, e->d_needPass, e->d_lvlMaxN, e->d_passList, e->d_passList + 1)
       if (items <= 8) YD_QT_FAST(8);
       else if (items <= 16) YD_QT_FAST(16);
       else YD_QT_FAST(32);
@@ -567,15 +573,18 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
       for (int l = l0; l < l1; l++) {
         const HostPlan::QtLevel& Q = P.qt[l];
         hipLaunchKernelGGL(k_quadtree, dim3(1, nFrames), dim3(kQtThreads), Q.lds, qs, D, e->d_cellCount, e->d_cellCand, e->d_qtCand, e->d_qtNode,
-                           P.qtFrameStride, Q.nodeCap, Q.candCap, l, e->d_lvlKp, e->d_lvlCount, e->d_status, nullptr, e->d_nodeScratch);
+                           P.qtFrameStride, Q.nodeCap, Q.candCap, l, e->d_lvlKp, e->d_lvlCount, e->d_status, e->d_nodeScratch);
       }
     }
     if (!e->qtInline) HIPCHK(hipEventRecord(e->evJoin[g], qs));
   }
   if (!e->qtInline) for (int g = 0; g < nGroups; g++) HIPCHK(hipStreamWaitEvent(s, e->evJoin[g], 0));
-  if (anyFast)   // units k_qt_fast handed over (rare): node table in LDS, candidates in HBM scratch (candCap 0); all others exit at once
-    hipLaunchKernelGGL(k_quadtree, dim3(D.nLevels, nFrames), dim3(kQtThreads), P.qtPassLds, s, D, e->d_cellCount, e->d_cellCand, e->d_qtCand,
-                       e->d_qtNode, P.qtFrameStride, -std::max(P.qtPassNodes, 1), 0, 0, e->d_lvlKp, e->d_lvlCount, e->d_status, e->d_needPass, e->d_nodeScratch);
+  if (anyFast) {  // units k_qt_fast handed over (rare): node table in LDS, candidates in HBM scratch; the list's counter is cleared for the next call
+    hipLaunchKernelGGL(k_quadtree_list, dim3(std::min(kQtPassWorkgroups, D.nLevels * nFrames)), dim3(kQtThreads), P.qtPassLds, s, D, e->d_cellCount, e->d_cellCand,
+                       e->d_qtCand, e->d_qtNode, P.qtFrameStride, -std::max(P.qtPassNodes, 1), e->d_lvlKp, e->d_lvlCount, e->d_status, e->d_passList,
+                       e->d_passList + 1, e->d_nodeScratch);
+    HIPCHK(hipMemsetAsync(e->d_passList, 0, sizeof(int), s));
+  }
   if (prof) HIPCHK(hipEventRecord(e->ev[4], s));
   {
     const int kpw = e->descKpw;   // keypoints per wave (YDORB_DESC_KPW: 1, 2 or 4)
