@@ -19,6 +19,12 @@ for i in range(4):
     k, d = OrbExtractorOracle(1000, 1.2, 8, 20, 7).extract(img)
     np.savez_compressed(pathlib.Path(__file__).with_name("dbow3_image%d_orb.npz" % i), image=img, keypoints=k, descriptors=d)
     print("image%d: %d keypoints" % (i, len(k)))
+# the reference's own test images (test/data: other sizes than 640x480; gray conversion by Pillow, the pixels travel in the fixture)
+for name, path, nf in (("test_img1", "/root/reference/test/data/img1.png", 500), ("test_angles", "/root/reference/test/data/same-picture-different-angles.jpg", 1000)):
+    img = np.array(Image.open(path).convert("L"))
+    k, d = OrbExtractorOracle(nf, 1.2, 8, 20, 7).extract(img)
+    np.savez_compressed(pathlib.Path(__file__).with_name("ref_%s_orb.npz" % name), image=img, keypoints=k, descriptors=d, n_features=nf)
+    print("%s %s: %d keypoints" % (name, img.shape, len(k)))
 h = {}
 for (w, hh, nf, idx) in [(640, 480, 1000, 0), (752, 480, 1000, 1), (1241, 376, 2000, 2), (321, 243, 500, 3)]:
     kk, dd = OrbExtractorOracle(nf, 1.2, 8, 20, 7).extract(synth_frame(w, hh, idx))

@@ -125,6 +125,17 @@ def test_real_images_match_the_committed_goldens(batched):
         assert np.array_equal(d, g["descriptors"]), i
 
 
+@pytest.mark.parametrize("name", ["test_img1", "test_angles"])
+def test_reference_test_images_match_the_committed_goldens(name):
+    """The reference's own test images (test/data: 318x476 and 650x476) through the HIP path against the committed oracle outputs."""
+    import os
+    import ydorbslam_amd as y
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_%s_orb.npz" % name))
+    k, d = y.OrbExtractor(int(g["n_features"]), 1.2, 8, 20, 7).extract(np.ascontiguousarray(g["image"]))
+    _same_kps(k, g["keypoints"])
+    assert np.array_equal(d, g["descriptors"])
+
+
 def test_quadtree_flat_and_pass_kernels_agree(oracle_lib, monkeypatch):
     """The thinning has two device forms: the rank one (k_qt_fast: histogram pyramid, list positions from one scan, per-node maxima,
     quadtree_flat.h) and the pass one (quadtree_core.h, taken for units the rank form hands over).  Both must give the

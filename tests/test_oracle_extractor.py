@@ -23,6 +23,15 @@ def test_golden_real_image(oracle_lib, idx):
     assert np.array_equal(d, g["descriptors"])
 
 
+@pytest.mark.parametrize("name", ["test_img1", "test_angles"])
+def test_golden_reference_test_images(oracle_lib, name):
+    """The reference's own test images (test/data/img1.png 318x476, same-picture-different-angles.jpg 650x476): committed oracle outputs
+    at sizes other than 640x480."""
+    g = np.load(os.path.join(HERE, "golden", "ref_%s_orb.npz" % name))
+    k, d = oracle_lib.OrbExtractorOracle(int(g["n_features"]), 1.2, 8, 20, 7).extract(g["image"])
+    assert k.tobytes() == g["keypoints"].tobytes() and np.array_equal(d, g["descriptors"])
+
+
 def test_golden_synthetic_hashes(oracle_lib):
     h = json.load(open(os.path.join(HERE, "golden", "synthetic_orb_hashes.json")))
     w, hh, nf, idx = 321, 243, 500, 3
