@@ -450,7 +450,7 @@ constexpr int kResolveWindow = 2048;  // queries whose (base,count) are staged i
 
 __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ calls, const FrameDev* __restrict__ frames,
                                                 const uint32_t* __restrict__ pool, int takenWords) {
-  extern __shared__ unsigned takenBits[];  // [takenWords]
+  extern __shared__ unsigned takenBits[];  // [takenWords], then claimBits [takenWords] (the group-parallel replay's scratch)
   __shared__ int hist[kHistLen];
   __shared__ int3 live[kResolveWindow];    // (query, pool base, record count) of the window's non-empty queries, in order
   __shared__ uint2 livePre[kResolveWindow]; // their pre-computed (best, second) records (projection family; see CallDev::qPre)
@@ -476,6 +476,7 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
   const auto gQueries = G(C.queries);
   const auto gQAngle = G(C.qAngle);
   const int n = takenWords * 32;
+  unsigned* claimBits = takenBits + takenWords;
   for (int w = lane; w < takenWords; w += 64) {
     unsigned bits = 0;
     for (int b = 0; b < 32; b++) {
@@ -483,6 +484,7 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
       if (C.taken && i < n && gTaken[i]) bits |= 1u << b;
     }
     takenBits[w] = bits;
+    claimBits[w] = 0;
   }
   if (lane < kHistLen) hist[lane] = 0;
   for (int q = lane; q < nq; q += 64) gMatchQ[q] = -1;
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
     const bool needSecond = C.mode == 0;
     unsigned recNext = 0;
     if (!havePre && nLive > 0 && lane < live[0].z) recNext = pool[live[0].y + lane];
-    for (int e = 0; e < nLive; e++) {
+    auto serial_one = [&](int e) {
       const int3 L3 = live[e];
       const int q = L3.x & 0x3FFFFFFF;
       const bool qObs = (L3.x >> 30) & 1;
@@ -592,6 +594,91 @@ __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ call
           }
           // (one wave per call: LDS accesses of a wave are ordered, so the next query sees the bit; no barrier and no wait for the stores)
           __builtin_amdgcn_wave_barrier();
+        }
+      }
+    };
+    if (!havePre) {
+      for (int e = 0; e < nLive; e++) serial_one(e);
+    } else {
+      // With the gather kernel's (best, second) records a query's outcome is known without looking at any other query - unless an
+      // earlier query of the replay takes (or is assigned) the keypoint one of its records names.  So the queries go 64 at a time, one
+      // per lane, and every lane decides from its own records.
+      //  * Modes whose acceptance is `best distance within a bound` alone (1, 2, 6, 7): losing candidates can only RAISE a query's best
+      //    distance, so a query whose pre-computed best fails stays rejected whatever the others take - it is inert.  Of the accepting
+      //    lanes, the first one whose keypoint is already taken or is also the keypoint of a LOWER accepting lane is the first whose
+      //    outcome depends on the order: the lanes below it are committed in one step, that one query is replayed by the serial form
+      //    (which defines the result), and the rest of the group is looked at again.
+      //  * The other modes (ratio / level tests on the second-best record): the group is committed in one step when no record names a
+      //    keypoint taken before the group or claimed by another lane, else replayed in order.
+      // ~120 of 1000 queries accept anything: a dozen steps per group of 64 at worst instead of a 1000-step chain per frame pair.
+      const bool monotone = C.mode == 1 || C.mode == 2 || C.mode == 6 || C.mode == 7;
+      for (int g0 = 0; g0 < nLive; g0 += 64) {
+        const int e = g0 + lane;
+        const bool in = e < nLive;
+        const int3 L3 = in ? live[e] : make_int3(0, 0, 0);
+        const uint2 pr = in ? livePre[e] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        const bool has1 = pr.x != 0xFFFFFFFFu, has2 = pr.y != 0xFFFFFFFFu;
+        const unsigned i1 = pr.x & 0xFFFFu, i2 = pr.y & 0xFFFFu;
+        bool would = false;              // the outcome if no other query interfered
+        if (has1) {
+          const int bestDist = (int)(pr.x >> 16), secondDist = has2 ? (int)(pr.y >> 16) : 256;
+          if (C.mode == 0) {
+            const int bestLevel = kps[i1].octave, secondLevel = has2 ? kps[i2].octave : -1;
+            would = bestDist <= kThHigh && (bestLevel != secondLevel || (float)bestDist <= __fmul_rn(C.ratio, (float)secondDist));
+          } else if (C.mode == 1) would = bestDist < kThHigh;
+          else if (C.mode == 2) would = bestDist <= C.orbDist;
+          else if (C.mode == 5) would = true;
+          else if (C.mode == 6) would = bestDist <= C.orbDist;
+          else if (C.mode == 7) would = bestDist <= kThLow;
+          else would = bestDist <= kThLow && (float)bestDist < __fmul_rn(C.ratio, (float)secondDist);
+        }
+        auto commit = [&](bool mine) {     // the accepted queries of `mine` lanes: assignment, taken bit, match list
+          matchNum += __popcll(__ballot(mine));
+          if (mine) {
+            const int q = L3.x & 0x3FFFFFFF;
+            const bool qObs = (L3.x >> 30) & 1;
+            if (C.mode == 4 || C.mode == 5) gAssigned[q] = (int)i1;
+            else gAssigned[i1] = q;
+            const bool nowTaken = C.mode == 6 ? false : C.mode >= 2 ? true : qObs;
+            if (nowTaken) atomicOr(&takenBits[i1 >> 5], 1u << (i1 & 31u));
+            gMatchQ[q] = (int)i1;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+        };
+        if (monotone) {
+          int first = 0;                   // lanes below `first` are settled
+          while (true) {
+            const bool acc = would && lane >= first;
+            bool conflict = acc && ((takenBits[i1 >> 5] >> (i1 & 31u)) & 1u);
+            for (unsigned long long rem = __ballot(acc); rem; rem &= rem - 1ull) {   // the same keypoint on a lower accepting lane
+              const int a = __ffsll((long long)rem) - 1;
+              const unsigned ia = (unsigned)__builtin_amdgcn_readlane((int)i1, a);
+              conflict = conflict || (acc && lane > a && i1 == ia);
+            }
+            const unsigned long long cm = __ballot(conflict);
+            const int c = cm ? __ffsll((long long)cm) - 1 : 64;
+            commit(acc && lane < c);
+            if (c == 64) break;
+            serial_one(g0 + c);
+            first = c + 1;
+          }
+        } else {
+          const bool stale = (has1 && ((takenBits[i1 >> 5] >> (i1 & 31u)) & 1u)) || (needSecond && has2 && ((takenBits[i2 >> 5] >> (i2 & 31u)) & 1u));
+          const bool accept = would && !stale;
+          bool conflict = stale;
+          if (accept) conflict = conflict || ((atomicOr(&claimBits[i1 >> 5], 1u << (i1 & 31u)) >> (i1 & 31u)) & 1u);   // two accepted queries, one keypoint
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+          if (has1 && !accept) conflict = conflict || ((claimBits[i1 >> 5] >> (i1 & 31u)) & 1u);                        // its best keypoint goes to another query
+          if (needSecond && has2) conflict = conflict || ((claimBits[i2 >> 5] >> (i2 & 31u)) & 1u);                      // its second keypoint goes to another query
+          const bool redo = __ballot(conflict) != 0ull;
+          __builtin_amdgcn_wave_barrier();
+          if (accept) atomicAnd(&claimBits[i1 >> 5], ~(1u << (i1 & 31u)));
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+          if (redo) for (int e2 = g0; e2 < min(g0 + 64, nLive); e2++) serial_one(e2);
+          else commit(accept);
         }
       }
     }

@@ -264,7 +264,7 @@ static int searchProjectionImpl(ydorb_matcher_t* m, int32_t mode, const YdFrameV
     int hmisc[3];
     if (!recordsOut) {
       const int takenWords = (n + 31) / 32;
-      hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), sizeof(unsigned) * takenWords, m->stream, m->calls.as<CallDev>(), m->frames.as<FrameDev>(),
+      hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), 2 * sizeof(unsigned) * takenWords, m->stream, m->calls.as<CallDev>(), m->frames.as<FrameDev>(),
                          m->pool.as<uint32_t>(), takenWords);
     }
     HIPCHK(hipGetLastError());
@@ -413,7 +413,7 @@ int ydorb_search_by_bow(ydorb_matcher_t* m, int32_t mode, const YdBowSide* A, co
   C.count = m->misc.as<int>() + 2; C.mode = mode; C.ratio = ratio; C.orbDist = 0; C.checkOri = checkOri;
   HIPCHK(hipMemcpyAsync(m->calls.p, &C, sizeof(CallDev), hipMemcpyHostToDevice, m->stream));
   const int takenWords = (B->n + 31) / 32;
-  hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), sizeof(unsigned) * takenWords, m->stream, m->calls.as<CallDev>(), (const FrameDev*)nullptr,
+  hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), 2 * sizeof(unsigned) * takenWords, m->stream, m->calls.as<CallDev>(), (const FrameDev*)nullptr,
                      m->pool.as<uint32_t>(), takenWords);
   HIPCHK(hipGetLastError());
   int hmisc[3];
@@ -514,7 +514,7 @@ int ydorb_search_for_triangulation(ydorb_matcher_t* m, const YdTriSide* A, const
   C.count = m->misc.as<int>() + 2; C.mode = 5; C.ratio = 0.f; C.orbDist = 0; C.checkOri = checkOri;
   HIPCHK(hipMemcpyAsync(m->calls.p, &C, sizeof(CallDev), hipMemcpyHostToDevice, m->stream));
   const int takenWords = (B->n + 31) / 32;
-  hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), sizeof(unsigned) * takenWords, m->stream, m->calls.as<CallDev>(), (const FrameDev*)nullptr,
+  hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), 2 * sizeof(unsigned) * takenWords, m->stream, m->calls.as<CallDev>(), (const FrameDev*)nullptr,
                      m->pool.as<uint32_t>(), takenWords);
   HIPCHK(hipGetLastError());
   int hmisc[3];
@@ -729,7 +729,7 @@ int ydorb_match_pairs_device(ydorb_matcher_t* m, const YdFrameSetDev* Q, const Y
                      m->pool.as<uint32_t>(), m->heads.as<unsigned>(), (unsigned)poolPerCall, m->misc.as<int>() + 1);
   if (prof) HIPCHK(hipEventRecord(m->ev[2], s));
   const int takenWords = (cap + 31) / 32;
-  hipLaunchKernelGGL(k_resolve, dim3(nCalls), dim3(64), sizeof(unsigned) * takenWords, s, m->calls.as<CallDev>(), m->frames.as<FrameDev>(),
+  hipLaunchKernelGGL(k_resolve, dim3(nCalls), dim3(64), 2 * sizeof(unsigned) * takenWords, s, m->calls.as<CallDev>(), m->frames.as<FrameDev>(),
                      m->pool.as<uint32_t>(), takenWords);
   if (prof) { HIPCHK(hipEventRecord(m->ev[3], s)); m->evPending = true; }
   HIPCHK(hipGetLastError());
