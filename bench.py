@@ -14,7 +14,7 @@ and SURVEY.md 8(d) times "the batch incl. H2D/D2H".  So the headline `value` is 
 `kernel_pipeline` is the same work with the frames already resident in HBM and the results left there (what rounds 1-2 reported as
 `value`), `pcie` is the measured host link next to it, `roofline` the dominant kernel against the HBM roof.
 
-One "step" = --substeps launches of --frames frames each (default 12 x 1024 = 12288 frames), dealt to four lanes in turn; the timed
+One "step" = --substeps launches of --frames frames each (default 16 x 1024 = 16384 frames), dealt to four lanes in turn; the timed
 region is exactly --steps steps, bracketed by barrier + synchronize, and it is repeated --repeats times: `value` is the median,
 `repeats` holds min / max.
 
@@ -261,6 +261,9 @@ class MonoStream:
     # on RCCL's internal stream and the lane waits for it).  One more stream means the lanes share hardware queues again: with an RCCL
     # process group at world size 1 on one GPU, 94 against 146 Mkeypoints/s inclusive (tools/rehearse_multigpu.sh) - off by default.
     COMM_STREAM = bool(int(os.environ.get("YDORB_BENCH_COMM_STREAM", "0")))
+    # Uploads on ONE stream of their own, queued back to back into a ring of LANES + 2 image buffers (a lane waits for its frames' event, the
+    # stream for the buffer's release event); read-backs stay in the lane.  With YDORB_BENCH_LANES=3 that is four streams again.
+    UPLOAD_STREAM = bool(int(os.environ.get("YDORB_BENCH_UPLOAD_STREAM", "0")))
 
     def __init__(self, ctx, y, exchange=None):
         import numpy as np
@@ -284,6 +287,7 @@ class MonoStream:
         # streams onto them in creation order (profiles/r02d_queue_overlap.txt).
         self.lane_streams = [torch.cuda.Stream(device=dev) for _ in range(self.LANES)]
         self.s_comm = torch.cuda.Stream(device=dev) if ctx.distributed and self.COMM_STREAM else None
+        self.s_up = torch.cuda.Stream(device=dev) if self.UPLOAD_STREAM else None
         self.exs = [y.OrbExtractor(self.NFEAT, 1.2, 8, 20, 7, device=ctx.local_rank, max_batch=F, single_stream=self.SINGLE) for _ in range(self.LANES)]
         self.cap = cap = self.exs[0].max_keypoints
         self.sf = self.exs[0].tables()["scale"]
@@ -320,7 +324,9 @@ class MonoStream:
         self.mts = [y.OrbMatcher(0.9, True, device=ctx.local_rank) for _ in range(NSET)]   # one matcher (own scratch) per output set
         # host side of the inclusive pipeline: pinned frames, one device image buffer per lane, pinned result sets
         self.h_img = torch.from_numpy(self.imgs).pin_memory()
-        self.d_img = [torch.empty_like(self.h_img, device=dev) for _ in range(self.LANES)]
+        self.NIMG = self.LANES + 2 if self.UPLOAD_STREAM else self.LANES      # upload stream: a ring it may run two launches ahead in
+        self.d_img = [torch.empty_like(self.h_img, device=dev) for _ in range(self.NIMG)]
+        self.ev_in, self.ev_free = [torch.cuda.Event() for _ in range(self.NIMG)], [None] * self.NIMG
         self.d_img[0].copy_(self.h_img)
         self.h_out = [[torch.zeros_like(t, device="cpu").pin_memory() for t in (self.own[b], self.d_assigned[b], self.d_counts[b])] for b in range(NSET)]
         ev = lambda n_: [torch.cuda.Event() for _ in range(n_)]
@@ -383,12 +389,24 @@ class MonoStream:
         self.k += 1
         lane = b = k % self.LANES
         sA = self.lane_streams[lane]
-        img = self.d_img[lane if inclusive else 0]
-        if inclusive:
+        r = k % self.NIMG if self.s_up is not None else lane
+        img = self.d_img[r if inclusive else 0]
+        if inclusive and self.s_up is not None:   # uploads queue back to back on their own stream; a lane waits for its frames only
+            if self.ev_free[r] is not None:
+                self.s_up.wait_event(self.ev_free[r])
+            with torch.cuda.stream(self.s_up):
+                img.copy_(self.h_img, non_blocking=True)
+            self.ev_in[r].record(self.s_up)
+            sA.wait_event(self.ev_in[r])
+        elif inclusive:
             with torch.cuda.stream(sA):
                 img.copy_(self.h_img, non_blocking=True)
         own = self.ptrs(b, self.ctx.rank)
         self.exs[lane].extract_batch_device(img.data_ptr(), W, H, W, W * H, F, own[0], own[1], self.cap, own[2], sA.cuda_stream)
+        if inclusive and self.s_up is not None:
+            if self.ev_free[r] is None:
+                self.ev_free[r] = torch.cuda.Event()
+            self.ev_free[r].record(sA)
         if not match:
             return
         if self.ctx.distributed:
@@ -908,7 +926,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=10, help="timed regions of exactly --steps steps each; value = median")
     ap.add_argument("--frames", type=int, default=1024, help="frames per launch and per GPU (measured, inclusive / resident Mkeypoints/s: 256 frames 142 / 214, "
                                                             "512 frames 163 / 213, 1024 frames 174 / 209: longer uploads keep the link busier)")
-    ap.add_argument("--substeps", type=int, default=12, help="launches per step (a step = substeps x frames frames: 20 steps are then a timed region of > 1 s)")
+    ap.add_argument("--substeps", type=int, default=16, help="launches per step (a step = substeps x frames frames: 20 steps are then a timed region of > 1 s)")
     ap.add_argument("--region-s", type=float, default=1.0, help="target length of the timed regions of the config 3 / config 4 sections")
     ap.add_argument("--segment", type=int, default=64, help="frames per synthetic scene (a new scene is a cut)")
     ap.add_argument("--exchange", choices=("allgather", "ring", "neighbour"), default="allgather",
