@@ -14,7 +14,8 @@ and SURVEY.md 8(d) times "the batch incl. H2D/D2H".  So the headline `value` is 
 `kernel_pipeline` is the same work with the frames already resident in HBM and the results left there (what rounds 1-2 reported as
 `value`), `pcie` is the measured host link next to it, `roofline` the dominant kernel against the HBM roof.
 
-One "step" = --substeps launches of --frames frames each (default 16 x 1024 = 16384 frames), dealt to four lanes in turn; the timed
+One "step" = --substeps launches of --frames frames each (default 16 x 1024 = 16384 frames), dealt to the lanes in turn (inclusive: three lanes + one
+stream that only uploads; resident: four lanes); the timed
 region is exactly --steps steps, bracketed by barrier + synchronize, and it is repeated --repeats times: `value` is the median,
 `repeats` holds min / max.
 
@@ -99,10 +100,32 @@ def cpu_info():
     return model, os.cpu_count() or 1, usable
 
 
+def prefer_image_rocm():
+    """libydorb.so is built against the image's ROCm (/opt/rocm, what a C++ host of the reference links), but a process that imports torch first
+    runs on the HIP / ROCr runtime bundled in the PyTorch wheel (torch/lib, an older release): same sonames, first one loaded wins.  Under the
+    bundled runtime an upload and a read-back in flight together slow each other (tools/ubench/duplex_runtimes.sh: 256 MB up + 64 MB down
+    52.7 + 13.2 GB/s against 57.0 + 14.2 on the image's runtime; torch copies both ways 28.5 + 28.5 against 48.5 + 48.5).  So the bench loads
+    the image's runtime before torch (YDORB_BENCH_SYSTEM_ROCM=0: leave the order alone).  Returns what was loaded, for the JSON line."""
+    if os.environ.get("YDORB_BENCH_SYSTEM_ROCM", "1") != "1" or "torch" in sys.modules:
+        return None
+    import ctypes
+    root = os.environ.get("ROCM_PATH", "/opt/rocm")
+    libs = [os.path.join(root, "lib", n) for n in ("libhsa-runtime64.so.1", "libamdhip64.so.7")]
+    if not all(os.path.exists(l_) for l_ in libs):
+        return None
+    try:
+        for l_ in libs:
+            ctypes.CDLL(l_, mode=ctypes.RTLD_GLOBAL)
+    except OSError:
+        return None
+    return os.path.realpath(libs[1])
+
+
 class Ctx:
     """Process-wide state: arguments, rank / world, device, the collectives (RCCL, or gloo staged through the host for rehearsals)."""
 
     def __init__(self, args):
+        self.hip_runtime = prefer_image_rocm()
         import torch
         import torch.distributed as dist
         self.args, self.torch, self.dist = args, torch, dist
@@ -191,8 +214,9 @@ def stats(per_repeat):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
-# Host link: pinned hipMemcpyAsync H2D, D2H and both at once.  The two directions SHARE the link's rate on this platform (H2D || D2H
-# gives half the one-way rate each), so the roof of a pipeline that moves `in` + `out` bytes per step is (in + out) / peak.
+# Host link: pinned hipMemcpyAsync H2D, D2H and both at once.  The link is full duplex (tools/ubench/duplex.hip: 48.5 GB/s each way together,
+# 57 + 14 for an upload with a quarter-size read-back) - on the image's ROCm runtime; under the runtime bundled with PyTorch the two directions
+# slow each other (28.5 each from torch copies), see prefer_image_rocm().  The pipeline's roof is its upload bytes / the one-way rate.
 # ---------------------------------------------------------------------------------------------------------------------------------
 def pcie_link(ctx, mb=160, reps=5):
     torch = ctx.torch
@@ -237,10 +261,9 @@ def pcie_link(ctx, mb=160, reps=5):
     torch.cuda.synchronize()
     r["mixed_5to1_GBps"] = (2 * n + 2 * n5) * reps / (time.perf_counter() - t0) / 1e9
     r["peak_GBps"] = max(r["h2d_GBps"], r["d2h_GBps"])
-    r["note"] = ("pinned hipMemcpyAsync of %d MB, this process on this box; peak_GBps = the better one-way rate.  h2d_plus_d2h (one stream per direction, "
-                 "sum of both) and mixed_5to1 (two uploads + read-backs of a fifth of the bytes) come out at the one-way rate in this microbenchmark, "
-                 "yet the pipeline's four lanes sustain uploads near peak WITH their read-backs beside them: the link is full duplex, the microbenchmark's "
-                 "two-stream form is not" % mb)
+    r["note"] = ("pinned hipMemcpyAsync of %d MB, this process on this box; peak_GBps = the better one-way rate; h2d_plus_d2h = one stream per direction, "
+                 "sum of both; mixed_5to1 = two uploads + read-backs of a fifth of the bytes, sum.  Both exceed the one-way rate only on the image's "
+                 "ROCm runtime (config.hip_runtime): the link is full duplex, the runtime bundled with PyTorch serialises the two directions" % mb)
     del h_a, h_b, d_a, d_b
     return r
 
@@ -251,19 +274,23 @@ def pcie_link(ctx, mb=160, reps=5):
 class MonoStream:
     W, H, NFEAT = 640, 480, 1000
     LANES = int(os.environ.get("YDORB_BENCH_LANES", "4"))
-    # single-stream handles (YDORB_EXTRACTOR_SINGLE_STREAM: quad-tree launches on the lane's stream): the device runs 4 hardware queues, so 4 lanes
-    # of one stream each keep every lane on its own queue; handles with side streams share queues with the copies and with each other.  The
-    # uploads and read-backs of the inclusive pipeline run on the lane's own stream (upload, kernels, read-back in stream order: no copy
-    # streams, no events - the other lanes' kernels run beside a lane's copies).  Measured, inclusive / resident Mkeypoints/s
-    # (tools/bench_copy_sweep.sh): 4 lanes single-stream 151 / 199, 2 lanes with side streams 93 / 194, copy-in / copy-out streams + 2 lanes 140 / 197.
+    # single-stream handles (YDORB_EXTRACTOR_SINGLE_STREAM: quad-tree launches on the lane's stream): the device runs 4 hardware queues, so 4
+    # streams keep every lane on its own queue; handles with side streams share queues with the copies and with each other.  Resident
+    # figures (kernel_pipeline, extract_only): 4 lanes of one stream each take consecutive launches.  Inclusive pipeline: see UPLOAD_STREAM.
+    # Measured, inclusive / resident Mkeypoints/s (tools/bench_copy_sweep.sh, 512 frames per launch): 2 lanes with side-stream handles 93 /
+    # 194, copy-in / copy-out streams + 2 single-stream lanes 140 / 197, 4 single-stream lanes with the copies in the lane 151 / 199.
     SINGLE = bool(int(os.environ.get("YDORB_BENCH_SINGLE_STREAM", "1")))
     # N > 1: the exchange on a communication stream of the bench's own (1), or issued from the lane's stream (0: the collective itself still runs
     # on RCCL's internal stream and the lane waits for it).  One more stream means the lanes share hardware queues again: with an RCCL
     # process group at world size 1 on one GPU, 94 against 146 Mkeypoints/s inclusive (tools/rehearse_multigpu.sh) - off by default.
     COMM_STREAM = bool(int(os.environ.get("YDORB_BENCH_COMM_STREAM", "0")))
-    # Uploads on ONE stream of their own, queued back to back into a ring of LANES + 2 image buffers (a lane waits for its frames' event, the
-    # stream for the buffer's release event); read-backs stay in the lane.  With YDORB_BENCH_LANES=3 that is four streams again.
-    UPLOAD_STREAM = bool(int(os.environ.get("YDORB_BENCH_UPLOAD_STREAM", "0")))
+    # Inclusive pipeline, 1 (default): the LAST lane's stream carries nothing but the uploads, queued back to back into a ring of image buffers
+    # (the link is the bottleneck of the inclusive figure: it must never wait for a lane), the other lanes take the launches - a lane waits
+    # for its frames' event, the upload stream for the buffer's release event - and read back in their own stream order.  0: every lane
+    # uploads its own frames in stream order (no events; the link idles whenever no lane is in its upload phase).  Same box, alternating
+    # (tools/bench_upload_ab.sh, image ROCm runtime): 172.7 / 175.3 against 165.7 / 162.1 Mkeypoints/s; a FIFTH stream for the uploads
+    # shares a hardware queue with a lane: 121 - 138.
+    UPLOAD_STREAM = bool(int(os.environ.get("YDORB_BENCH_UPLOAD_STREAM", "1")))
 
     def __init__(self, ctx, y, exchange=None):
         import numpy as np
@@ -287,7 +314,8 @@ class MonoStream:
         # streams onto them in creation order (profiles/r02d_queue_overlap.txt).
         self.lane_streams = [torch.cuda.Stream(device=dev) for _ in range(self.LANES)]
         self.s_comm = torch.cuda.Stream(device=dev) if ctx.distributed and self.COMM_STREAM else None
-        self.s_up = torch.cuda.Stream(device=dev) if self.UPLOAD_STREAM else None
+        self.s_up = self.lane_streams[-1] if self.UPLOAD_STREAM and self.LANES >= 2 else None
+        self.INC_LANES = self.LANES - 1 if self.s_up is not None else self.LANES   # lanes that take the inclusive pipeline's launches
         self.exs = [y.OrbExtractor(self.NFEAT, 1.2, 8, 20, 7, device=ctx.local_rank, max_batch=F, single_stream=self.SINGLE) for _ in range(self.LANES)]
         self.cap = cap = self.exs[0].max_keypoints
         self.sf = self.exs[0].tables()["scale"]
@@ -324,7 +352,7 @@ class MonoStream:
         self.mts = [y.OrbMatcher(0.9, True, device=ctx.local_rank) for _ in range(NSET)]   # one matcher (own scratch) per output set
         # host side of the inclusive pipeline: pinned frames, one device image buffer per lane, pinned result sets
         self.h_img = torch.from_numpy(self.imgs).pin_memory()
-        self.NIMG = self.LANES + 2 if self.UPLOAD_STREAM else self.LANES      # upload stream: a ring it may run two launches ahead in
+        self.NIMG = self.INC_LANES + 2 if self.s_up is not None else self.LANES      # upload stream: a ring it may run two launches ahead in
         self.d_img = [torch.empty_like(self.h_img, device=dev) for _ in range(self.NIMG)]
         self.ev_in, self.ev_free = [torch.cuda.Event() for _ in range(self.NIMG)], [None] * self.NIMG
         self.d_img[0].copy_(self.h_img)
@@ -332,6 +360,7 @@ class MonoStream:
         ev = lambda n_: [torch.cuda.Event() for _ in range(n_)]
         self.ev_x, self.ev_g = ev(NSET), ev(NSET)
         self.k = 0
+        self.up_trace = [] if self.s_up is not None and os.environ.get("YDORB_BENCH_UPLOAD_TRACE") else None   # diagnostic: (start, end) events of every upload
         self.bytes_in = F * W * H
         self.bytes_out = sum(t.numel() * t.element_size() for t in self.h_out[0])
 
@@ -387,7 +416,7 @@ class MonoStream:
         torch, W, H, F = self.ctx.torch, self.W, self.H, self.F
         k = self.k
         self.k += 1
-        lane = b = k % self.LANES
+        lane = b = k % (self.INC_LANES if inclusive else self.LANES)
         sA = self.lane_streams[lane]
         r = k % self.NIMG if self.s_up is not None else lane
         img = self.d_img[r if inclusive else 0]
@@ -395,7 +424,13 @@ class MonoStream:
             if self.ev_free[r] is not None:
                 self.s_up.wait_event(self.ev_free[r])
             with torch.cuda.stream(self.s_up):
+                if self.up_trace is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.s_up)
                 img.copy_(self.h_img, non_blocking=True)
+                if self.up_trace is not None:
+                    e1.record(self.s_up)
+                    self.up_trace.append((e0, e1))
             self.ev_in[r].record(self.s_up)
             sA.wait_event(self.ev_in[r])
         elif inclusive:
@@ -521,6 +556,14 @@ def mono_section(ctx, y, link):
     # ---- the contract's number: H2D/D2H-inclusive, exactly --steps steps per timed region -----------------------------------------
     t_inc = ctx.timed(lambda: S.step(True), args.steps, args.warmup, args.repeats)
     S.synchronize()
+    if S.up_trace:   # diagnostic (YDORB_BENCH_UPLOAD_TRACE): duration of the uploads and the gaps between consecutive ones, last region
+        tr = S.up_trace[-launches:]
+        dur = [a_.elapsed_time(b_) for a_, b_ in tr]
+        gap = [tr[i][1].elapsed_time(tr[i + 1][0]) for i in range(len(tr) - 1)]
+        q = lambda v, f: sorted(v)[int(f * (len(v) - 1))]
+        sys.stderr.write("upload trace: %d uploads, duration ms min %.2f median %.2f p90 %.2f max %.2f; gap ms median %.3f p90 %.3f max %.3f; sum dur %.1f sum gap %.1f\n"
+                         % (len(tr), min(dur), q(dur, .5), q(dur, .9), max(dur), q(gap, .5), q(gap, .9), max(gap), sum(dur), sum(gap)))
+        S.up_trace = None
     kp_local = int(S.counts(0, host=True).sum().item())   # from the pinned host copy the pipeline delivered
     matched_local = int(S.h_out[0][2].sum().item())
     if kp_local != int(S.counts(0).sum().item()) or kp_local <= 0:
@@ -608,15 +651,20 @@ def mono_section(ctx, y, link):
                                   "pinned host frames in, results back in pinned host memory",
                       "frames_per_step_per_gpu": F * args.substeps, "frames_per_launch": F, "launches_per_step": args.substeps,
                       "distinct_frames": F * world, "frames_per_scene": args.segment,
-                      "pipelining": "%d lanes (extractor handle + matcher + image buffer + output set + ONE stream each) take consecutive launches: upload, "
-                                    "extraction, matching and read-back of a launch in its lane's stream order, the lanes overlap each other" % S.LANES,
+                      "pipelining": ("%d lanes (extractor handle + matcher + output set + ONE stream each) take consecutive launches: extraction, matching and "
+                                     "read-back of a launch in its lane's stream order; the uploads run back to back on a stream of their own (the 4th "
+                                     "hardware queue) into a ring of %d image buffers, a lane waits for its frames' event only.  kernel_pipeline / "
+                                     "extract_only: %d lanes, no copies" % (S.INC_LANES, S.NIMG, S.LANES)) if S.s_up is not None else
+                                    ("%d lanes (extractor handle + matcher + image buffer + output set + ONE stream each) take consecutive launches: upload, "
+                                     "extraction, matching and read-back of a launch in its lane's stream order, the lanes overlap each other" % S.LANES),
                       "motion": "per frame: roll within +-3 deg, shift within +-8 px (bounded walk); prediction = true motion + N(0,1.5^2) px on the translation",
                       "keypoints_per_frame": kp_local / F, "matches_per_pair": matched_local / max(S.NPAIR, 1),
                       "matches_note": "what the reference's rules accept: ~770 of 1000 keypoints of a frame re-appear within 2.5 px x scale in the next one "
                                       "(median Hamming distance 35), but Frame::getKeyPointsInArea keeps only candidates with |dx| > r inside the "
                                       "window's grid cells (frame.cpp:353, reproduced bit for bit) and the rotation histogram uses the factor 1/30 "
                                       "(orbMatcher.cpp:78): ~120 pass the distance test, ~50 the rotation check",
-                      "parallelism": par},
+                      "parallelism": par,
+                      "hip_runtime": ctx.hip_runtime or "the one bundled with PyTorch (torch/lib)"},
            "kernel_pipeline": {"value": res["median"], "unit": "Mkeypoints/s", "ms_per_step": dt_res / args.steps * 1e3, "min": res["min"], "max": res["max"],
                                "n": res["n"], "timed_region_s": dt_res,
                                "note": "frames resident in HBM, results left in HBM; the same launches, lanes and streams without the copies"},
@@ -663,14 +711,25 @@ def stereo_config(ctx, y, link, w, h, nf, n_pairs, label, repeats, tile_default=
     # lanes.  The handles are single-stream (YDORB_EXTRACTOR_SINGLE_STREAM): with side streams, 5+ streams share the device's 4 hardware
     # queues and a stream that lands behind a chain stalls.
     NSETS = int(os.environ.get("YDORB_BENCH_STEREO_SETS", "4"))
-    in_lane = os.environ.get("YDORB_BENCH_COPY", "lane") == "lane"   # uploads and read-backs on the lane's own stream (see MonoStream.COPY)
-    RING = NSETS if in_lane else NSETS + 1
+    # YDORB_BENCH_COPY: "lane" (default) = every lane uploads its own pairs in stream order; "upload" = the last lane's stream only uploads, back
+    # to back into a ring of image pairs, the other lanes take the launches (MonoStream.UPLOAD_STREAM: what the mono stream uses - but these
+    # configurations need the fourth lane to hide their two serial chains: config 3 164 against 197, config 4 147 against 146 Mkeypoints/s,
+    # tools/bench_stereo_copy_ab.sh); "streams" = a copy-in and a copy-out stream beside the lanes (round 2's form)
+    copy_mode = os.environ.get("YDORB_BENCH_COPY", "lane")
+    in_lane, up_mode = copy_mode == "lane", copy_mode == "upload" and NSETS >= 2
+    INC = NSETS - 1 if up_mode else NSETS                     # lanes that take the inclusive pipeline's launches
+    RING = INC + 2 if up_mode else NSETS if in_lane else NSETS + 1
     lanes = [torch.cuda.Stream(device=dev) for _ in range(NSETS)]
-    s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    if up_mode:
+        s_in = lanes[-1]
+        s_out = None
+    else:
+        s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     ring = [(torch.empty_like(hL, device=dev), torch.empty_like(hR, device=dev)) for _ in range(RING)]
     ring[0][0].copy_(hL); ring[0][1].copy_(hR)
     ev = lambda n_: [torch.cuda.Event() for _ in range(n_)]
     ev_in, ev_free, ev_done, ev_out = ev(RING), ev(RING), ev(NSETS), ev(NSETS)
+    free_used = [False] * RING
     sets = []
     for i in range(NSETS):
         S_ = dict(xL=y.OrbExtractor(nf, 1.2, 8, 20, 7, device=ctx.local_rank, max_batch=n_pairs, single_stream=True),
@@ -686,40 +745,45 @@ def stereo_config(ctx, y, link, w, h, nf, n_pairs, label, repeats, tile_default=
     scap = sets[0]["xL"].max_keypoints
     ssf = sets[0]["xL"].tables()["scale"]
     kstep = [0]
+    parts = os.environ.get("YDORB_BENCH_STEREO_PARTS", "stereo,match").split(",")   # diagnostic: leave the association or the search out
 
     def one(inclusive, full=True):
         k = kstep[0]
         kstep[0] += 1
-        b = k % NSETS
+        b = k % (INC if inclusive else NSETS)
         S_ = sets[b]
         sA, st = S_["st"], S_["st"].cuda_stream
         dL_, dR_ = ring[0]
+        r = k % RING
         if inclusive and in_lane:
             dL_, dR_ = ring[b]
             with torch.cuda.stream(sA):
                 dL_.copy_(hL, non_blocking=True)
                 dR_.copy_(hR, non_blocking=True)
         elif inclusive:
-            r = k % RING
             dL_, dR_ = ring[r]
-            s_in.wait_event(ev_free[r])
+            if not up_mode or free_used[r]:
+                s_in.wait_event(ev_free[r])
             with torch.cuda.stream(s_in):
                 dL_.copy_(hL, non_blocking=True)
                 dR_.copy_(hR, non_blocking=True)
             ev_in[r].record(s_in)
             sA.wait_event(ev_in[r])
-            sA.wait_event(ev_out[b])
+            if not up_mode:
+                sA.wait_event(ev_out[b])
         S_["xL"].extract_batch_device(dL_.data_ptr(), w, h, w, w * h, n_pairs, S_["kL"].data_ptr(), S_["dL"].data_ptr(), scap, S_["nL"].data_ptr(), st)
         S_["xR"].extract_batch_device(dR_.data_ptr(), w, h, w, w * h, n_pairs, S_["kR"].data_ptr(), S_["dR"].data_ptr(), scap, S_["nR"].data_ptr(), st)
         if inclusive and not in_lane:
             ev_free[r].record(sA)
-        if full:
+            free_used[r] = True
+        if full and "stereo" in parts:
             S_["sm"].stereo_matches_device(S_["xL"], S_["xR"], S_["kL"].data_ptr(), S_["dL"].data_ptr(), S_["nL"].data_ptr(), scap, S_["kR"].data_ptr(),
                                            S_["dR"].data_ptr(), S_["nR"].data_ptr(), scap, n_pairs, 40.0, 0.1, S_["rx"].data_ptr(), S_["dp"].data_ptr(),
                                            S_["kept"].data_ptr(), None, False, (0, 1), (0, 1), st)
+        if full and "match" in parts:
             fs_ = (S_["kL"].data_ptr(), S_["dL"].data_ptr(), S_["nL"].data_ptr(), n_pairs, scap)
             S_["mm"].match_pairs_device(fs_, fs_, prs, w, h, 15.0, ssf, S_["asg"].data_ptr(), S_["cnt"].data_ptr(), daf.data_ptr(), st)
-        if inclusive and in_lane:
+        if inclusive and (in_lane or up_mode):
             with torch.cuda.stream(sA):
                 for h_, d_ in zip(S_["h_outs"], S_["outs"]):
                     h_.copy_(d_, non_blocking=True)
@@ -771,8 +835,10 @@ def stereo_config(ctx, y, link, w, h, nf, n_pairs, label, repeats, tile_default=
     out = {"workload": label, "value": res["inclusive"]["value"], "unit": "Mkeypoints/s", "inclusive": res["inclusive"], "kernel_pipeline": res["kernel_pipeline"],
            "extract_only": res["extract_only"], "stereo_pairs_per_launch": n_pairs, "distinct_stereo_pairs": distinct, "keypoints_per_image": kp_img,
            "stereo_measurements_per_pair": float(sets[0]["kept"].float().mean().item()), "matches_per_left_pair": float(sets[0]["cnt"].float().mean().item()),
-           "pipelining": "%d lanes (handle pair + matchers + one stream each) take consecutive launches; a launch's extractions, association and search run back "
-                         "to back on its lane; uploads into a ring of %d device image pairs on a copy-in stream, read-backs on a copy-out stream" % (NSETS, RING),
+           "pipelining": "%d lanes (handle pair + matchers + one stream each) take consecutive launches; a launch's extractions, association, search and "
+                         "read-back run back to back on its lane; copies: %s (ring of %d device image pairs).  kernel_pipeline / extract_only: %d lanes, no copies"
+                         % (INC, "the uploads back to back on a stream of their own" if up_mode else "uploads in the lane too" if in_lane else
+                            "a copy-in and a copy-out stream", RING, NSETS),
            "pcie": {"host_to_device_MB_per_launch": bytes_in / 1e6, "device_to_host_MB_per_launch": bytes_out / 1e6,
                     "achieved_GBps": bytes_in / t_inc / 1e9, "achieved_d2h_GBps": bytes_out / t_inc / 1e9, "peak_GBps": link["peak_GBps"],
                     "frac": bytes_in / t_inc / (link["peak_GBps"] * 1e9)},

@@ -760,7 +760,8 @@ __device__ __forceinline__ void qt_pass_unit(const PlanDev& P, const uint32_t* _
   // concatenate the level's cells in (row, col) order == keyPointsToDistr (orbExtractor.cpp:584-590)
   const uint32_t* cnts = cellCount + (size_t)f * P.nCellsTotal + L.cellBegin;
   unsigned n = 0;
-  for (int c0 = 0; c0 < L.nCells; c0 += kQtThreads) {
+  const int NTQ = cx.nthreads();   // k_quadtree: kQtThreads; k_quadtree_list: kQtListThreads
+  for (int c0 = 0; c0 < L.nCells; c0 += NTQ) {
     const int c = c0 + lane;
     const unsigned v = c < L.nCells ? cnts[c] : 0u;
     unsigned tot;
@@ -781,7 +782,7 @@ __device__ __forceinline__ void qt_pass_unit(const PlanDev& P, const uint32_t* _
     if (lane == 0) atomicMax(status, 1);  // more candidates than the packed 16-bit counters allow
   } else {
     // one thread per cell: its (few) entries are independent loads
-    for (int c = lane; c < L.nCells; c += kQtThreads) {
+    for (int c = lane; c < L.nCells; c += NTQ) {
       const unsigned m = cnts[c], b = cellBase[c];
       const uint32_t* src = cellCand + ((size_t)f * P.nCellsTotal + L.cellBegin + c) * P.cellCap;
       if (inLds) { for (unsigned i = 0; i < m; i++) ldsCand[b + i] = src[i]; }
@@ -813,14 +814,19 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(PlanDev P, const uint32
 }
 // the units k_qt_fast handed over (rare): a FEW workgroups walk the hand-over list.  (One workgroup per (frame, level) unit that leaves at
 // once when its unit was not handed over looked free - 4.5 us alone - but 8192 workgroups of 512 threads and ~40 KB of LDS queue behind the
-// other lanes' kernels: 2.7 ms on average in the four-lane pipeline, in front of the lane's descriptor kernel.)
-constexpr int kQtPassWorkgroups = 32;
+// other lanes' kernels: 2.7 ms on average in the four-lane pipeline, in front of the lane's descriptor kernel; even 32 of them waited
+// 0.25 - 0.9 ms for their slots with an EMPTY list.)  The host sizes the grid from the list length of an earlier call (*lastCount, copied
+// back with the level maxima): one workgroup while nothing is handed over, up to kQtPassWorkgroups when a stream's frames need it - any grid
+// >= 1 walks the whole list.
+constexpr int kQtPassWorkgroups = 256;
+constexpr int kQtListThreads = 256;   // the footprint of the other kernels' workgroups (4 waves): placed as soon as one of those retires
 __global__ __launch_bounds__(kQtThreads) void k_quadtree_list(PlanDev P, const uint32_t* __restrict__ cellCount,
                                                  const uint32_t* __restrict__ cellCand, uint32_t* __restrict__ qtCand,
                                                  uint16_t* __restrict__ qtNode, size_t qtFrameStride, int nodeCap, uint32_t* __restrict__ lvlKp,
                                                  int* __restrict__ lvlCount, int* __restrict__ status, const int* __restrict__ passCount,
-                                                 const int* __restrict__ passList, uint8_t* __restrict__ nodeScratch) {
+                                                 const int* __restrict__ passList, uint8_t* __restrict__ nodeScratch, int* __restrict__ lastCount) {
   const int n = *passCount;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *lastCount = n;
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
     const int unit = passList[i];
     qt_pass_unit(P, cellCount, cellCand, qtCand, qtNode, qtFrameStride, nodeCap, 0, unit % kMaxLevels, unit / kMaxLevels, lvlKp, lvlCount, status, nodeScratch);

@@ -80,7 +80,7 @@ struct ydorb_extractor {
   uint8_t* h_pyr = nullptr;           // pinned staging of one frame's pyramid block (ydorb_extractor_read_pyramid)
   size_t h_pyrBytes = 0;
   hipStream_t lastStream = nullptr;   // stream of the last enqueue (a caller's stream on the device-resident path)
-  int *d_lvlMaxN = nullptr, *h_lvlMaxN = nullptr;   // largest candidate count seen per level (device max, copied back after every call)
+  int *d_lvlMaxN = nullptr, *h_lvlMaxN = nullptr;   // largest candidate count seen per level (device max) + [kMaxLevels] the last hand-over list length; copied back after every call
   float* d_lvlAngle = nullptr;
   CellDev* d_cells = nullptr;
   int* d_tabInt = nullptr;
@@ -392,10 +392,10 @@ int ensurePlan(ydorb_extractor* e, int w, int h, int nFrames) {
   HIPCHK(hipMalloc(&e->d_lvlKp, sizeof(uint32_t) * (size_t)D.sumQuota * B));
   HIPCHK(hipMalloc(&e->d_lvlAngle, sizeof(float) * (size_t)D.sumQuota * B));
   HIPCHK(hipMalloc(&e->d_lvlCount, sizeof(int) * kMaxLevels * B));
-  HIPCHK(hipMalloc(&e->d_lvlMaxN, sizeof(int) * kMaxLevels));
-  HIPCHK(hipMemsetAsync(e->d_lvlMaxN, 0, sizeof(int) * kMaxLevels, e->stream));
-  HIPCHK(hipHostMalloc(&e->h_lvlMaxN, sizeof(int) * kMaxLevels));
-  memset(e->h_lvlMaxN, 0, sizeof(int) * kMaxLevels);
+  HIPCHK(hipMalloc(&e->d_lvlMaxN, sizeof(int) * (kMaxLevels + 1)));
+  HIPCHK(hipMemsetAsync(e->d_lvlMaxN, 0, sizeof(int) * (kMaxLevels + 1), e->stream));
+  HIPCHK(hipHostMalloc(&e->h_lvlMaxN, sizeof(int) * (kMaxLevels + 1)));
+  memset(e->h_lvlMaxN, 0, sizeof(int) * (kMaxLevels + 1));
   HIPCHK(hipMalloc(&e->d_status, sizeof(int)));
   HIPCHK(hipMalloc(&e->d_nOut, sizeof(int) * B));
   HIPCHK(hipMalloc(&e->d_cells, sizeof(CellDev) * std::max<size_t>(P.cells.size(), 1)));
@@ -580,9 +580,11 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
   }
   if (!e->qtInline) for (int g = 0; g < nGroups; g++) HIPCHK(hipStreamWaitEvent(s, e->evJoin[g], 0));
   if (anyFast) {  // units k_qt_fast handed over (rare): node table in LDS, candidates in HBM scratch; the list's counter is cleared for the next call
-    hipLaunchKernelGGL(k_quadtree_list, dim3(std::min(kQtPassWorkgroups, D.nLevels * nFrames)), dim3(kQtThreads), P.qtPassLds, s, D, e->d_cellCount, e->d_cellCand,
+    const int seen = e->h_lvlMaxN[kMaxLevels];   // hand-over list length of an earlier call (copied back below)
+    const int listGrid = std::max(1, std::min({kQtPassWorkgroups, D.nLevels * nFrames, seen + seen / 4}));
+    hipLaunchKernelGGL(k_quadtree_list, dim3(listGrid), dim3(kQtListThreads), P.qtPassLds, s, D, e->d_cellCount, e->d_cellCand,
                        e->d_qtCand, e->d_qtNode, P.qtFrameStride, -std::max(P.qtPassNodes, 1), e->d_lvlKp, e->d_lvlCount, e->d_status, e->d_passList,
-                       e->d_passList + 1, e->d_nodeScratch);
+                       e->d_passList + 1, e->d_nodeScratch, e->d_lvlMaxN + kMaxLevels);
     HIPCHK(hipMemsetAsync(e->d_passList, 0, sizeof(int), s));
   }
   if (prof) HIPCHK(hipEventRecord(e->ev[4], s));
@@ -599,7 +601,7 @@ int enqueue(ydorb_extractor* e, const uint8_t* d_img, int stride, size_t frameSt
 #undef YD_DESC
   }
   if (prof) { HIPCHK(hipEventRecord(e->ev[5], s)); e->profPending = true; }
-  HIPCHK(hipMemcpyAsync(e->h_lvlMaxN, e->d_lvlMaxN, sizeof(int) * kMaxLevels, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(e->h_lvlMaxN, e->d_lvlMaxN, sizeof(int) * (kMaxLevels + 1), hipMemcpyDeviceToHost, s));
   HIPCHK(hipGetLastError());
   e->lastFrames = nFrames;
   e->lastStream = s;
