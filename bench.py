@@ -682,7 +682,7 @@ def mono_section(ctx, y, link):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # Configs 3 and 4: stereo streams (extract L + R, computeStereoMatches, consecutive left-frame search), inclusive and resident
 # ---------------------------------------------------------------------------------------------------------------------------------
-def stereo_config(ctx, y, link, w, h, nf, n_pairs, label, repeats, tile_default=1):
+def stereo_config(ctx, y, link, w, h, nf, n_pairs, label, repeats, tile_default=1, copy_default="lane"):
     import numpy as np
     from ydorbslam_amd.synth import stream_plan, stream_render
     torch, dev, args = ctx.torch, ctx.dev, ctx.args
@@ -711,11 +711,11 @@ def stereo_config(ctx, y, link, w, h, nf, n_pairs, label, repeats, tile_default=
     # lanes.  The handles are single-stream (YDORB_EXTRACTOR_SINGLE_STREAM): with side streams, 5+ streams share the device's 4 hardware
     # queues and a stream that lands behind a chain stalls.
     NSETS = int(os.environ.get("YDORB_BENCH_STEREO_SETS", "4"))
-    # YDORB_BENCH_COPY: "lane" (default) = every lane uploads its own pairs in stream order; "upload" = the last lane's stream only uploads, back
-    # to back into a ring of image pairs, the other lanes take the launches (MonoStream.UPLOAD_STREAM: what the mono stream uses - but these
-    # configurations need the fourth lane to hide their two serial chains: config 3 164 against 197, config 4 147 against 146 Mkeypoints/s,
-    # tools/bench_stereo_copy_ab.sh); "streams" = a copy-in and a copy-out stream beside the lanes (round 2's form)
-    copy_mode = os.environ.get("YDORB_BENCH_COPY", "lane")
+    # YDORB_BENCH_COPY: "lane" = every lane uploads its own pairs in stream order; "upload" = the last lane's stream only uploads, back to back
+    # into a ring of image pairs, the other lanes take the launches (MonoStream.UPLOAD_STREAM); "streams" = a copy-in and a copy-out stream
+    # beside the lanes (round 2's form).  Config 3 is bound by its kernels and needs the fourth lane to hide its two serial chains (lane 212,
+    # upload 167 Mkeypoints/s), config 4 is bound by the link (lane 138, upload 146) - tools/bench_hwq_sweep.sh, profiles/r03_sweeps.txt.
+    copy_mode = os.environ.get("YDORB_BENCH_COPY", copy_default)
     in_lane, up_mode = copy_mode == "lane", copy_mode == "upload" and NSETS >= 2
     INC = NSETS - 1 if up_mode else NSETS                     # lanes that take the inclusive pipeline's launches
     RING = INC + 2 if up_mode else NSETS if in_lane else NSETS + 1
@@ -1034,7 +1034,7 @@ def main():
     if want("config4"):
         out["config4"] = stereo_config(ctx, y, link, 752, 480, 1000, 64, "EuRoC-MH-size 752x480 stereo batch, 1000 feat/image, one GPU's share: extract L+R, "
                                        "computeStereoMatches, consecutive left-frame search; pinned host frames in, results back in pinned host memory",
-                                       max(3, args.repeats // 2), tile_default=8)
+                                       max(3, args.repeats // 2), tile_default=8, copy_default="upload")
     state = None
     if extras:
         import bench_extras

@@ -587,21 +587,12 @@ int ydorb_stereo_matches(ydorb_matcher_t* m, const YdStereoSide* L, const YdSter
   P.capL = L->cap; P.capR = R->cap; P.frameL0 = L->first_frame; P.frameLStep = L->frame_step; P.frameR0 = R->first_frame; P.frameRStep = R->frame_step;
   P.nLevels = vl.nLevels; P.flags = flags; P.bf = bf; P.maxD = bf / b;   // :382
   P.counters = m->stereoCnt.as<int>(); P.keptOut = m->stereoOut.as<int>(); P.statusOut = m->stereoOut.as<int>() + nPairs;
-  // replay form: room for the per-row candidate lists in LDS: every right keypoint covers at most 2*ceil(2*scale)+1 rows
+  // replay form: the right-keypoint table (8 bytes each) + the index sorted by first band row (row starts, fill cursors, 2 bytes per keypoint)
   size_t ldsReplay = (size_t)R->cap * 8;
   {
-    // Room for the lists: a right keypoint of level l sits in 2 ceil(2 scale_l) + 1 rows (:372-377).  The worst case (every keypoint on
-    // the top level) is 80 KB at 2000 features and leaves one workgroup per CU - two such calls then fill the chip and everything
-    // else waits; the right extractor's level quotas give the expected total (+ 25 %), about half of that.  A pair whose lists do not
-    // fit at run time takes the scan form (same result).
-    const int band = 2 * (int)std::ceil(2.0f * vl.scale[vl.nLevels - 1]) + 2;
-    size_t expect = 0, quotaSum = 0;
-    for (int l = 0; l < vr.nLevels; l++) { expect += (size_t)vr.quota[l] * (2 * (size_t)std::ceil(2.0f * vr.scale[l]) + 1); quotaSum += (size_t)vr.quota[l]; }
-    if (quotaSum > 0) expect = expect * (size_t)R->cap / quotaSum;
-    const size_t entries = std::min((size_t)R->cap * band, expect + expect / 4 + 256);
-    const size_t bytes = (size_t)R->cap * 8 + sizeof(int) * (2 * (size_t)vl.h[0] + 1) + 2 * entries + 16;
+    const size_t bytes = (size_t)R->cap * 8 + sizeof(int) * (2 * (size_t)vl.h[0] + 1) + 2 * (size_t)R->cap + 16;
     const bool noLists = getenv("YDORB_STEREO_NO_ROW_LISTS") != nullptr;   // diagnostic: force the scan form (tests compare the two)
-    if (!noLists && !(flags & YDORB_STEREO_INDEX_BY_KEYPOINT) && bytes <= 120 * 1024 && entries < (1u << 30)) { P.rowLists = (int)entries; ldsReplay = bytes; }
+    if (!noLists && !(flags & YDORB_STEREO_INDEX_BY_KEYPOINT) && bytes <= 120 * 1024 && vl.h[0] < 4095) { P.rowLists = 1; ldsReplay = bytes; }
   }
   // P travels as a kernel argument: an asynchronous copy out of pageable host memory makes the host wait for everything queued on
   // the stream before it - here the extraction the association waits for - and a caller that pipelines steps would run in lock step

@@ -17,7 +17,11 @@
 //
 // Row bands: instead of the reference's per-row index lists the kernel keeps one (lo, hi, octave, x) record per right
 // keypoint in LDS and scans them in index order — the same candidates in the same order (the lists are filled in keypoint
-// order, :373-379), so "first minimum" is the minimum of (distance << 16 | index).
+// order, :373-379), so "first minimum" is the minimum of (distance << 16 | index).  The replay form adds an index of the right
+// keypoints sorted by the FIRST row of their band (2 bytes each): the candidates of a row are then the entries whose first row lies in
+// [row - widest band, row], filtered by the band test.  (The reference's lists themselves - every keypoint in each of its ~9 rows -
+// took 44 KB of LDS per pair at 2000 features; the workgroup's LDS is what the other lanes' kernels cannot use while the serial walk
+// runs: +32 KB cost the pipeline 12 %, tools/bench_stereo_lds.sh.)
 #pragma once
 #include "match_kernels.hip.h"
 
@@ -42,7 +46,7 @@ struct StereoDev {
   float* rightX; float* depth;
   int* counters;   // per pair: [0] measurements kept, [1] of those with block-match minimum 0, [2] status bits, [3] unused
   int* keptOut; int* statusOut;
-  int rowLists;   // replay kernel: LDS entries reserved for per-row candidate lists (0 = scan all right keypoints per step)
+  int rowLists;   // replay kernel: 1 = LDS holds the first-row-sorted index of the right keypoints (0 = scan all right keypoints per step)
 };
 
 struct StereoAcc { int kept, zeros, status; };
@@ -58,7 +62,7 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 // says whether the reference's loop body reaches `leftIdx++` (:462).
 __device__ StereoRes stereo_one(const StereoDev& P, int pair, float kx, float ky, int o, uint4 a0, uint4 a1, int nR,
                                 const float* __restrict__ rx, const unsigned* __restrict__ rinfo, unsigned short* cand, int lane,
-                                const int* __restrict__ rowStart = nullptr, const unsigned short* __restrict__ rowEnt = nullptr) {
+                                const int* __restrict__ rowStart = nullptr, const unsigned short* __restrict__ rowEnt = nullptr, int bandMax = 0) {
   StereoRes Rz{false, false, false, 0, -1.0f, -1.0f};
   const int row = (int)ky;
   if (!(ky >= 0.0f) || row >= P.h[0]) { Rz.status = 1; return Rz; }   // out-of-range row index at :389 (undefined in the reference)
@@ -80,19 +84,32 @@ __device__ StereoRes stereo_one(const StereoDev& P, int pair, float kx, float ky
     }
   };
   if (rowStart) {
-    // per-row lists (the reference's vRowIndices, :368-379, built once per pair): the candidates of this row, 64 at a time; list order
-    // does not matter because the winner is the minimum of (distance << 16 | index)
-    const int e0 = rowStart[row], e1 = rowStart[row + 1];
-    any = e1 > e0;
-    for (int e = e0 + lane; e < e1; e += 64) {
-      const int j = rowEnt[e];
-      const int oc = (int)(rinfo[j] >> 24);
-      const float x = rx[j];
-      if (oc >= o - 1 && oc <= o + 1 && x >= xlo && x <= xhi) {
-        const uint4 b0 = *reinterpret_cast<const uint4*>(dr + (size_t)j * 32), b1 = *reinterpret_cast<const uint4*>(dr + (size_t)j * 32 + 16);
+    // rowEnt = the right keypoints sorted by the first row of their band, rowStart[r] = first entry whose band starts at row >= r: the
+    // candidates of this row start in [row - bandMax, row] (bandMax = widest band - 1 of this pair).  Two entries per lane and trip, so
+    // that the usual ~90 entries are one trip with all LDS reads - and then all descriptor rows - in flight together; entry order does not
+    // matter because the winner is the minimum of (distance << 16 | index).
+    const int e0 = rowStart[max(row - bandMax, 0)], e1 = rowStart[row + 1];
+    for (int e = e0 + lane; e < e1; e += 128) {
+      const bool h1 = e + 64 < e1;
+      const int ja = rowEnt[e], jb = h1 ? rowEnt[e + 64] : ja;
+      const unsigned ia = rinfo[ja], ib = rinfo[jb];
+      const float xa = rx[ja], xb = rx[jb];
+      const int oa = (int)(ia >> 24), ob = (int)(ib >> 24);
+      const bool ra = row <= (int)((ia >> 12) & 0xFFF), rb = h1 && row <= (int)((ib >> 12) & 0xFFF);   // first row <= row holds for every entry
+      any |= ra | rb;
+      const bool pa = ra && oa >= o - 1 && oa <= o + 1 && xa >= xlo && xa <= xhi, pb = rb && ob >= o - 1 && ob <= o + 1 && xb >= xlo && xb <= xhi;
+      uint4 b0 = {}, b1 = {}, c0 = {}, c1 = {};
+      if (pa) { b0 = *reinterpret_cast<const uint4*>(dr + (size_t)ja * 32); b1 = *reinterpret_cast<const uint4*>(dr + (size_t)ja * 32 + 16); }
+      if (pb) { c0 = *reinterpret_cast<const uint4*>(dr + (size_t)jb * 32); c1 = *reinterpret_cast<const uint4*>(dr + (size_t)jb * 32 + 16); }
+      if (pa) {
         const int d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
                       __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
-        best = min(best, ((unsigned)d << 16) | (unsigned)j);
+        best = min(best, ((unsigned)d << 16) | (unsigned)ja);
+      }
+      if (pb) {
+        const int d = __popc(a0.x ^ c0.x) + __popc(a0.y ^ c0.y) + __popc(a0.z ^ c0.z) + __popc(a0.w ^ c0.w) + __popc(a1.x ^ c1.x) +
+                      __popc(a1.y ^ c1.y) + __popc(a1.z ^ c1.z) + __popc(a1.w ^ c1.w);
+        best = min(best, ((unsigned)d << 16) | (unsigned)jb);
       }
     }
   } else {
@@ -223,24 +240,30 @@ __global__ __launch_bounds__(256) void k_stereo(const StereoDev P, int kBegin, i
   const int k0 = REPLAY ? 0 : blockIdx.x * kStereoChunk, k1 = REPLAY ? P.capL : min(k0 + kStereoChunk, P.capL);
   if (!REPLAY && k0 >= nL) return;
   stereo_right_table(P, pair, nR, rx, rinfo);
-  // Replay form: the reference's per-row lists (vRowIndices, :368-379) as a CSR in LDS when the host reserved room for them -
-  // a step of the serial walk then reads its row's ~15 candidates instead of scanning every right keypoint's band.
+  // Replay form: the right keypoints sorted by the first row of their band (counting sort over the rows, order inside a row arbitrary) -
+  // a step of the serial walk then reads the ~90 entries whose band can cover its row instead of scanning every right keypoint.
   int* rowStart = nullptr;
   unsigned short* rowEnt = nullptr;
+  int bandMax = 0;
   if (REPLAY && P.rowLists > 0) {
     const int rows = P.h[0];
     int* rs = reinterpret_cast<int*>(rinfo + P.capR);          // [rows + 1]
     int* cur = rs + rows + 1;                                   // [rows] counts, then fill cursors
-    unsigned short* ent = reinterpret_cast<unsigned short*>(cur + rows);
+    unsigned short* ent = reinterpret_cast<unsigned short*>(cur + rows);   // [nR]
     __shared__ int rlWave[4];
-    __shared__ int rlTotal;
+    __shared__ int rlBand;
     for (int r = tid; r < rows; r += 256) cur[r] = 0;
+    if (tid == 0) rlBand = 0;
     __syncthreads();
+    int wmax = 0;
     for (int j = tid; j < nR; j += 256) {
       const unsigned inf = rinfo[j];
       const int lo = inf & 0xFFF, hi = (inf >> 12) & 0xFFF;
-      for (int r = lo; r <= hi; r++) atomicAdd(&cur[r], 1);
+      if (lo <= hi) { atomicAdd(&cur[lo], 1); wmax = max(wmax, hi - lo); }   // (an empty band, lo 4095 > hi 0, is in no row's list)
     }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
+    if (lane == 0) atomicMax(&rlBand, wmax);
     __syncthreads();
     {  // exclusive scan of the row counts: contiguous chunk per thread + block scan of the chunk sums
       const int per = (rows + 255) / 256, r0 = tid * per, r1 = min(r0 + per, rows);
@@ -254,21 +277,20 @@ __global__ __launch_bounds__(256) void k_stereo(const StereoDev P, int kBegin, i
       int off = x - sum;
       for (int w = 0; w < wave; w++) off += rlWave[w];
       for (int r = r0; r < r1; r++) { rs[r] = off; off += cur[r]; }
-      if (tid == 255) { rs[rows] = off; rlTotal = off; }
+      if (tid == 255) rs[rows] = off;
       __syncthreads();
     }
-    if (rlTotal <= P.rowLists) {   // wave-uniform: the lists fit the reserved room (else: scan form)
-      for (int r = tid; r < rows; r += 256) cur[r] = 0;
-      __syncthreads();
-      for (int j = tid; j < nR; j += 256) {
-        const unsigned inf = rinfo[j];
-        const int lo = inf & 0xFFF, hi = (inf >> 12) & 0xFFF;
-        for (int r = lo; r <= hi; r++) ent[rs[r] + atomicAdd(&cur[r], 1)] = (unsigned short)j;
-      }
-      __syncthreads();
-      rowStart = rs;
-      rowEnt = ent;
+    for (int r = tid; r < rows; r += 256) cur[r] = 0;
+    __syncthreads();
+    for (int j = tid; j < nR; j += 256) {
+      const unsigned inf = rinfo[j];
+      const int lo = inf & 0xFFF, hi = (inf >> 12) & 0xFFF;
+      if (lo <= hi) ent[rs[lo] + atomicAdd(&cur[lo], 1)] = (unsigned short)j;
     }
+    __syncthreads();
+    rowStart = rs;
+    rowEnt = ent;
+    bandMax = rlBand;
   }
   StereoAcc A{0, 0, 0};
   const KeyPointDev* kl = P.kpsL + (size_t)pair * P.capL;
@@ -293,7 +315,7 @@ __global__ __launch_bounds__(256) void k_stereo(const StereoDev P, int kBegin, i
       const float nkx = kl[kn].x, nky = kl[kn].y;
       const int no = kl[kn].octave;
       const uint4 n0 = dl[2 * sn], n1 = dl[2 * sn + 1];
-      const StereoRes r = stereo_one(P, pair, kx, ky, o, a0, a1, nR, rx, rinfo, candList[wave], lane, rowStart, rowEnt);
+      const StereoRes r = stereo_one(P, pair, kx, ky, o, a0, a1, nR, rx, rinfo, candList[wave], lane, rowStart, rowEnt, bandMax);
       if (r.kept && lane == 0) { outRx[s] = r.rx; outDepth[s] = r.depth; }
       A.kept += r.kept; A.zeros += r.zero; A.status |= r.status;
       if (r.complete) { s++; a0 = n0; a1 = n1; }
