@@ -664,7 +664,8 @@ def mono_section(ctx, y, link):
                                       "window's grid cells (frame.cpp:353, reproduced bit for bit) and the rotation histogram uses the factor 1/30 "
                                       "(orbMatcher.cpp:78): ~120 pass the distance test, ~50 the rotation check",
                       "parallelism": par,
-                      "hip_runtime": ctx.hip_runtime or "the one bundled with PyTorch (torch/lib)"},
+                      "hip_runtime": ctx.hip_runtime or "the one bundled with PyTorch (torch/lib)",
+                      "hardware_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))},
            "kernel_pipeline": {"value": res["median"], "unit": "Mkeypoints/s", "ms_per_step": dt_res / args.steps * 1e3, "min": res["min"], "max": res["max"],
                                "n": res["n"], "timed_region_s": dt_res,
                                "note": "frames resident in HBM, results left in HBM; the same launches, lanes and streams without the copies"},
@@ -682,7 +683,7 @@ def mono_section(ctx, y, link):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # Configs 3 and 4: stereo streams (extract L + R, computeStereoMatches, consecutive left-frame search), inclusive and resident
 # ---------------------------------------------------------------------------------------------------------------------------------
-def stereo_config(ctx, y, link, w, h, nf, n_pairs, label, repeats, tile_default=1, copy_default="lane"):
+def stereo_config(ctx, y, link, w, h, nf, n_pairs, label, repeats, tile_default=1, copy_default="lane", sets_default=4):
     import numpy as np
     from ydorbslam_amd.synth import stream_plan, stream_render
     torch, dev, args = ctx.torch, ctx.dev, ctx.args
@@ -710,11 +711,13 @@ def stereo_config(ctx, y, link, w, h, nf, n_pairs, label, repeats, tile_default=
     # launches go to consecutive lanes, no events between lanes: the two latency chains of a launch hide behind the extractions of the other
     # lanes.  The handles are single-stream (YDORB_EXTRACTOR_SINGLE_STREAM): with side streams, 5+ streams share the device's 4 hardware
     # queues and a stream that lands behind a chain stalls.
-    NSETS = int(os.environ.get("YDORB_BENCH_STEREO_SETS", "4"))
+    NSETS = int(os.environ.get("YDORB_BENCH_STEREO_SETS", str(sets_default)))
     # YDORB_BENCH_COPY: "lane" = every lane uploads its own pairs in stream order; "upload" = the last lane's stream only uploads, back to back
     # into a ring of image pairs, the other lanes take the launches (MonoStream.UPLOAD_STREAM); "streams" = a copy-in and a copy-out stream
-    # beside the lanes (round 2's form).  Config 3 is bound by its kernels and needs the fourth lane to hide its two serial chains (lane 212,
-    # upload 167 Mkeypoints/s), config 4 is bound by the link (lane 138, upload 146) - tools/bench_hwq_sweep.sh, profiles/r03_sweeps.txt.
+    # beside the lanes (round 2's form).  Config 3 is bound by its kernels and needs many lanes to hide its two serial chains: with the
+    # process's 8 hardware queues (GPU_MAX_HW_QUEUES, main()) 7 lanes + the upload stream 207 (202-211) against 4 lanes with in-lane copies
+    # 184-193 (138-212), 3 lanes + upload stream 167; config 4 is bound by the link: 3 lanes + upload stream 146, in-lane 138
+    # (tools/bench_c3_ab.sh, tools/bench_hwq_sweep.sh, profiles/r03_sweeps.txt).
     copy_mode = os.environ.get("YDORB_BENCH_COPY", copy_default)
     in_lane, up_mode = copy_mode == "lane", copy_mode == "upload" and NSETS >= 2
     INC = NSETS - 1 if up_mode else NSETS                     # lanes that take the inclusive pipeline's launches
@@ -1007,6 +1010,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the single-call / config 3 / config 4 / brute-force / next-row sections")
     args = ap.parse_args()
 
+    # The HIP runtime deals a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share one run in turn.  The
+    # mono pipeline needs four (its default), config 3's eight lanes need eight.  Read when the runtime loads, so set before anything else.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus)
         return
@@ -1030,7 +1037,7 @@ def main():
     if want("config3"):
         out["config3"] = stereo_config(ctx, y, link, 1241, 376, 2000, 128, "KITTI-00-size 1241x376 stereo, 2000 feat/image: extract L+R, computeStereoMatches "
                                        "(as the reference writes it), consecutive left-frame search; pinned host frames in, results back in pinned host memory",
-                                       max(3, args.repeats // 2), tile_default=2)
+                                       max(3, args.repeats // 2), tile_default=2, copy_default="upload", sets_default=8)
     if want("config4"):
         out["config4"] = stereo_config(ctx, y, link, 752, 480, 1000, 64, "EuRoC-MH-size 752x480 stereo batch, 1000 feat/image, one GPU's share: extract L+R, "
                                        "computeStereoMatches, consecutive left-frame search; pinned host frames in, results back in pinned host memory",

@@ -446,7 +446,8 @@ __global__ __launch_bounds__(256) void k_distinctive(const uint8_t* __restrict__
   if (lane == 0) best[p] = (int)(win & 0xFFFFu);
 }
 
-constexpr int kResolveWindow = 2048;  // queries whose (base,count) are staged in LDS at a time
+constexpr int kResolveWindow = 512;   // queries whose (base,count) are staged in LDS at a time (10 KB: this one-wave workgroup's LDS is what the other
+                                       // lanes' kernels cannot use meanwhile; 2048 = 41 KB x 4 workgroups per CU left them none)
 
 __global__ __launch_bounds__(64) void k_resolve(const CallDev* __restrict__ calls, const FrameDev* __restrict__ frames,
                                                 const uint32_t* __restrict__ pool, int takenWords) {
