@@ -14,7 +14,7 @@ and SURVEY.md 8(d) times "the batch incl. H2D/D2H".  So the headline `value` is 
 `kernel_pipeline` is the same work with the frames already resident in HBM and the results left there (what rounds 1-2 reported as
 `value`), `pcie` is the measured host link next to it, `roofline` the dominant kernel against the HBM roof.
 
-One "step" = --substeps launches of --frames frames each (default 16 x 1024 = 16384 frames), dealt to the lanes in turn (inclusive: three lanes + one
+One "step" = --substeps launches of --frames frames each (default 8 x 2048 = 16384 frames), dealt to the lanes in turn (inclusive: three lanes + one
 stream that only uploads; resident: four lanes); the timed
 region is exactly --steps steps, bracketed by barrier + synchronize, and it is repeated --repeats times: `value` is the median,
 `repeats` holds min / max.
@@ -993,9 +993,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--repeats", type=int, default=10, help="timed regions of exactly --steps steps each; value = median")
-    ap.add_argument("--frames", type=int, default=1024, help="frames per launch and per GPU (measured, inclusive / resident Mkeypoints/s: 256 frames 142 / 214, "
-                                                            "512 frames 163 / 213, 1024 frames 174 / 209: longer uploads keep the link busier)")
-    ap.add_argument("--substeps", type=int, default=16, help="launches per step (a step = substeps x frames frames: 20 steps are then a timed region of > 1 s)")
+    ap.add_argument("--frames", type=int, default=2048, help="frames per launch and per GPU (measured, inclusive / resident Mkeypoints/s, uploads on their own "
+                                                            "stream: 512 frames 158 / 248, 1024 frames 174 / 250, 2048 frames 180 / 250: longer uploads keep the link busier)")
+    ap.add_argument("--substeps", type=int, default=8, help="launches per step (a step = substeps x frames frames: 20 steps are then a timed region of > 1 s)")
     ap.add_argument("--region-s", type=float, default=1.0, help="target length of the timed regions of the config 3 / config 4 sections")
     ap.add_argument("--segment", type=int, default=64, help="frames per synthetic scene (a new scene is a cut)")
     ap.add_argument("--exchange", choices=("allgather", "ring", "neighbour"), default="allgather",

@@ -1,4 +1,5 @@
 """Deterministic synthetic inputs: frames, warps, BA problems.  numpy only."""
+import os
 import numpy as np
 
 
@@ -247,7 +248,7 @@ def stream_plan(w, h, n_frames, seed=0, segment=64, pred_sigma=1.5):
     return dict(w=w, h=h, n_frames=n_frames, seed=seed, segment=segment, pose=poses, affine=aff, predicted=pred, cut=cut)
 
 
-def stream_render(plan, indices, stereo=False, disparities=(7, 15, 26), margin=112):
+def stream_render(plan, indices, stereo=False, disparities=(7, 15, 26), margin=112, workers=None):
     """Render the frames `indices` of a planned stream: the segment's scene `synth_frame(w + 2*margin, h + 2*margin, seed*1000 + s)`
     sampled bilinearly through the frame's similarity, plus N(0,1) sensor noise (rng seeded per frame, so the pixels of frame t do not
     depend on which process renders it).  Returns (frames [n,h,w] u8, right [n,h,w] u8 or None); the rectified right view shows the
@@ -257,6 +258,18 @@ def stream_render(plan, indices, stereo=False, disparities=(7, 15, 26), margin=1
     indices = list(indices)
     frames = np.empty((len(indices), h, w), np.uint8)
     right = np.empty((len(indices), h, w), np.uint8) if stereo else None
+    if workers is None:
+        workers = min(8, os.cpu_count() or 1)
+    if workers > 1 and len(indices) >= 4 * workers:   # contiguous chunks on threads (numpy releases the GIL); same pixels: the noise is seeded per frame
+        from concurrent.futures import ThreadPoolExecutor
+        step = -(-len(indices) // (2 * workers))
+        chunks = [(i0, indices[i0:i0 + step]) for i0 in range(0, len(indices), step)]
+        with ThreadPoolExecutor(workers) as pool:
+            for (i0, idx), (fr, rt) in zip(chunks, pool.map(lambda c: stream_render(plan, c[1], stereo, disparities, margin, workers=1), chunks)):
+                frames[i0:i0 + len(idx)] = fr
+                if stereo:
+                    right[i0:i0 + len(idx)] = rt
+        return frames, right
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
     xx -= cx; yy -= cy
     bands = np.linspace(0, h, len(disparities) + 1).astype(int)
