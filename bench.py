@@ -105,8 +105,11 @@ def prefer_image_rocm():
     runs on the HIP / ROCr runtime bundled in the PyTorch wheel (torch/lib, an older release): same sonames, first one loaded wins.  Under the
     bundled runtime an upload and a read-back in flight together slow each other (tools/ubench/duplex_runtimes.sh: 256 MB up + 64 MB down
     52.7 + 13.2 GB/s against 57.0 + 14.2 on the image's runtime; torch copies both ways 28.5 + 28.5 against 48.5 + 48.5).  So the bench loads
-    the image's runtime before torch (YDORB_BENCH_SYSTEM_ROCM=0: leave the order alone).  Returns what was loaded, for the JSON line."""
-    if os.environ.get("YDORB_BENCH_SYSTEM_ROCM", "1") != "1" or "torch" in sys.modules:
+    the image's runtime before torch (YDORB_BENCH_SYSTEM_ROCM=0: leave the order alone).  N > 1 keeps PyTorch's own stack unless
+    YDORB_BENCH_SYSTEM_ROCM=1 asks otherwise: the RCCL build in the wheel was made for the runtime beside it, and the combination with the
+    image's runtime could only be rehearsed at world size 1 on this pool (tools/rehearse_multigpu.sh).  Returns what was loaded, for the JSON line."""
+    multi = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if os.environ.get("YDORB_BENCH_SYSTEM_ROCM", "0" if multi else "1") != "1" or "torch" in sys.modules:
         return None
     import ctypes
     root = os.environ.get("ROCM_PATH", "/opt/rocm")
@@ -913,6 +916,7 @@ def ba_section(ctx, y):
         ba["concurrent"] = {"problems": len(probs), "in_flight": NT, "value": sb["median"], "unit": "it/s (aggregate)", "min": sb["min"], "max": sb["max"], "n": sb["n"],
                             "ms_per_batch": sum(b_["trials"] for b_ in bres) / sb["median"] * 1e3,
                             "note": "ydorb_ba_solve_batch, lock-step batch: independent copies of the same C5 problem, every result bit-identical to its single solve"}
+        y.Optimizer.release(ctx.local_rank)   # the batch's pooled scratch (~2.5 GB) goes back before the stream pipeline allocates
     return ba
 
 
@@ -1026,10 +1030,13 @@ def main():
 
     ctx = Ctx(args)
     import ydorbslam_amd as y
+    # Config 5 first: with the stream pipeline's handles resident (25 GB of batch buffers for four 2048-frame lanes) the same solve takes
+    # 8.8 ms instead of 7.9 (device time, not host time: the solver's pooled buffers are then carved out of a crowded address space)
+    ba = None if args.no_ba else ba_section(ctx, y)
     link = pcie_link(ctx)
     out, S = mono_section(ctx, y, link)
-    if not args.no_ba:
-        out["ba"] = ba_section(ctx, y)
+    if ba is not None:
+        out["ba"] = ba
 
     extras = ctx.world == 1 and not args.no_extras
     only = [x for x in args.only.split(",") if x]
