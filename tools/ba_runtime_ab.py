@@ -18,3 +18,10 @@ for _ in range(30):
 ts = np.array(ts) * 1e3
 print("%-6s queues %s: ms min %.2f median %.2f max %.2f -> %.0f it/s (median)" % ("torch" if "torch" in sys.argv else "image", os.environ.get("GPU_MAX_HW_QUEUES", "default"),
       ts.min(), np.median(ts), ts.max(), r["trials"] / np.median(ts) * 1e3))
+probs = [synth_ba_problem(100, 10000, 8, seed=1) for _ in range(64)]
+y.Optimizer.local_bundle_adjust_batch(probs, o, 64)
+rs = []
+for _ in range(5):
+    t = time.perf_counter(); res = y.Optimizer.local_bundle_adjust_batch(probs, o, 64); dt = time.perf_counter() - t
+    rs.append(sum(b["trials"] for b in res) / dt)
+print("       64 problems in lock step: %.0f it/s median (%.0f - %.0f)" % (np.median(rs), min(rs), max(rs)))
