@@ -276,7 +276,9 @@ def pcie_link(ctx, mb=160, reps=5):
 # ---------------------------------------------------------------------------------------------------------------------------------
 class MonoStream:
     W, H, NFEAT = 640, 480, 1000
-    LANES = int(os.environ.get("YDORB_BENCH_LANES", "4"))
+    # 4 streams = the inclusive pipeline's three lanes + upload stream; N > 1: 6 (five lanes + upload stream, on the process's 8 hardware queues) -
+    # every launch of a lane then also waits for its exchange, and the other lanes' launches are what hides that wait (N = 1: 4 and 6 measure the same)
+    LANES = int(os.environ.get("YDORB_BENCH_LANES", "6" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "4"))
     # single-stream handles (YDORB_EXTRACTOR_SINGLE_STREAM: quad-tree launches on the lane's stream): the device runs 4 hardware queues, so 4
     # streams keep every lane on its own queue; handles with side streams share queues with the copies and with each other.  Resident
     # figures (kernel_pipeline, extract_only): 4 lanes of one stream each take consecutive launches.  Inclusive pipeline: see UPLOAD_STREAM.
