@@ -695,7 +695,8 @@ def stereo_config(ctx, y, link, w, h, nf, n_pairs, label, repeats, tile_default=
     # `tile` launches' worth of the stream per launch: the two serial chains of a launch (stereo replay, ordered resolve) take the same time
     # for 128 pairs as for 512 (one wave per pair), so larger launches hide them better behind the other lanes' extractions
     # (measured, inclusive / resident Mkeypoints/s with 4 lanes - tools/bench_stereo_sweep.sh: config 3 at 128 / 256 pairs per launch 133 / 193 ->
-    # 186 / 205; config 4 at 64 / 128 / 256 / 512 pairs per launch 79 / 138 -> 93 / 171 -> 124 / 190 -> 139 / 194)
+    # 186 / 205; config 4 at 64 / 128 / 256 / 512 pairs per launch 79 / 138 -> 93 / 171 -> 124 / 190 -> 139 / 194; with the upload stream,
+    # tools/bench_stereo_tile.sh: config 3 at 256 / 512 / 1024 pairs 206 / 226 / 225 inclusive, config 4 at 512 / 1024 pairs 146 / 154.5)
     tile = max(1, int(os.environ.get("YDORB_BENCH_STEREO_TILE", str(tile_default))))
     distinct = n_pairs
     pl = stream_plan(w, h, distinct, seed=7, segment=32)
@@ -1046,11 +1047,11 @@ def main():
     if want("config3"):
         out["config3"] = stereo_config(ctx, y, link, 1241, 376, 2000, 128, "KITTI-00-size 1241x376 stereo, 2000 feat/image: extract L+R, computeStereoMatches "
                                        "(as the reference writes it), consecutive left-frame search; pinned host frames in, results back in pinned host memory",
-                                       max(3, args.repeats // 2), tile_default=2, copy_default="upload", sets_default=8)
+                                       max(3, args.repeats // 2), tile_default=4, copy_default="upload", sets_default=8)
     if want("config4"):
         out["config4"] = stereo_config(ctx, y, link, 752, 480, 1000, 64, "EuRoC-MH-size 752x480 stereo batch, 1000 feat/image, one GPU's share: extract L+R, "
                                        "computeStereoMatches, consecutive left-frame search; pinned host frames in, results back in pinned host memory",
-                                       max(3, args.repeats // 2), tile_default=8, copy_default="upload")
+                                       max(3, args.repeats // 2), tile_default=16, copy_default="upload")
     state = None
     if extras:
         import bench_extras
