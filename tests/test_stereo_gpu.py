@@ -204,8 +204,8 @@ def test_device_resident_form_equals_the_host_form():
 
 
 def test_replay_with_and_without_row_lists(oracle_lib, monkeypatch):
-    """The replay kernel reads per-row candidate lists from LDS when they fit and scans every right keypoint's band otherwise
-    (large scale factors, many keypoints); YDORB_STEREO_NO_ROW_LISTS forces the second form.  Same bits either way."""
+    """The replay kernel takes a row's candidates from an index of the right keypoints sorted by the first row of their band (LDS) or
+    scans every right keypoint's band (YDORB_STEREO_NO_ROW_LISTS forces the second form).  Same bits either way."""
     import ydorbslam_amd as y
     left, right, _ = synth_stereo_pair(640, 480, 41)
     ex = y.OrbExtractor(1000, max_batch=2)
@@ -221,10 +221,9 @@ def test_replay_with_and_without_row_lists(oracle_lib, monkeypatch):
         assert np.array_equal(got[0][0].view(np.uint32), orx.view(np.uint32)) and np.array_equal(got[1][0].view(np.uint32), odepth.view(np.uint32))
 
 
-def test_row_lists_that_outgrow_their_reserved_room_fall_back_to_the_scan(oracle_lib):
-    """The LDS room for the per-row candidate lists is sized from the right extractor's level quotas (expected total + 25 %), not
-    for the worst case.  Right keypoints that all claim the top level (17 rows each instead of ~8 on average) overflow it: the pair must
-    then take the scan form by itself and still give the reference's result."""
+def test_every_right_keypoint_on_the_top_level(oracle_lib):
+    """Right keypoints that all claim the top level have the widest bands (17 rows each instead of ~8 on average): every row's window of the
+    sorted index is then as long as it can get for this keypoint density.  Still the reference's result."""
     import ydorbslam_amd as y
     left, right, _ = synth_stereo_pair(640, 480, 43)
     ex = y.OrbExtractor(1000, max_batch=2)
@@ -233,5 +232,22 @@ def test_row_lists_that_outgrow_their_reserved_room_fall_back_to_the_scan(oracle
     kr2["octave"] = 7
     got = y.OrbMatcher().stereo_matches(ex, ex, kl[None], dl[None], [len(kl)], kr2[None], dr[None], [len(kr2)], BF, B, left_frames=(0, 1), right_frames=(1, 1))
     _, (orx, odepth, okept, ostatus) = _oracle_pair(oracle_lib, left, right, 1000, kl=kl, dl=dl, kr=kr2, dr=dr)
+    assert got[2][0] == okept and got[3][0] == ostatus
+    assert np.array_equal(got[0][0].view(np.uint32), orx.view(np.uint32)) and np.array_equal(got[1][0].view(np.uint32), odepth.view(np.uint32))
+
+
+def test_right_keypoints_crowded_into_a_few_rows(oracle_lib):
+    """More than 128 index entries in one row's window (the first trip of the candidate scan takes two per lane): the right keypoints are
+    moved onto three image rows, the left ones onto the same rows, so every step walks several trips.  Same bits as the oracle and the scan form."""
+    import ydorbslam_amd as y
+    left, right, _ = synth_stereo_pair(640, 480, 44)
+    ex = y.OrbExtractor(1000, max_batch=2)
+    (kl, dl), (kr, dr) = ex.extract_batch(np.stack([left, right]))
+    kl2, kr2 = kl.copy(), kr.copy()
+    kr2["y"] = (200 + 40 * (np.arange(len(kr2)) % 3)).astype(np.float32) + (kr2["y"] - np.floor(kr2["y"]))
+    kl2["y"] = (200 + 40 * (np.arange(len(kl2)) % 3)).astype(np.float32) + (kl2["y"] - np.floor(kl2["y"]))
+    args = (ex, ex, kl2[None], dl[None], [len(kl2)], kr2[None], dr[None], [len(kr2)], BF, B)
+    got = y.OrbMatcher().stereo_matches(*args, left_frames=(0, 1), right_frames=(1, 1))
+    _, (orx, odepth, okept, ostatus) = _oracle_pair(oracle_lib, left, right, 1000, kl=kl2, dl=dl, kr=kr2, dr=dr)
     assert got[2][0] == okept and got[3][0] == ostatus
     assert np.array_equal(got[0][0].view(np.uint32), orx.view(np.uint32)) and np.array_equal(got[1][0].view(np.uint32), odepth.view(np.uint32))
