@@ -7,9 +7,11 @@
 //
 // The reference indexes the left descriptor and the output slot with a counter that only advances when a keypoint reaches
 // the end of the loop body (:462), which makes the result a serial chain over the keypoints: s(k+1) = s(k) + c(k, s(k)), where
-// c says whether keypoint k, matched with descriptor s(k), reaches `leftIdx++`.  k_stereo<true> replays that chain exactly: one
-// wave per pair walks the keypoints, the 64 lanes share each keypoint's candidate scan and block match, and the loads a step
-// depends on (the next keypoint, the descriptor rows s and s + 1) are issued one step ahead.  (Solving the chain as a fixed
+// c says whether keypoint k, matched with descriptor s(k), reaches `leftIdx++`.  k_stereo<true> replays that chain exactly: the
+// four waves of a pair's workgroup take the keypoints in turn, each evaluating its keypoint with the index it expects (c = 1 for the
+// keypoints still in flight) and committing in keypoint order once the exact index is published (see the kernel); the 64 lanes of a
+// wave share the keypoint's candidate scan and block match, and the loads a step depends on (the wave's next keypoint, the two descriptor
+// rows its next guess can be) are issued one step ahead.  (Solving the chain as a fixed
 // point of parallel evaluation rounds was measured and dropped: with a lagging index ~3 % of the evaluations still end in a
 // `continue`, each depending on s, so the settled prefix grows by only 10-50 keypoints per round - DESIGN.md.)
 // k_stereo<false> is the per-keypoint form (descriptor and slot = the keypoint's own index, YDORB_STEREO_INDEX_BY_KEYPOINT)
@@ -32,6 +34,11 @@ namespace ydorb {
 constexpr int kStereoChunk = 32;       // left keypoints per workgroup in the per-keypoint form
 constexpr int kStereoMaxRight = 8192;  // right keypoints per pair (LDS table: 8 bytes each)
 constexpr int kStereoOrbDist = (100 + 50) / 2;   // (m_int_highThd + m_int_lowThd) / 2, frame.cpp:365
+#ifndef STEREO_REPLAY_WAVES
+#define STEREO_REPLAY_WAVES 4
+#endif
+constexpr int kStereoReplayWaves = STEREO_REPLAY_WAVES;   // waves that share the serial walk of a pair (1: the plain walk; n: n - 1 steps of speculation;
+                                                            // one pair of 2000 keypoints: 2.40 / 1.71 / 1.37 / 1.21 ms for 1 / 2 / 3 / 4 waves, tools/stereo_chain_time.py)
 
 struct StereoDev {
   const KeyPointDev* kpsL; const uint8_t* descL; const int* nL;
@@ -239,6 +246,8 @@ __global__ __launch_bounds__(256) void k_stereo(const StereoDev P, int kBegin, i
   unsigned* rinfo = reinterpret_cast<unsigned*>(rx + P.capR);
   const int k0 = REPLAY ? 0 : blockIdx.x * kStereoChunk, k1 = REPLAY ? P.capL : min(k0 + kStereoChunk, P.capL);
   if (!REPLAY && k0 >= nL) return;
+  __shared__ int replayTag[8], replayS[8];   // replay form, several waves: the exact index after each step (see below)
+  if (REPLAY && tid < 8) { replayTag[tid] = 0; replayS[tid] = 0; }   // (the table's barrier orders this before the walk)
   stereo_right_table(P, pair, nR, rx, rinfo);
   // Replay form: the right keypoints sorted by the first row of their band (counting sort over the rows, order inside a row arbitrary) -
   // a step of the serial walk then reads the ~90 entries whose band can cover its row instead of scanning every right keypoint.
@@ -298,30 +307,84 @@ __global__ __launch_bounds__(256) void k_stereo(const StereoDev P, int kBegin, i
   float* outRx = P.rightX + (size_t)pair * P.capL;
   float* outDepth = P.depth + (size_t)pair * P.capL;
   if (REPLAY) {
-    if (wave != 0 || nL == 0 || kBegin >= nL) return;
-    // a single wave whose latency is the call's latency: highest issue priority among the waves of its SIMD (the other streams'
+    if (wave >= kStereoReplayWaves || nL == 0 || kBegin >= nL) return;
+    // waves whose latency is the call's latency: highest issue priority among the waves of their SIMD (the other streams'
     // throughput kernels fill the CU and would otherwise get 7 of 8 issue slots)
 #ifndef YDORB_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
-    int s = kBegin > 0 ? P.counters[pair * 4 + 3] : 0;
-    // one step ahead: keypoint k + 1 and descriptor row s + 1 (the row the next step needs is s or s + 1)
-    float kx = kl[kBegin].x, ky = kl[kBegin].y;
-    int o = kl[kBegin].octave;
-    uint4 a0 = dl[2 * s], a1 = dl[2 * s + 1];
     const int kStop = min(kEnd, nL);
-    for (int k = kBegin; k < kStop; k++) {
-      const int kn = min(k + 1, nL - 1), sn = min(s + 1, nL - 1);
-      const float nkx = kl[kn].x, nky = kl[kn].y;
-      const int no = kl[kn].octave;
-      const uint4 n0 = dl[2 * sn], n1 = dl[2 * sn + 1];
-      const StereoRes r = stereo_one(P, pair, kx, ky, o, a0, a1, nR, rx, rinfo, candList[wave], lane, rowStart, rowEnt, bandMax);
-      if (r.kept && lane == 0) { outRx[s] = r.rx; outDepth[s] = r.depth; }
-      A.kept += r.kept; A.zeros += r.zero; A.status |= r.status;
-      if (r.complete) { s++; a0 = n0; a1 = n1; }
-      kx = nkx; ky = nky; o = no;
+    const int sStart = kBegin > 0 ? P.counters[pair * 4 + 3] : 0;
+    if (kStereoReplayWaves == 1) {
+      int s = sStart;
+      // one step ahead: keypoint k + 1 and descriptor row s + 1 (the row the next step needs is s or s + 1)
+      float kx = kl[kBegin].x, ky = kl[kBegin].y;
+      int o = kl[kBegin].octave;
+      uint4 a0 = dl[2 * s], a1 = dl[2 * s + 1];
+      for (int k = kBegin; k < kStop; k++) {
+        const int kn = min(k + 1, nL - 1), sn = min(s + 1, nL - 1);
+        const float nkx = kl[kn].x, nky = kl[kn].y;
+        const int no = kl[kn].octave;
+        const uint4 n0 = dl[2 * sn], n1 = dl[2 * sn + 1];
+        const StereoRes r = stereo_one(P, pair, kx, ky, o, a0, a1, nR, rx, rinfo, candList[wave], lane, rowStart, rowEnt, bandMax);
+        if (r.kept && lane == 0) { outRx[s] = r.rx; outDepth[s] = r.depth; }
+        A.kept += r.kept; A.zeros += r.zero; A.status |= r.status;
+        if (r.complete) { s++; a0 = n0; a1 = n1; }
+        kx = nkx; ky = nky; o = no;
+      }
+      if (lane == 0 && kStop < nL) P.counters[pair * 4 + 3] = s;
+    } else {
+      // NW waves take the keypoints in turn (wave w: k = kBegin + w, + NW, ...).  The index s_k a step needs is s_{k-1} + c of the previous
+      // step - which is still running on another wave - so the step is evaluated with the guess "every keypoint since the last index this
+      // wave knows exactly reaches leftIdx++" (true for ~97 % of the keypoints), checked against the exact s_k the previous step's wave
+      // publishes through LDS when it commits, and evaluated again in the rare other case.  Commits stay in keypoint order (a step commits
+      // only after its predecessor published), so outputs, counters and the hand-over to the next slice are those of the serial walk; NW
+      // steps are in flight instead of one.  replayTag[k & 7] == k + 1 says replayS[k & 7] holds s_{k+1}; commits are in order, so the slot's
+      // next writer (step k + 8) cannot get there before its reader (step k + 1) has committed.  Every step of [kBegin, kStop) is executed
+      // and published, and a wave without steps just leaves: no wave waits for something that never comes.
+      int k = kBegin + wave;
+      int sGuess = min(sStart + wave, nL - 1);
+      float kx = 0.f, ky = 0.f;
+      int o = 0;
+      uint4 a0{}, a1{};
+      if (k < kStop) { kx = kl[k].x; ky = kl[k].y; o = kl[k].octave; a0 = dl[2 * sGuess]; a1 = dl[2 * sGuess + 1]; }
+      int sLast = sStart;
+      constexpr int NW = kStereoReplayWaves;
+      for (; k < kStop; k += NW) {
+        // ahead of their use: this wave's next keypoint and the two descriptor rows its guess can be (s_k + NW - 1 or s_k + NW when the guess holds)
+        const int kn = min(k + NW, nL - 1), sn = min(sGuess + NW - 1, nL - 1), sm = min(sGuess + NW, nL - 1);
+        const float nkx = kl[kn].x, nky = kl[kn].y;
+        const int no = kl[kn].octave;
+        const uint4 n0 = dl[2 * sn], n1 = dl[2 * sn + 1], m0 = dl[2 * sm], m1 = dl[2 * sm + 1];
+        StereoRes r = stereo_one(P, pair, kx, ky, o, a0, a1, nR, rx, rinfo, candList[wave], lane, rowStart, rowEnt, bandMax);
+        int sk = sStart;
+        if (k > kBegin) {
+          const int slot = (k - 1) & 7;
+          while (__hip_atomic_load(&replayTag[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != k) __builtin_amdgcn_s_sleep(1);
+          sk = __hip_atomic_load(&replayS[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        const bool redo = sk != sGuess;
+        if (redo) {
+          a0 = dl[2 * sk]; a1 = dl[2 * sk + 1];
+          r = stereo_one(P, pair, kx, ky, o, a0, a1, nR, rx, rinfo, candList[wave], lane, rowStart, rowEnt, bandMax);
+        }
+        if (r.kept && lane == 0) { outRx[sk] = r.rx; outDepth[sk] = r.depth; }
+        A.kept += r.kept; A.zeros += r.zero; A.status |= r.status;
+        sLast = sk + (r.complete ? 1 : 0);                                   // s_{k+1}
+        if (lane == 0) {
+          __hip_atomic_store(&replayS[k & 7], sLast, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(&replayTag[k & 7], k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        const int gNext = min(sLast + NW - 1, nL - 1);                         // this wave's next step guesses that the steps in between complete
+        if (redo) { a0 = dl[2 * gNext]; a1 = dl[2 * gNext + 1]; }
+        else if (r.complete) { a0 = m0; a1 = m1; }
+        else { a0 = n0; a1 = n1; }
+        sGuess = gNext;
+        kx = nkx; ky = nky; o = no;
+      }
+      // the wave that ran the slice's last step hands s to the next slice
+      if (lane == 0 && kStop < nL && ((kStop - 1 - kBegin) % NW) == wave) P.counters[pair * 4 + 3] = sLast;
     }
-    if (lane == 0 && kStop < nL) P.counters[pair * 4 + 3] = s;
   } else {
     for (int k = k0 + wave; k < min(k1, nL); k += 4) {
       const StereoRes r = stereo_one(P, pair, kl[k].x, kl[k].y, kl[k].octave, dl[2 * k], dl[2 * k + 1], nR, rx, rinfo, candList[wave], lane);
