@@ -40,9 +40,12 @@ namespace {
 struct DBuf {
   void* p = nullptr;
   size_t cap = 0;
+  bool view = false;   // a slice of another DBuf (Ctx::upArena): not owned
+  void setView(void* ptr, size_t bytes) { if (!view && p) (void)hipFree(p); p = ptr; cap = bytes; view = true; }
   int ensure(size_t bytes) {
-    if (bytes <= cap) return YDORB_OK;
-    if (p) (void)hipFree(p);
+    if (bytes <= cap && !view) return YDORB_OK;
+    if (p && !view) (void)hipFree(p);
+    view = false;
     p = nullptr; cap = 0;
     const size_t want = std::max<size_t>(bytes + bytes / 4, 256);
     if (hipMalloc(&p, want) != hipSuccess) { set_error("hipMalloc(%zu) failed", want); return YDORB_ERR_HIP; }
@@ -50,7 +53,7 @@ struct DBuf {
     return YDORB_OK;
   }
   template <class T> T* as() { return reinterpret_cast<T*>(p); }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  void release() { if (p && !view) (void)hipFree(p); p = nullptr; cap = 0; view = false; }
 };
 
 enum { PH_ERR = 0, PH_BUILD, PH_SCHUR, PH_SOLVE, PH_UPDATE, PH_COUNT };
@@ -59,6 +62,8 @@ struct Ctx {  // per-device scratch, reused across calls (localBundleAdjust runs
   int device = -1;
   hipStream_t stream = nullptr;
   DBuf poses[2], pts[2];
+  DBuf upArena;   // the ordered edge arrays and index lists of a stage, laid out like the pinned staging area: ONE upload per stage; the twelve buffers
+                  // below that the host fills (ePose .. ptOf except eInfo0 / eOutlier) are views into it
   DBuf ePose, ePidx, ePt, eMeas, eInfo, eInfo0, eRobust, eOutlier, eLm, ptStart, poseStart, poseEdges, poseOf, ptOf;
   DBuf err, partial, Hll, bl, Hpl, BD, Hpp, bp, S, diagL, diagInv, bs, Dinv, db, xp, xl, yv, scal, status, pairCnt, pairStart, pairCursor, pairA, pairB;
   hipEvent_t ev[2 * PH_COUNT + 2]{};
@@ -76,7 +81,7 @@ struct Ctx {  // per-device scratch, reused across calls (localBundleAdjust runs
   }
   DBuf pStart, pPoses, pX, pMeas, pInfo, pErr, pFlags, pOutlier, pInl, pChi, pTrials;   // pose-only batches
   void releaseBuffers() {   // ydorb_ba_release: device scratch and pinned staging back to the system (stream and events stay)
-    for (DBuf* b : {&poses[0], &poses[1], &pts[0], &pts[1], &ePose, &ePidx, &ePt, &eMeas, &eInfo, &eInfo0, &eRobust, &eOutlier, &eLm, &ptStart,
+    for (DBuf* b : {&poses[0], &poses[1], &pts[0], &pts[1], &upArena, &ePose, &ePidx, &ePt, &eMeas, &eInfo, &eInfo0, &eRobust, &eOutlier, &eLm, &ptStart,
                     &poseStart, &poseEdges, &poseOf, &ptOf, &err, &partial, &Hll, &bl, &Hpl, &BD, &Hpp, &bp, &S, &diagL, &diagInv, &bs, &Dinv, &db,
                     &xp, &xl, &yv, &scal, &status, &pairCnt, &pairStart, &pairCursor, &pairA, &pairB, &pStart, &pPoses, &pX, &pMeas, &pInfo, &pErr,
                     &pFlags, &pOutlier, &pInl, &pChi, &pTrials})
@@ -214,11 +219,7 @@ int prepareStage(Run& R_, bool reuse) {
     const int n = std::max(NB, (6 * nPf + NB - 1) / NB * NB), nb = n / NB;
     const int nBlkE = (Ea + 255) / 256;
     int rc;
-    if ((rc = c.ePose.ensure(sizeof(int) * Ea)) || (rc = c.ePidx.ensure(sizeof(int) * Ea)) || (rc = c.ePt.ensure(sizeof(int) * Ea)) ||
-        (rc = c.eLm.ensure(sizeof(int) * Ea)) || (rc = c.eMeas.ensure(sizeof(double) * 3 * Ea)) || (rc = c.eInfo.ensure(sizeof(double) * Ea)) ||
-        (rc = c.eRobust.ensure(Ea)) || (rc = c.eInfo0.ensure(sizeof(double) * Ea)) || (rc = c.eOutlier.ensure(Ea)) || (rc = c.ptStart.ensure(sizeof(int) * (nL + 1))) || (rc = c.poseStart.ensure(sizeof(int) * (nPf + 1))) ||
-        (rc = c.poseEdges.ensure(sizeof(int) * std::max<size_t>(hPoseEdges.size(), 1))) || (rc = c.poseOf.ensure(sizeof(int) * std::max(nPf, 1))) ||
-        (rc = c.ptOf.ensure(sizeof(int) * nL)) || (rc = c.err.ensure(sizeof(double) * 3 * Ea)) || (rc = c.partial.ensure(sizeof(double) * (nBlkE + (6 * nPf + 3 * nL + 255) / 256 + 1))) ||
+    if ((rc = c.eInfo0.ensure(sizeof(double) * Ea)) || (rc = c.eOutlier.ensure(Ea)) || (rc = c.err.ensure(sizeof(double) * 3 * Ea)) || (rc = c.partial.ensure(sizeof(double) * (nBlkE + (6 * nPf + 3 * nL + 255) / 256 + 1))) ||
         (rc = c.Hll.ensure(sizeof(double) * 6 * nL)) || (rc = c.bl.ensure(sizeof(double) * 3 * nL)) || (rc = c.Hpl.ensure(sizeof(double) * 18 * (size_t)Ea)) ||
         (rc = c.BD.ensure(sizeof(double) * 18 * (size_t)Ea)) ||
         (rc = c.Hpp.ensure(sizeof(double) * 42 * std::max(nPf, 1))) || (rc = c.S.ensure(sizeof(double) * ((size_t)n * n + n))) ||
@@ -232,24 +233,24 @@ int prepareStage(Run& R_, bool reuse) {
       auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
       const size_t total = 4 * al(sizeof(int) * Ea) + al(sizeof(double) * 3 * Ea) + al(sizeof(double) * Ea) + al(Ea) + al(sizeof(int) * (nL + 1)) +
                            al(sizeof(int) * (nPf + 1)) + al(sizeof(int) * ptOf.size()) + al(sizeof(int) * hPoseEdges.size()) + al(sizeof(int) * poseOf.size());
-      if ((rc = c.stage(total))) return rc;
+      if ((rc = c.stage(total)) || (rc = c.upArena.ensure(total))) return rc;
       size_t off = 0;
-      auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
-        if (!bytes) return hipSuccess;
-        memcpy(c.hStage + off, src, bytes);
-        const hipError_t e_ = hipMemcpyAsync(dst, c.hStage + off, bytes, hipMemcpyHostToDevice, s);
+      // every array is copied into the staging area and its device buffer becomes the slice of the arena at the same offset; ONE
+      // hipMemcpyAsync then moves the stage's inputs (twelve calls before: with 16 set-up threads of a batch the runtime's lock was the cost)
+      auto up = [&](DBuf& dst, const void* src, size_t bytes) {
+        if (bytes) memcpy(c.hStage + off, src, bytes);
+        dst.setView(reinterpret_cast<uint8_t*>(c.upArena.p) + off, bytes);
         off += al(bytes);
-        return e_;
       };
-  #define UP(buf, vec, T) HIPCHK(up(c.buf.p, vec.data(), sizeof(T) * vec.size()))
+  #define UP(buf, vec, T) up(c.buf, vec.data(), sizeof(T) * vec.size())
       UP(ePose, hPose, int); UP(ePidx, hPidx, int); UP(ePt, hPt, int); UP(eLm, hLm, int); UP(eMeas, hMeas, double); UP(eInfo, hInfo, double);
+      UP(eRobust, hRobust, uint8_t); UP(ptStart, hPtStart, int); UP(poseStart, hPoseStart, int); UP(ptOf, ptOf, int);
+      UP(poseEdges, hPoseEdges, int); UP(poseOf, poseOf, int);
+  #undef UP
+      if (off) HIPCHK(hipMemcpyAsync(c.upArena.p, c.hStage, off, hipMemcpyHostToDevice, s));
       // the original information: the chi2 tests between and after the stages use it (k_cull)
       HIPCHK(hipMemcpyAsync(c.eInfo0.p, c.eInfo.p, sizeof(double) * Ea, hipMemcpyDeviceToDevice, s));
       HIPCHK(hipMemsetAsync(c.err.p, 0, sizeof(double) * 3 * Ea, s));   // an edge that is never evaluated (stop flag) has error 0
-      UP(eRobust, hRobust, uint8_t); UP(ptStart, hPtStart, int); UP(poseStart, hPoseStart, int); UP(ptOf, ptOf, int);
-      if (!hPoseEdges.empty()) UP(poseEdges, hPoseEdges, int);
-      if (nPf) UP(poseOf, poseOf, int);
-  #undef UP
     }
     trace("optimize: uploads enqueued");
     // pose-pair buckets of the Schur complement (structure is fixed for this optimize() call)
